@@ -1,0 +1,271 @@
+/*
+ * vecchio_amd.h — C ABI of the MI355X-native per-pixel sample loop.
+ *
+ * This is the drop-in boundary for ONE hot path of browserdotsys/vecchio: the closure at
+ * reference src/main.rs:181-198 (pixel loop) and everything it calls (ray_color
+ * main.rs:123-153, BVHNode::hit accel.rs:58-83, every Hittable::hit in hittable.rs, every
+ * Material/Texture/PDF in material.rs / util.rs).  Everything above it (scene.rs builders,
+ * BVHNode::new, the frame loop and the PPM writer of main.rs:155-221) stays on the host
+ * side of this boundary.
+ *
+ * The reference has no FFI of its own (no extern "C" anywhere), so the entry points below
+ * are "what a cgo/FFI binding for this path would bind": one scene upload
+ * (vk_scene_create), one blocking call per camera frame (vk_render) placed where
+ * main.rs:181-198 is today.  The Rust-side binding a maintainer would add is shown in
+ * INTEGRATION.md and vecchio_amd/rust_shim/.
+ *
+ * Conventions
+ *   - plain C, POD structs, caller owns every pointer it passes, library owns the handle.
+ *   - every entry point returns an int status (VK_OK == 0); nothing unwinds across the
+ *     boundary; vk_last_error() gives a thread-local message for the last failure.
+ *   - the scene crosses the boundary as a *graph of tagged records* that mirrors the
+ *     reference's trait objects 1:1 (one record per Arc<dyn Hittable/Material/Texture>),
+ *     so that `flatten()` on the Rust side is a one-record push per object.  The library
+ *     linearises that graph for the GPU itself (threaded pre-order BVH, SoA primitives).
+ */
+#ifndef VECCHIO_AMD_H
+#define VECCHIO_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VK_ABI_VERSION 1
+
+/* ---- status codes (reference convention is panic!/unwrap, main.rs:166,202) ---------- */
+enum {
+    VK_OK = 0,
+    VK_ERR_BAD_ARG = 1,      /* null pointer, bad index, time0>=time1 (main.rs:118 would panic) */
+    VK_ERR_UNSUPPORTED = 2,  /* scene graph shape the device path does not implement      */
+    VK_ERR_HIP = 3,          /* a HIP runtime call failed                                  */
+    VK_ERR_NO_DEVICE = 4,    /* no gfx950 device / HIP runtime unusable                    */
+    VK_ERR_OOM = 5
+};
+
+/* ---- object references -------------------------------------------------------------
+ * A vk_ref names one Arc<dyn Hittable>: kind in bits 31..28, FlipFace parity in bit 27
+ * (FlipFace, hittable.rs:294-312, only negates `front`, so wrapping is an XOR of this
+ * bit), index into the per-kind array in bits 26..0.                                    */
+typedef uint32_t vk_ref;
+enum {
+    VK_KIND_NONE = 0,
+    VK_KIND_BVH = 1,           /* accel.rs:52-56                 */
+    VK_KIND_SPHERE = 2,        /* hittable.rs:46-51              */
+    VK_KIND_MOVING_SPHERE = 3, /* hittable.rs:136-144            */
+    VK_KIND_RECT = 4,          /* hittable.rs:199-210            */
+    VK_KIND_LIST = 5,          /* Vec<Arc<HittableSS>>, hittable.rs:380 (Boxy::sides) */
+    VK_KIND_MEDIUM = 6,        /* hittable.rs:436-440            */
+    VK_KIND_TRANSLATE = 7,     /* hittable.rs:500-504            */
+    VK_KIND_ROTATE = 8         /* hittable.rs:534-539,631,720    */
+};
+#define VK_REF_FLIP 0x08000000u
+#define VK_REF_INDEX_MASK 0x07FFFFFFu
+#define VK_MAKE_REF(kind, index) ((((uint32_t)(kind)) << 28) | ((uint32_t)(index) & VK_REF_INDEX_MASK))
+#define VK_REF_KIND(r) ((r) >> 28)
+#define VK_REF_INDEX(r) ((r) & VK_REF_INDEX_MASK)
+
+/* ---- hittables ---------------------------------------------------------------------- */
+typedef struct vk_bvh_node {   /* accel.rs:52-56 — 32 bytes, the canonical node record */
+    float bb_min[3];
+    float bb_max[3];
+    vk_ref left;
+    vk_ref right;
+} vk_bvh_node;
+
+typedef struct vk_sphere {     /* hittable.rs:47-51; radius may be negative (scene.rs:123-127) */
+    float center[3];
+    float radius;
+    uint32_t material;
+} vk_sphere;
+
+typedef struct vk_moving_sphere { /* hittable.rs:137-144 */
+    float center0[3];
+    float center1[3];
+    float time0, time1;
+    float radius;
+    uint32_t material;
+} vk_moving_sphere;
+
+typedef struct vk_rect {       /* hittable.rs:200-210; XY=(0,1,2) XZ=(0,2,1) YZ=(1,2,0) */
+    float c0, c1, d0, d1, k;
+    uint8_t axis0, axis1, axis2, _pad;
+    uint32_t material;
+} vk_rect;
+
+typedef struct vk_list {       /* Vec<Arc<HittableSS>>: items[first .. first+count) */
+    uint32_t first;
+    uint32_t count;
+} vk_list;
+
+typedef struct vk_medium {     /* hittable.rs:436-440; material = the Isotropic phase function */
+    vk_ref boundary;
+    float neg_inv_density;
+    uint32_t material;
+} vk_medium;
+
+typedef struct vk_translate {  /* hittable.rs:500-504 */
+    vk_ref child;
+    float offset[3];
+} vk_translate;
+
+typedef struct vk_rotate {     /* hittable.rs:534-539 (Y), 631-636 (X), 720-725 (Z) */
+    vk_ref child;
+    uint32_t axis;             /* 0 = RotateX, 1 = RotateY, 2 = RotateZ */
+    float sin_theta, cos_theta;
+} vk_rotate;
+
+/* ---- materials (material.rs) -------------------------------------------------------- */
+enum {
+    VK_MAT_LAMBERTIAN = 0,   /* material.rs:45-109   texture */
+    VK_MAT_METAL = 1,        /* material.rs:111-142  texture, param = fuzz */
+    VK_MAT_DIELECTRIC = 2,   /* material.rs:144-207  param = ref_idx */
+    VK_MAT_DIFFUSE_LIGHT = 3,/* material.rs:209-226  texture = emit */
+    VK_MAT_ISOTROPIC = 4,    /* material.rs:436-465  texture */
+    VK_MAT_SPEC_DIFFUSE = 5  /* material.rs:467-488  a = specular material, b = diffuse material, param = pct */
+};
+typedef struct vk_material {
+    uint32_t kind;
+    uint32_t texture;
+    float param;
+    uint32_t a, b;
+} vk_material;
+
+enum {
+    VK_TEX_SOLID = 0,   /* material.rs:233-242 color            */
+    VK_TEX_CHECKER = 1, /* material.rs:244-259 a = odd, b = even (texture indices) */
+    VK_TEX_IMAGE = 2,   /* material.rs:261-304 a = image index  */
+    VK_TEX_NOISE = 3    /* material.rs:416-434 a = perlin index, scale */
+};
+typedef struct vk_texture {
+    uint32_t kind;
+    float color[3];
+    uint32_t a, b;
+    float scale;
+} vk_texture;
+
+typedef struct vk_image {      /* decoded 8-bit RGB, row 0 = top (material.rs:261-279) */
+    uint32_t width, height;
+    const uint8_t *rgb;        /* width*height*3 bytes */
+} vk_image;
+
+typedef struct vk_perlin {     /* material.rs:306-311 */
+    float ranvec[256][3];
+    uint32_t perm_x[256], perm_y[256], perm_z[256];
+} vk_perlin;
+
+/* ---- the flattened scene ------------------------------------------------------------ */
+typedef struct vk_scene_desc {
+    uint32_t abi_version;      /* must be VK_ABI_VERSION */
+    uint32_t n_bvh;            const vk_bvh_node *bvh;
+    uint32_t n_spheres;        const vk_sphere *spheres;
+    uint32_t n_moving_spheres; const vk_moving_sphere *moving_spheres;
+    uint32_t n_rects;          const vk_rect *rects;
+    uint32_t n_lists;          const vk_list *lists;
+    uint32_t n_list_items;     const vk_ref *list_items;
+    uint32_t n_media;          const vk_medium *media;
+    uint32_t n_translates;     const vk_translate *translates;
+    uint32_t n_rotates;        const vk_rotate *rotates;
+    uint32_t n_materials;      const vk_material *materials;
+    uint32_t n_textures;       const vk_texture *textures;
+    uint32_t n_images;         const vk_image *images;
+    uint32_t n_perlins;        const vk_perlin *perlins;
+    vk_ref world;              /* main.rs:168 world_bvh */
+    uint32_t n_lights;         const vk_ref *lights;  /* main.rs:169 config.lights */
+} vk_scene_desc;
+
+/* ---- camera: the ten fields of main.rs:57-68, computed by Camera::new on the host --- */
+typedef struct vk_camera {
+    float origin[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3], v[3], w[3];
+    float lens_radius;
+    float time0, time1;
+} vk_camera;
+
+/* ---- render parameters: the reference's compile-time constants, made arguments ------ */
+enum {
+    VK_INTEGRATOR_PDF = 0,     /* HEAD ray_color, main.rs:123-153 (scatter_with_pdf + mixture PDF) */
+    VK_INTEGRATOR_SCATTER = 1  /* InOneWeekend/TheNextWeek tags: emitted + attenuation*L via
+                                  Material::scatter (material.rs:21-28,85-90,118-132,150-175,442-446) */
+};
+enum {
+    VK_BACKGROUND_SOLID = 0,   /* main.rs:124 (HEAD: black) */
+    VK_BACKGROUND_SKY = 1      /* InOneWeekend gradient (1-t)*white + t*(0.5,0.7,1.0), t = 0.5*(unit(d).y+1) */
+};
+typedef struct vk_render_params {
+    uint32_t width, height;        /* main.rs:171-172 */
+    uint32_t samples_per_pixel;    /* main.rs:28 */
+    uint32_t max_depth;            /* main.rs:29; depth starts at 1, path stops when depth > max_depth */
+    uint64_t seed;                 /* replaces rand::thread_rng(): counter-based, keyed (seed,pixel,sample) */
+    uint32_t integrator;           /* VK_INTEGRATOR_* */
+    uint32_t background;           /* VK_BACKGROUND_* */
+    float background_color[3];     /* for VK_BACKGROUND_SOLID */
+    /* pixel-tile partition for multi-GPU: 8x8-pixel tiles are dealt round-robin; this call
+     * renders tiles t with t % tile_world == tile_rank.  (0,1) or (0,0) = whole image. */
+    uint32_t tile_rank, tile_world;
+} vk_render_params;
+
+typedef struct vk_stats {
+    uint64_t samples;          /* pixel-samples rendered by this call            */
+    double seconds;            /* wall seconds of the call (incl. gather/copies) */
+    double kernel_ms;          /* HIP-event time of the megakernel launch(es)    */
+    uint32_t kernel_launches;
+    uint32_t scene_in_lds;     /* 1 if the linear BVH + primitives were LDS-resident */
+} vk_stats;
+
+typedef struct vk_scene vk_scene;  /* opaque */
+
+/* replaces: nothing (version handshake for the Rust shim) */
+int vk_abi_version(void);
+/* replaces: nothing (reference is single-device CPU); number of usable gfx950 devices */
+int vk_device_count(void);
+/* replaces: panic!/unwrap messages (main.rs:166,202); thread-local, never NULL */
+const char *vk_last_error(void);
+
+/* replaces: the ownership hand-off at main.rs:168-169 (Arc::new(BVHNode::new(..)),
+ * Arc::new(config.lights)): deep-copies the described graph, linearises it and uploads it
+ * to `device`.  The scene is immutable afterwards and may be rendered many times
+ * (RotatingCamera, scene.rs:65-91).                                                    */
+int vk_scene_create(const vk_scene_desc *desc, int device, vk_scene **out);
+void vk_scene_destroy(vk_scene *scene);
+
+/* replaces: the closure body at main.rs:181-198 for one Camera yielded by cam_iter
+ * (main.rs:176).  Blocking.  rgb_out is caller-owned, width*height*3 floats, index
+ * (y*width + x)*3 with y = 0 the BOTTOM row (main.rs:182-183,209).  Pixels outside this
+ * call's tile partition are left untouched.                                            */
+int vk_render(vk_scene *scene, const vk_camera *cam, const vk_render_params *params,
+              float *rgb_out, vk_stats *stats_out);
+
+/* same as vk_render but the framebuffer is a device pointer on the scene's device and the
+ * work is enqueued on `hip_stream` (a hipStream_t, or NULL for the default stream) without
+ * a host synchronisation; used by the multi-GPU host (one process per GPU) so the RCCL
+ * gather can be enqueued behind it.  stats_out->kernel_ms is not filled.               */
+int vk_render_device(vk_scene *scene, const vk_camera *cam, const vk_render_params *params,
+                     void *d_rgb_out, void *hip_stream, vk_stats *stats_out);
+
+/* replaces: Vec3::to_color (vec3.rs:54-61) applied per pixel at main.rs:211 — sqrt gamma,
+ * clamp to [0,0.999], *256, truncate — plus the top-down row order of main.rs:209.
+ * d_rgb: width*height*3 floats (y up); d_rgb8_out: width*height*3 bytes, row 0 = TOP.  */
+int vk_to_color_device(vk_scene *scene, const void *d_rgb, uint32_t width, uint32_t height,
+                       void *d_rgb8_out, void *hip_stream);
+
+/* introspection used by bench/tests: bytes of the linearised scene, item counts */
+typedef struct vk_scene_info {
+    uint32_t n_items;          /* 32-byte linear BVH records */
+    uint32_t n_prims;          /* primitive records */
+    uint32_t n_instances;
+    uint64_t device_bytes;
+    uint32_t lds_bytes;        /* bytes staged into LDS per workgroup (0 = not resident) */
+    uint32_t features;         /* VKF_* mask of the kernel variant selected */
+} vk_scene_info;
+int vk_scene_get_info(const vk_scene *scene, vk_scene_info *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VECCHIO_AMD_H */

@@ -1,0 +1,350 @@
+// host.cpp — flatten() impls, BVHNode::new, Camera::new (see vecchio_host.hpp)
+#include "vecchio_host.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+namespace vecchio {
+
+static thread_local vk::Rng g_build_rng = vk::rng_for_stream(1, 0);
+vk::Rng &thread_rng() { return g_build_rng; }
+void seed_thread_rng(uint64_t seed) { g_build_rng = vk::rng_for_stream(seed, 0); }
+
+// ------------------------------------------------------------------ FlatBuilder
+uint32_t FlatBuilder::material(const MaterialP &m) {
+    auto it = seen_material.find(m.get());
+    if (it != seen_material.end()) return it->second;
+    uint32_t idx = m->flatten(*this);
+    seen_material[m.get()] = idx;
+    return idx;
+}
+uint32_t FlatBuilder::texture(const TextureP &t) {
+    auto it = seen_texture.find(t.get());
+    if (it != seen_texture.end()) return it->second;
+    uint32_t idx = t->flatten(*this);
+    seen_texture[t.get()] = idx;
+    return idx;
+}
+vk_ref FlatBuilder::hittable(const HittableP &h) {
+    auto it = seen_hittable.find(h.get());
+    if (it != seen_hittable.end()) return it->second;
+    vk_ref r = h->flatten(*this);
+    seen_hittable[h.get()] = r;
+    return r;
+}
+vk_scene_desc FlatBuilder::desc() {
+    for (size_t i = 0; i < images.size(); i++) images[i].rgb = image_storage[i].data();
+    vk_scene_desc d;
+    memset(&d, 0, sizeof(d));
+    d.abi_version = VK_ABI_VERSION;
+    d.n_bvh = (uint32_t)bvh.size(); d.bvh = bvh.data();
+    d.n_spheres = (uint32_t)spheres.size(); d.spheres = spheres.data();
+    d.n_moving_spheres = (uint32_t)moving_spheres.size(); d.moving_spheres = moving_spheres.data();
+    d.n_rects = (uint32_t)rects.size(); d.rects = rects.data();
+    d.n_lists = (uint32_t)lists.size(); d.lists = lists.data();
+    d.n_list_items = (uint32_t)list_items.size(); d.list_items = list_items.data();
+    d.n_media = (uint32_t)media.size(); d.media = media.data();
+    d.n_translates = (uint32_t)translates.size(); d.translates = translates.data();
+    d.n_rotates = (uint32_t)rotates.size(); d.rotates = rotates.data();
+    d.n_materials = (uint32_t)materials.size(); d.materials = materials.data();
+    d.n_textures = (uint32_t)textures.size(); d.textures = textures.data();
+    d.n_images = (uint32_t)images.size(); d.images = images.data();
+    d.n_perlins = (uint32_t)perlins.size(); d.perlins = perlins.data();
+    d.world = world;
+    d.n_lights = (uint32_t)lights.size(); d.lights = lights.data();
+    return d;
+}
+
+// ------------------------------------------------------------------ textures
+uint32_t SolidColor::flatten(FlatBuilder &b) const {
+    vk_texture t; memset(&t, 0, sizeof(t));
+    t.kind = VK_TEX_SOLID; t.color[0] = color_value.x; t.color[1] = color_value.y; t.color[2] = color_value.z;
+    b.textures.push_back(t);
+    return (uint32_t)b.textures.size() - 1;
+}
+uint32_t Checker::flatten(FlatBuilder &b) const {
+    vk_texture t; memset(&t, 0, sizeof(t));
+    t.kind = VK_TEX_CHECKER; t.a = b.texture(odd); t.b = b.texture(even);
+    b.textures.push_back(t);
+    return (uint32_t)b.textures.size() - 1;
+}
+uint32_t ImageTexture::flatten(FlatBuilder &b) const {
+    b.image_storage.push_back(buf);
+    vk_image im; im.width = width; im.height = height; im.rgb = nullptr;  // pointer fixed up after all pushes
+    b.images.push_back(im);
+    vk_texture t; memset(&t, 0, sizeof(t));
+    t.kind = VK_TEX_IMAGE; t.a = (uint32_t)b.images.size() - 1;
+    b.textures.push_back(t);
+    return (uint32_t)b.textures.size() - 1;
+}
+std::shared_ptr<ImageTexture> ImageTexture::from_ppm(const std::string &path) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    char magic[3] = {0, 0, 0};
+    unsigned w = 0, h = 0, maxv = 0;
+    if (fscanf(f, "%2s %u %u %u", magic, &w, &h, &maxv) != 4 || strcmp(magic, "P6") != 0 || maxv != 255 || !w || !h) {
+        fclose(f);
+        throw std::runtime_error("not a binary 8-bit PPM: " + path);
+    }
+    fgetc(f);
+    std::vector<uint8_t> rgb((size_t)w * h * 3);
+    size_t got = fread(rgb.data(), 1, rgb.size(), f);
+    fclose(f);
+    if (got != rgb.size()) throw std::runtime_error("short PPM: " + path);
+    return std::make_shared<ImageTexture>(w, h, std::move(rgb));
+}
+std::shared_ptr<ImageTexture> ImageTexture::synthetic_earth(uint32_t w, uint32_t h, uint64_t seed) {
+    // Deterministic "continents": a few octaves of value noise thresholded into land/sea/ice.
+    // Stands in for assets/earthmap.png (1024x512 RGB8), which cannot ship to the GPU box.
+    std::vector<uint8_t> rgb((size_t)w * h * 3);
+    auto hash = [seed](int32_t x, int32_t y, int32_t o) {
+        uint64_t k = vk::mix64(seed * 0x9E3779B97F4A7C15ull + ((uint64_t)(uint32_t)x << 32 | (uint32_t)y) + (uint64_t)o * 0xD1B54A32D192ED03ull);
+        return (float)(k >> 40) * (1.0f / 16777216.0f);
+    };
+    for (uint32_t j = 0; j < h; j++)
+        for (uint32_t i = 0; i < w; i++) {
+            float v = 0.0f, amp = 0.5f;
+            for (int o = 0; o < 5; o++) {
+                float cells = (float)(4 << o);
+                float fx = (float)i / (float)w * cells, fy = (float)j / (float)h * cells * 0.5f;
+                int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+                float tx = fx - (float)x0, ty = fy - (float)y0;
+                int wrap = (int)cells;
+                float a = hash(x0 % wrap, y0, o), bq = hash((x0 + 1) % wrap, y0, o), c = hash(x0 % wrap, y0 + 1, o), d = hash((x0 + 1) % wrap, y0 + 1, o);
+                tx = tx * tx * (3.0f - 2.0f * tx); ty = ty * ty * (3.0f - 2.0f * ty);
+                v += amp * ((a * (1 - tx) + bq * tx) * (1 - ty) + (c * (1 - tx) + d * tx) * ty);
+                amp *= 0.5f;
+            }
+            float lat = fabsf((float)j / (float)h - 0.5f) * 2.0f;
+            uint8_t *p = &rgb[((size_t)j * w + i) * 3];
+            if (lat > 0.88f) { p[0] = 235; p[1] = 240; p[2] = 245; }
+            else if (v > 0.5f) { float g = (v - 0.5f) * 4.0f; p[0] = (uint8_t)(60 + 90 * g); p[1] = (uint8_t)(110 + 40 * g); p[2] = (uint8_t)(50 + 30 * g); }
+            else { float s = v * 2.0f; p[0] = (uint8_t)(10 + 20 * s); p[1] = (uint8_t)(30 + 60 * s); p[2] = (uint8_t)(90 + 110 * s); }
+        }
+    return std::make_shared<ImageTexture>(w, h, std::move(rgb));
+}
+
+Perlin::Perlin() {  // material.rs:357-377
+    for (int i = 0; i < 256; i++) random_data[i] = Vec3::random_range(-1.0f, 1.0f).unit_vector();
+    for (uint32_t i = 0; i < 256; i++) { perm_x[i] = i; perm_y[i] = i; perm_z[i] = i; }
+    // SliceRandom::shuffle (rand 0.7.3): for i in (1..len).rev() { swap(i, gen_index(i+1)) }
+    auto shuffle = [](uint32_t *p) {
+        for (uint32_t i = 255; i >= 1; i--) std::swap(p[i], p[gen_index(i + 1)]);
+    };
+    shuffle(perm_x); shuffle(perm_y); shuffle(perm_z);
+}
+uint32_t NoiseTexture::flatten(FlatBuilder &b) const {
+    vk_perlin p;
+    for (int i = 0; i < 256; i++) {
+        p.ranvec[i][0] = noise.random_data[i].x; p.ranvec[i][1] = noise.random_data[i].y; p.ranvec[i][2] = noise.random_data[i].z;
+        p.perm_x[i] = noise.perm_x[i]; p.perm_y[i] = noise.perm_y[i]; p.perm_z[i] = noise.perm_z[i];
+    }
+    b.perlins.push_back(p);
+    vk_texture t; memset(&t, 0, sizeof(t));
+    t.kind = VK_TEX_NOISE; t.a = (uint32_t)b.perlins.size() - 1; t.scale = scale;
+    b.textures.push_back(t);
+    return (uint32_t)b.textures.size() - 1;
+}
+
+// ------------------------------------------------------------------ materials
+static uint32_t push_mat(FlatBuilder &b, uint32_t kind, uint32_t tex, float param, uint32_t a = 0, uint32_t bb = 0) {
+    vk_material m; m.kind = kind; m.texture = tex; m.param = param; m.a = a; m.b = bb;
+    b.materials.push_back(m);
+    return (uint32_t)b.materials.size() - 1;
+}
+uint32_t Lambertian::flatten(FlatBuilder &b) const { return push_mat(b, VK_MAT_LAMBERTIAN, b.texture(albedo), 0.0f); }
+uint32_t Metal::flatten(FlatBuilder &b) const { return push_mat(b, VK_MAT_METAL, b.texture(albedo), fuzz); }
+uint32_t Dielectric::flatten(FlatBuilder &b) const { return push_mat(b, VK_MAT_DIELECTRIC, 0, ref_idx); }
+uint32_t DiffuseLight::flatten(FlatBuilder &b) const { return push_mat(b, VK_MAT_DIFFUSE_LIGHT, b.texture(emit), 0.0f); }
+uint32_t Isotropic::flatten(FlatBuilder &b) const { return push_mat(b, VK_MAT_ISOTROPIC, b.texture(albedo), 0.0f); }
+uint32_t SpecDiffuse::flatten(FlatBuilder &b) const {
+    uint32_t s = b.material(specular), d = b.material(diffuse);
+    return push_mat(b, VK_MAT_SPEC_DIFFUSE, 0, pct, s, d);
+}
+
+// ------------------------------------------------------------------ hittables
+vk_ref Sphere::flatten(FlatBuilder &b) const {
+    vk_sphere s; s.center[0] = center.x; s.center[1] = center.y; s.center[2] = center.z; s.radius = radius; s.material = b.material(material);
+    b.spheres.push_back(s);
+    return VK_MAKE_REF(VK_KIND_SPHERE, b.spheres.size() - 1);
+}
+vk_ref MovingSphere::flatten(FlatBuilder &b) const {
+    vk_moving_sphere s;
+    s.center0[0] = center0.x; s.center0[1] = center0.y; s.center0[2] = center0.z;
+    s.center1[0] = center1.x; s.center1[1] = center1.y; s.center1[2] = center1.z;
+    s.time0 = time0; s.time1 = time1; s.radius = radius; s.material = b.material(material);
+    b.moving_spheres.push_back(s);
+    return VK_MAKE_REF(VK_KIND_MOVING_SPHERE, b.moving_spheres.size() - 1);
+}
+vk_ref Rect::flatten(FlatBuilder &b) const {
+    vk_rect r; r.c0 = c0; r.c1 = c1; r.d0 = d0; r.d1 = d1; r.k = k;
+    r.axis0 = (uint8_t)axis0; r.axis1 = (uint8_t)axis1; r.axis2 = (uint8_t)axis2; r._pad = 0; r.material = b.material(mat);
+    b.rects.push_back(r);
+    return VK_MAKE_REF(VK_KIND_RECT, b.rects.size() - 1);
+}
+vk_ref FlipFace::flatten(FlatBuilder &b) const { return b.hittable(ptr) ^ VK_REF_FLIP; }  // only negates `front`
+
+Boxy::Boxy(Vec3 p0, Vec3 p1, MaterialP mat) : box_min(p0), box_max(p1) {  // hittable.rs:321-359
+    assert(p0.x < p1.x); assert(p0.y < p1.y); assert(p0.z < p1.z);
+    sides.push_back(Rect::XYRect(p0.x, p1.x, p0.y, p1.y, p1.z, mat));
+    sides.push_back(std::make_shared<FlipFace>(Rect::XYRect(p0.x, p1.x, p0.y, p1.y, p0.z, mat)));
+    sides.push_back(Rect::XZRect(p0.x, p1.x, p0.z, p1.z, p1.y, mat));
+    sides.push_back(std::make_shared<FlipFace>(Rect::XZRect(p0.x, p1.x, p0.z, p1.z, p0.y, mat)));
+    sides.push_back(Rect::YZRect(p0.y, p1.y, p0.z, p1.z, p1.x, mat));
+    sides.push_back(std::make_shared<FlipFace>(Rect::YZRect(p0.y, p1.y, p0.z, p1.z, p0.x, mat)));
+}
+static vk_ref flatten_list(FlatBuilder &b, const std::vector<HittableP> &items) {
+    std::vector<vk_ref> refs;
+    for (auto &h : items) refs.push_back(b.hittable(h));
+    vk_list l; l.first = (uint32_t)b.list_items.size(); l.count = (uint32_t)refs.size();
+    b.list_items.insert(b.list_items.end(), refs.begin(), refs.end());
+    b.lists.push_back(l);
+    return VK_MAKE_REF(VK_KIND_LIST, b.lists.size() - 1);
+}
+vk_ref Boxy::flatten(FlatBuilder &b) const { return flatten_list(b, sides); }  // Boxy::hit forwards to sides (hittable.rs:362-365)
+std::optional<AxisBB> HittableList::bounding_box(float t0, float t1) const {  // hittable.rs:396-418
+    if (items.empty()) return std::nullopt;
+    std::optional<AxisBB> out;
+    bool first = true;
+    for (auto &o : items) {
+        auto bb = o->bounding_box(t0, t1);
+        if (!bb) return std::nullopt;
+        out = first ? *bb : AxisBB::surrounding_box(*bb, *out);
+        first = false;
+    }
+    return out;
+}
+vk_ref HittableList::flatten(FlatBuilder &b) const { return flatten_list(b, items); }
+vk_ref ConstantMedium::flatten(FlatBuilder &b) const {
+    vk_medium m; m.boundary = b.hittable(boundary); m.neg_inv_density = neg_inv_density; m.material = b.material(phase_function);
+    b.media.push_back(m);
+    return VK_MAKE_REF(VK_KIND_MEDIUM, b.media.size() - 1);
+}
+vk_ref Translate::flatten(FlatBuilder &b) const {
+    vk_translate t; t.child = b.hittable(ptr); t.offset[0] = offset.x; t.offset[1] = offset.y; t.offset[2] = offset.z;
+    b.translates.push_back(t);
+    return VK_MAKE_REF(VK_KIND_TRANSLATE, b.translates.size() - 1);
+}
+Rotate::Rotate(HittableP p, int axis_, float angle) : ptr(p), axis(axis_) {  // hittable.rs:542-575, 639-672, 728-761
+    sin_theta = sinf(to_radians(angle));
+    cos_theta = cosf(to_radians(angle));
+    AxisBB bbox = *p->bounding_box(0.0f, 1.0f);
+    Vec3 mn = Vec3::new_const(INFINITY), mx = Vec3::new_const(-INFINITY);
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
+            for (int k = 0; k < 2; k++) {
+                float x = i == 1 ? bbox.max.x : bbox.min.x;
+                float y = j == 1 ? bbox.max.y : bbox.min.y;
+                float z = k == 1 ? bbox.max.z : bbox.min.z;
+                Vec3 tester;
+                if (axis == 1) tester = Vec3(cos_theta * x + sin_theta * z, y, -sin_theta * x + cos_theta * z);
+                else if (axis == 0) tester = Vec3(x, cos_theta * y - sin_theta * z, sin_theta * y + cos_theta * z);
+                else tester = Vec3(cos_theta * x - sin_theta * y, sin_theta * x + cos_theta * y, z);
+                for (int c = 0; c < 3; c++) { mn[c] = fminf(mn[c], tester[c]); mx[c] = fmaxf(mx[c], tester[c]); }
+            }
+    bb = AxisBB{mn, mx};
+}
+vk_ref Rotate::flatten(FlatBuilder &b) const {
+    vk_rotate r; r.child = b.hittable(ptr); r.axis = (uint32_t)axis; r.sin_theta = sin_theta; r.cos_theta = cos_theta;
+    b.rotates.push_back(r);
+    return VK_MAKE_REF(VK_KIND_ROTATE, b.rotates.size() - 1);
+}
+
+// accel.rs:98-136
+std::shared_ptr<BVHNode> BVHNode::build(std::vector<HittableP> &objects, size_t begin, size_t end) {
+    uint32_t axis = gen_index(3);  // rng.gen_range(0, 3)
+    size_t len = end - begin;
+    if (len == 0) throw std::runtime_error("BVHNode::new on an empty slice (index out of bounds in the reference)");
+    auto node = std::make_shared<BVHNode>();
+    auto bbox = [](const HittableP &h) {
+        auto bb = h->bounding_box(0.0f, 0.0f);
+        if (!bb) throw std::runtime_error("bounding_box() is None (unwrap panics, accel.rs:93)");
+        return *bb;
+    };
+    if (len == 1) {
+        node->left = objects[begin]; node->right = objects[begin];
+        node->bb = AxisBB::surrounding_box(bbox(objects[begin]), bbox(objects[begin]));
+    } else if (len == 2) {
+        AxisBB a_bb = bbox(objects[begin]), b_bb = bbox(objects[begin + 1]);
+        size_t i1 = begin, i2 = begin + 1;
+        if (a_bb.min[(int)axis] < b_bb.min[(int)axis]) { i1 = begin + 1; i2 = begin; }  // sic: larger min goes LEFT
+        node->left = objects[i1]; node->right = objects[i2];
+        node->bb = AxisBB::surrounding_box(bbox(objects[i1]), bbox(objects[i2]));
+    } else {
+        // slice::sort_by is a stable merge sort; partial_cmp().unwrap() panics on NaN
+        std::vector<std::pair<float, HittableP>> keyed;
+        keyed.reserve(len);
+        for (size_t i = begin; i < end; i++) {
+            float k = bbox(objects[i]).min[(int)axis];
+            if (k != k) throw std::runtime_error("NaN in bounding box (partial_cmp unwrap panics, accel.rs:125)");
+            keyed.emplace_back(k, objects[i]);
+        }
+        std::stable_sort(keyed.begin(), keyed.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+        for (size_t i = 0; i < len; i++) objects[begin + i] = keyed[i].second;
+        keyed.clear(); keyed.shrink_to_fit();
+        size_t mid = begin + len / 2;
+        auto l = build(objects, begin, mid);
+        auto r = build(objects, mid, end);
+        node->left = l; node->right = r;
+        node->bb = AxisBB::surrounding_box(l->bb, r->bb);
+    }
+    return node;
+}
+vk_ref BVHNode::flatten(FlatBuilder &b) const {
+    vk_bvh_node n;
+    n.bb_min[0] = bb.min.x; n.bb_min[1] = bb.min.y; n.bb_min[2] = bb.min.z;
+    n.bb_max[0] = bb.max.x; n.bb_max[1] = bb.max.y; n.bb_max[2] = bb.max.z;
+    size_t idx = b.bvh.size();
+    b.bvh.push_back(n);
+    vk_ref l = b.hittable(left);
+    vk_ref r = b.hittable(right);
+    b.bvh[idx].left = l; b.bvh[idx].right = r;
+    return VK_MAKE_REF(VK_KIND_BVH, idx);
+}
+
+// main.rs:71-109
+vk_camera camera_new(Vec3 lookfrom, Vec3 lookat, Vec3 vup, float vfov, float aspect_ratio, float aperture,
+                     float focus_dist, float time0, float time1) {
+    float theta = to_radians(vfov);
+    float h = tanf(theta / 2.0f);
+    float viewport_height = h * 2.0f;
+    float viewport_width = aspect_ratio * viewport_height;
+    Vec3 w = (lookfrom - lookat).unit_vector();
+    Vec3 u = vup.cross(w).unit_vector();
+    Vec3 v = w.cross(u);
+    Vec3 origin = lookfrom;
+    Vec3 horizontal = u * viewport_width * focus_dist;
+    Vec3 vertical = v * viewport_height * focus_dist;
+    Vec3 llc = origin - horizontal / 2.0f - vertical / 2.0f - w * focus_dist;
+    vk_camera c;
+    auto put = [](float *d, Vec3 s) { d[0] = s.x; d[1] = s.y; d[2] = s.z; };
+    put(c.origin, origin); put(c.lower_left_corner, llc); put(c.horizontal, horizontal); put(c.vertical, vertical);
+    put(c.u, u); put(c.v, v); put(c.w, w);
+    c.lens_radius = aperture / 2.0f; c.time0 = time0; c.time1 = time1;
+    return c;
+}
+
+std::function<bool(vk_camera &)> FixedCamera(vk_camera cam) {  // scene.rs:24-46
+    auto called = std::make_shared<bool>(false);
+    return [cam, called](vk_camera &out) {
+        if (*called) return false;
+        *called = true; out = cam; return true;
+    };
+}
+std::function<bool(vk_camera &)> RotatingCamera(Vec3 lookat, Vec3 vup, float vfov, float aspect_ratio, float aperture,
+                                                float focus_dist, float time0, float time1, float height, float angle,
+                                                float radius, float incr, float limit) {  // scene.rs:48-91
+    auto ang = std::make_shared<float>(angle);
+    return [=](vk_camera &out) {
+        if (*ang > limit) return false;
+        float look_x = radius * cosf(to_radians(*ang));
+        float look_z = radius * sinf(to_radians(*ang));
+        out = camera_new(Vec3(look_x, height, look_z), lookat, vup, vfov, aspect_ratio, aperture, focus_dist, time0, time1);
+        *ang += incr;
+        return true;
+    };
+}
+
+}  // namespace vecchio

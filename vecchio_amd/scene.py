@@ -1,0 +1,109 @@
+"""Python handles over the two product libraries.
+
+HostScene  = a scene built by the C++ mirror of scene.rs (libvecchio_host.so) and flattened
+             into a vk_scene_desc (what the Rust shim's flatten() would hand over).
+DeviceScene = that description uploaded through the C ABI (vk_scene_create) to one MI355X;
+             render() is one call of the drop-in for main.rs:181-198.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import ffi
+
+
+class HostScene:
+    def __init__(self, name, seed=1):
+        self._lib = ffi.load_host_lib()
+        self._h = self._lib.vkh_scene_build(name.encode(), seed)
+        if not self._h:
+            raise RuntimeError(self._lib.vkh_last_error().decode())
+        self.name = name
+        self.desc = self._lib.vkh_scene_desc(self._h)  # POINTER(SceneDesc), owned by the handle
+        ar, integ, bg = C.c_float(), C.c_uint32(), C.c_uint32()
+        col = ffi.F3()
+        self._lib.vkh_scene_defaults(self._h, C.byref(ar), C.byref(integ), C.byref(bg), col)
+        self.aspect_ratio = ar.value
+        self.integrator = integ.value
+        self.background = bg.value
+        self.background_color = tuple(col)
+
+    def next_camera(self):
+        cam = ffi.Camera()
+        if not self._lib.vkh_scene_next_camera(self._h, C.byref(cam)):
+            return None
+        return cam
+
+    def params(self, width, spp, max_depth, seed=2, height=None, tile_rank=0, tile_world=1):
+        """vk_render_params with the scene's integrator/background; height = width/aspect (main.rs:172)."""
+        p = ffi.RenderParams()
+        p.width = width
+        p.height = height if height is not None else int(np.float32(width) / np.float32(self.aspect_ratio))
+        p.samples_per_pixel = spp
+        p.max_depth = max_depth
+        p.seed = seed
+        p.integrator = self.integrator
+        p.background = self.background
+        p.background_color = ffi.F3(*self.background_color)
+        p.tile_rank = tile_rank
+        p.tile_world = tile_world
+        return p
+
+    def close(self):
+        if self._h:
+            self._lib.vkh_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def check(lib, status):
+    if status != ffi.VK_OK:
+        raise RuntimeError(f"vecchio_amd status {status}: {lib.vk_last_error().decode()}")
+
+
+class DeviceScene:
+    def __init__(self, desc, device=0):
+        self._lib = ffi.load_device_lib()
+        h = C.c_void_p()
+        check(self._lib, self._lib.vk_scene_create(desc, device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def info(self):
+        inf = ffi.SceneInfo()
+        check(self._lib, self._lib.vk_scene_get_info(self._h, C.byref(inf)))
+        return inf
+
+    def render(self, cam, params, out=None):
+        """Blocking render into a host numpy array (height, width, 3) float32, y = 0 bottom row."""
+        if out is None:
+            out = np.zeros((params.height, params.width, 3), dtype=np.float32)
+        stats = ffi.Stats()
+        check(self._lib, self._lib.vk_render(self._h, C.byref(cam), C.byref(params), out.ctypes.data_as(C.c_void_p), C.byref(stats)))
+        return out, stats
+
+    def render_device(self, cam, params, d_ptr, stream=None):
+        """Enqueue a render into device memory at d_ptr on `stream` (no host sync)."""
+        stats = ffi.Stats()
+        check(self._lib, self._lib.vk_render_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(d_ptr),
+                                                    C.c_void_p(stream or 0), C.byref(stats)))
+        return stats
+
+    def to_color_device(self, d_rgb, width, height, d_rgb8, stream=None):
+        check(self._lib, self._lib.vk_to_color_device(self._h, C.c_void_p(d_rgb), width, height, C.c_void_p(d_rgb8), C.c_void_p(stream or 0)))
+
+    def close(self):
+        if self._h:
+            self._lib.vk_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
