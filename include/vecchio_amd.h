@@ -265,6 +265,18 @@ typedef struct vk_scene_info {
 } vk_scene_info;
 int vk_scene_get_info(const vk_scene *scene, vk_scene_info *out);
 
+/* ---- diagnostics (used by tests/ and bench.py; not needed by the Rust shim) ------------ */
+/* HIP-event time (ms) of the launches enqueued by the last vk_render / vk_render_device on
+ * this scene, on the stream they were launched on; waits for their end event.            */
+int vk_scene_last_kernel_ms(vk_scene *scene, double *ms_out);
+/* as vk_render, also returning every sample: samples_out[(pixel*spp + s)*4 + 0..2] = radiance
+ * before the finite filter (main.rs:192), [+3] = the sample's u32 draw count (bit pattern) */
+int vk_debug_render_samples(vk_scene *scene, const vk_camera *cam, const vk_render_params *params,
+                            float *rgb_out, float *samples_out);
+/* evaluate the shared host/device arithmetic ON THE DEVICE (host arrays in/out):
+ * op 0 sin, 1 cos, 2 ln, 3 asin, 4 atan2(a,b), 5 pow5, 6 a/b, 7 sqrt(a), 8 draws, 9 a*b+a  */
+int vk_debug_math(int device, int op, const float *a, const float *b, float *out, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1082,8 +1082,21 @@ extern "C" {
 
 const char *oracle_last_error(void) { return g_err.c_str(); }
 
+static int oracle_render_impl(const vk_scene_desc *desc, const vk_camera *cam_in, const vk_render_params *params,
+                              float *rgb_out, int n_threads, oracle_counters *counters_out, float *per_sample_out);
+
 int oracle_render(const vk_scene_desc *desc, const vk_camera *cam_in, const vk_render_params *params,
                   float *rgb_out, int n_threads, oracle_counters *counters_out) {
+    return oracle_render_impl(desc, cam_in, params, rgb_out, n_threads, counters_out, nullptr);
+}
+
+int oracle_render_samples(const vk_scene_desc *desc, const vk_camera *cam_in, const vk_render_params *params,
+                          float *rgb_out, float *per_sample_out, int n_threads) {
+    return oracle_render_impl(desc, cam_in, params, rgb_out, n_threads, nullptr, per_sample_out);
+}
+
+static int oracle_render_impl(const vk_scene_desc *desc, const vk_camera *cam_in, const vk_render_params *params,
+                              float *rgb_out, int n_threads, oracle_counters *counters_out, float *per_sample_out) {
     g_err.clear();
     if (!rgb_out) { g_err = "null output"; return VK_ERR_BAD_ARG; }
     if (!check_params(cam_in, params)) return VK_ERR_BAD_ARG;
@@ -1116,6 +1129,12 @@ int oracle_render(const vk_scene_desc *desc, const vk_camera *cam_in, const vk_r
                     g_rng = &rng;
                     Vec3 color = trace_sample(ctx, cam, p, x, y);
                     g_cnt.samples++;
+                    if (per_sample_out) {
+                        float *o = per_sample_out + ((size_t)i * p.samples_per_pixel + s) * 4;
+                        o[0] = color.x; o[1] = color.y; o[2] = color.z;
+                        uint32_t dr = rng.ctr;
+                        memcpy(&o[3], &dr, 4);
+                    }
                     if (std::isfinite(color.x) && std::isfinite(color.y) && std::isfinite(color.z)) {  // main.rs:192-194
                         c = c + color;
                     } else {

@@ -42,6 +42,11 @@ typedef struct oracle_counters {
 int oracle_render(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *params,
                   float *rgb_out, int n_threads, oracle_counters *counters_out);
 
+/* As oracle_render, also storing every sample: per_sample_out[(pixel*spp + s)*4 + 0..2] =
+ * radiance before the finite filter, [+3] = the sample's u32 draw count (bit pattern).   */
+int oracle_render_samples(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *params,
+                          float *rgb_out, float *per_sample_out, int n_threads);
+
 /* Trace ONE sample of ONE pixel; returns its radiance (before the finite filter) and the
  * number of u32 draws it consumed.  Debug aid for per-sample parity.                   */
 int oracle_sample(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *params,

@@ -1,0 +1,110 @@
+// emu.cpp — TEST TOOL: runs the megakernel's per-lane logic (vecchio_amd/csrc/vk_trace.h) and
+// the lineariser on the host, one sample at a time, so the iterative/deferred/threaded
+// formulation can be compared with the recursive oracle WITHOUT a GPU.  It is built only
+// under tests/, is not part of libvecchio_amd.so and is never reachable from the C ABI.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <atomic>
+#include <vector>
+
+#include "../../vecchio_amd/csrc/vk_linearize.h"
+#include "../../vecchio_amd/csrc/vk_trace.h"
+
+using namespace vkd;
+
+static thread_local std::string g_err;
+
+template <uint32_t F>
+static void trace_one(const DScene &S, const GlobalMem &M, const RenderConsts &C, uint32_t pixel, uint32_t sample, V3 &rgb, uint32_t &draws, uint64_t *steps) {
+    Lane L;
+    start_sample(L, S, C, pixel % C.width, pixel / C.width, sample);
+    for (;;) {
+        while (traversing(L)) { traverse_step<F, GlobalMem>(L, S, M); if (steps) (*steps)++; }
+        if (!shade<F, GlobalMem>(L, S, M, C)) break;
+    }
+    rgb = L.acc;
+    draws = L.rng.ctr;
+}
+
+static RenderConsts make_consts(const vk_camera *cam, const vk_render_params *p) {
+    RenderConsts C;
+    C.cam = *cam;
+    C.width = p->width; C.height = p->height; C.spp = p->samples_per_pixel; C.max_depth = p->max_depth;
+    C.seed = p->seed; C.integrator = p->integrator; C.background = p->background;
+    C.bg[0] = p->background_color[0]; C.bg[1] = p->background_color[1]; C.bg[2] = p->background_color[2];
+    return C;
+}
+
+extern "C" {
+
+const char *emu_last_error(void) { return g_err.c_str(); }
+
+// full-feature variant only (the GPU picks leaner variants; logic is the same code)
+static const uint32_t FALL = 0x7Fu;
+static const uint32_t FPDF = 0x7Fu | VKF_INTEG_PDF;
+
+int emu_sample(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *p, uint32_t pixel, uint32_t sample,
+               float rgb[3], uint32_t *draws) {
+    LinearScene LS;
+    int st = linearize(desc, LS, g_err);
+    if (st != VK_OK) return st;
+    DScene S = LS.host_view();
+    GlobalMem M{S.items, S.spheres, S.sphere_mat};
+    RenderConsts C = make_consts(cam, p);
+    V3 c; uint32_t dr;
+    if (p->integrator == VK_INTEGRATOR_PDF) trace_one<FPDF>(S, M, C, pixel, sample, c, dr, nullptr);
+    else trace_one<FALL>(S, M, C, pixel, sample, c, dr, nullptr);
+    rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+    if (draws) *draws = dr;
+    return VK_OK;
+}
+
+// per-sample outputs: out_rgbd[(pixel*spp + s)*4 + {0,1,2}] = radiance, [3] = draw count (as float bits of uint)
+int emu_render(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *p, float *rgb_out,
+               float *per_sample_out, int n_threads, uint64_t *steps_out, uint32_t *info_out) {
+    LinearScene LS;
+    int st = linearize(desc, LS, g_err);
+    if (st != VK_OK) return st;
+    if (p->integrator == VK_INTEGRATOR_PDF && LS.lights.empty()) { g_err = "PDF integrator needs a non-empty lights list (hittable.rs:431 would panic)"; return VK_ERR_UNSUPPORTED; }
+    DScene S = LS.host_view();
+    GlobalMem M{S.items, S.spheres, S.sphere_mat};
+    RenderConsts C = make_consts(cam, p);
+    if (info_out) { info_out[0] = S.n_items; info_out[1] = LS.n_prims; info_out[2] = (uint32_t)LS.instances.size(); info_out[3] = LS.features; }
+    if (n_threads < 1) n_threads = 1;
+    std::atomic<uint32_t> next_row(0);
+    std::atomic<uint64_t> total_steps(0);
+    auto worker = [&]() {
+        uint64_t steps = 0;
+        for (;;) {
+            uint32_t y = next_row.fetch_add(1);
+            if (y >= p->height) break;
+            for (uint32_t x = 0; x < p->width; x++) {
+                uint32_t pix = y * p->width + x;
+                V3 sum = v3s(0.0f);
+                for (uint32_t s = 0; s < p->samples_per_pixel; s++) {
+                    V3 c; uint32_t dr;
+                    if (p->integrator == VK_INTEGRATOR_PDF) trace_one<FPDF>(S, M, C, pix, s, c, dr, &steps);
+                    else trace_one<FALL>(S, M, C, pix, s, c, dr, &steps);
+                    if (per_sample_out) {
+                        float *o = per_sample_out + ((size_t)pix * p->samples_per_pixel + s) * 4;
+                        o[0] = c.x; o[1] = c.y; o[2] = c.z; memcpy(&o[3], &dr, 4);
+                    }
+                    if (std::isfinite(c.x) && std::isfinite(c.y) && std::isfinite(c.z)) sum = sum + c;
+                }
+                sum = sum / (float)p->samples_per_pixel;
+                rgb_out[(size_t)pix * 3 + 0] = sum.x; rgb_out[(size_t)pix * 3 + 1] = sum.y; rgb_out[(size_t)pix * 3 + 2] = sum.z;
+            }
+        }
+        total_steps += steps;
+    };
+    std::vector<std::thread> ths;
+    for (int t = 1; t < n_threads; t++) ths.emplace_back(worker);
+    worker();
+    for (auto &t : ths) t.join();
+    if (steps_out) *steps_out = total_steps.load();
+    return VK_OK;
+}
+
+}  // extern "C"

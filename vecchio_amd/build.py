@@ -1,0 +1,96 @@
+"""Build recipes (explicit hipcc / g++ command lines, outputs in-tree so they travel with gpurun).
+
+-ffp-contract=off everywhere: the reference's f32 arithmetic is unfused (Rust never
+contracts a*b+c) and host/device parity of every control-flow value depends on it.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "vecchio_amd", "csrc")
+HOST = os.path.join(ROOT, "vecchio_amd", "host")
+LIB = os.path.join(ROOT, "vecchio_amd", "lib")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXX = os.environ.get("CXX", "g++")
+CXXFLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall", "-Wextra"]
+HIPFLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+            "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+
+
+def build_host(force=False):
+    out = os.path.join(LIB, "libvecchio_host.so")
+    srcs = [os.path.join(HOST, f) for f in ("host.cpp", "scene.cpp", "host_api.cpp")]
+    deps = srcs + [os.path.join(HOST, "vecchio_host.hpp"), os.path.join(HOST, "host_api.h"),
+                   os.path.join(CSRC, "vk_math.h"), os.path.join(ROOT, "include", "vecchio_amd.h")]
+    if force or _newer(out, deps):
+        os.makedirs(LIB, exist_ok=True)
+        _run([CXX] + CXXFLAGS + ["-shared", "-o", out] + srcs)
+    return out
+
+
+def build_cli(force=False):
+    out = os.path.join(LIB, "vecchio_cli")
+    src = os.path.join(HOST, "main.cpp")
+    if not os.path.exists(src):
+        return None
+    if force or _newer(out, [src, build_host()]):
+        _run([CXX] + CXXFLAGS + ["-o", out, src, "-L" + LIB, "-lvecchio_host", "-ldl", "-Wl,-rpath,$ORIGIN"])
+    return out
+
+
+def build_device(force=False):
+    """hipcc cross-compiles for gfx950 without a GPU present."""
+    out = os.path.join(LIB, "libvecchio_amd.so")
+    srcs = [os.path.join(CSRC, "vk_api.hip"), os.path.join(CSRC, "vk_linearize.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("vk_trace.h", "vk_math.h", "vk_device_scene.h", "vk_linearize.h")] + \
+        [os.path.join(ROOT, "include", "vecchio_amd.h")]
+    if force or _newer(out, deps):
+        os.makedirs(LIB, exist_ok=True)
+        _run([HIPCC] + HIPFLAGS + ["-shared", "-o", out] + srcs)
+    return out
+
+
+def build_oracle(force=False):
+    """CPU oracle (test infrastructure).  oracle/_ref does not exist: the reference is Rust and
+    there is no cargo/rustc in this image."""
+    odir = os.path.join(ROOT, "oracle")
+    out = os.path.join(odir, "_build", "liboracle.so")
+    deps = [os.path.join(odir, "oracle.cpp"), os.path.join(odir, "oracle.h"), os.path.join(CSRC, "vk_math.h"),
+            os.path.join(ROOT, "include", "vecchio_amd.h")]
+    if force or _newer(out, deps):
+        _run(["make", "-C", odir])
+    return out
+
+
+def build_emu(force=False):
+    """Test-only host build of the kernel's per-lane logic (tests/emu)."""
+    edir = os.path.join(ROOT, "tests", "emu")
+    out = os.path.join(edir, "_build", "libemu.so")
+    srcs = [os.path.join(edir, "emu.cpp"), os.path.join(CSRC, "vk_linearize.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("vk_trace.h", "vk_math.h", "vk_device_scene.h", "vk_linearize.h")]
+    if force or _newer(out, deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        _run([CXX] + CXXFLAGS + ["-shared", "-o", out] + srcs + ["-lpthread"])
+    return out
+
+
+def build_all(force=False):
+    return [build_host(force), build_device(force), build_oracle(force), build_emu(force), build_cli(force)]
+
+
+if __name__ == "__main__":
+    build_all("--force" in sys.argv)

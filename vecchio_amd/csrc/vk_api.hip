@@ -1,0 +1,651 @@
+// vk_api.hip — the HIP megakernel and the C ABI of include/vecchio_amd.h (libvecchio_amd.so).
+//
+// Kernel structure (gfx950 / CDNA4, wave64):
+//   * persistent workgroups of 256 threads (4 waves); each WAVE repeatedly pulls one work
+//     unit = (8x8-pixel tile, sample chunk) from a global atomic counter;
+//   * one ray per lane.  A lane whose path ended pulls the next (pixel, sample) of the
+//     wave's unit through a ballot + prefix-popcount ("active-ray compaction": lanes never
+//     idle while the unit still has samples); the RNG is keyed (seed, pixel, sample), so the
+//     result does not depend on which lane, wave or GPU traces a sample;
+//   * traversal is the stack-free threaded walk of vk_trace.h; when the linear BVH + sphere
+//     buffer fit, every workgroup stages them into its LDS (160 KB/CU on MI355X) once and all
+//     node/primitive fetches are ds_read_b128 instead of L1/L2 gathers;
+//   * per-pixel sums live in LDS (one float3 per tile pixel per wave, ds_add_f32), written
+//     once per unit: the framebuffer costs 12 B per pixel per launch;
+//   * no MFMA: there is no dense contraction in a path tracer.
+//
+// There is NO CPU fallback in this library: every entry point either runs on a gfx950
+// device or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/vecchio_amd.h"
+#include "vk_linearize.h"
+#include "vk_trace.h"
+
+using namespace vkd;
+
+namespace {
+
+thread_local std::string g_err = "";
+
+int fail(int code, const std::string &m) { g_err = m; return code; }
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) return fail(VK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+constexpr int WG_THREADS = 256;
+constexpr int WAVES_PER_WG = WG_THREADS / 64;
+constexpr int TILE = 8;   // 8x8 pixels = one wave
+
+struct KArgs {
+    DScene S;
+    RenderConsts C;
+    float *out;              // full framebuffer (width*height*3)
+    float *partial;          // [n_chunks][width*height*3] when n_chunks > 1
+    float4 *debug;           // optional per-sample (rgb, draws) dump
+    uint32_t *counter;       // work-unit counter
+    uint32_t tiles_x, tiles_y;
+    uint32_t n_local_tiles;  // tiles of this call's partition
+    uint32_t tile_rank, tile_world;
+    uint32_t n_chunks;
+    uint32_t lds_items, lds_spheres;   // counts staged into LDS (LDS variant)
+};
+
+// LDS-resident hot records
+struct LdsMem {
+    const uint4 *items;      // 2 x uint4 per item
+    const float4 *spheres;
+    const uint32_t *sphere_mat;
+    __device__ __forceinline__ DItem item(uint32_t i) const {
+        uint4 a = items[2 * i], b = items[2 * i + 1];
+        DItem n;
+        n.bmin[0] = __uint_as_float(a.x); n.bmin[1] = __uint_as_float(a.y); n.bmin[2] = __uint_as_float(a.z);
+        n.bmax0 = __uint_as_float(a.w); n.bmax1 = __uint_as_float(b.x); n.bmax2 = __uint_as_float(b.y);
+        n.w0 = b.z; n.w1 = b.w;
+        return n;
+    }
+    __device__ __forceinline__ DSphere sphere(uint32_t i) const {
+        float4 s = spheres[i];
+        DSphere o; o.cx = s.x; o.cy = s.y; o.cz = s.z; o.r = s.w;
+        return o;
+    }
+    __device__ __forceinline__ uint32_t smat(uint32_t i) const { return sphere_mat[i]; }
+};
+
+extern __shared__ uint4 smem[];
+
+// The persistent loop below is one big region; left alone, LLVM hoists every value that is
+// invariant across it (seed hashes, camera terms, scene pointers, division magic numbers)
+// into the prologue and then spills them (>1 KB of scratch per lane, reloaded inside the hot
+// loop).  So nothing is read from the by-value kernel argument directly: each phase re-reads
+// what it needs from the kernarg segment (scalar loads, K$-resident) through a pointer that
+// is laundered by an empty asm, which pins the loads, and everything derived from them,
+// inside the phase that uses them.
+typedef const __attribute__((address_space(4))) KArgs *KArgsC;
+__device__ __forceinline__ KArgsC kargs_fresh() {
+    KArgsC p = (KArgsC)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#define KARG(p, field) (*(const decltype(KArgs::field) *)&((p)->field))
+
+template <uint32_t F, bool LDS_SCENE>
+__device__ __forceinline__ typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type make_mem(const DScene &S, uint32_t lds_items) {
+    typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type M;
+    if constexpr (LDS_SCENE) {
+        M.items = smem; M.spheres = reinterpret_cast<const float4 *>(smem + 2u * lds_items); M.sphere_mat = S.sphere_mat;
+    } else {
+        M.items = S.items; M.spheres = S.spheres; M.sphere_mat = S.sphere_mat;
+    }
+    return M;
+}
+
+template <uint32_t F, bool LDS_SCENE, int MINW>
+__global__ __launch_bounds__(WG_THREADS, MINW) void render_kernel(KArgs A_byval) {
+    (void)A_byval;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    using Mem = typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type;
+
+    // ---- LDS layout: [items][spheres][per-wave accumulators]
+    uint32_t lds_items = 0;
+    float *acc_lds;
+    {
+        KArgsC P = kargs_fresh();
+        lds_items = LDS_SCENE ? KARG(P, lds_items) : 0u;
+        uint32_t lds_spheres = LDS_SCENE ? KARG(P, lds_spheres) : 0u;
+        acc_lds = reinterpret_cast<float *>(smem + (2u * lds_items + lds_spheres)) + wave * (64 * 3);
+        if (LDS_SCENE) {
+            const uint4 *gi = reinterpret_cast<const uint4 *>(KARG(P, S.items));
+            for (uint32_t k = threadIdx.x; k < 2u * lds_items; k += WG_THREADS) smem[k] = gi[k];
+            const uint4 *gs = reinterpret_cast<const uint4 *>(KARG(P, S.spheres));
+            for (uint32_t k = threadIdx.x; k < lds_spheres; k += WG_THREADS) smem[2u * lds_items + k] = gs[k];
+            __syncthreads();
+        }
+    }
+
+    for (;;) {
+        KArgsC U = kargs_fresh();
+        uint32_t unit = 0;
+        if (lane == 0) unit = atomicAdd(KARG(U, counter), 1u);
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        const uint32_t n_chunks = KARG(U, n_chunks);
+        if (unit >= KARG(U, n_local_tiles) * n_chunks) break;
+        const uint32_t chunk = unit % n_chunks;
+        const uint32_t tile = KARG(U, tile_rank) + (unit / n_chunks) * KARG(U, tile_world);
+        const uint32_t tiles_x = KARG(U, tiles_x);
+        const uint32_t tx = (tile % tiles_x) * TILE, ty = (tile / tiles_x) * TILE;
+        const uint32_t spp = KARG(U, C.spp);
+        const uint32_t s0 = (uint32_t)(((uint64_t)spp * chunk) / n_chunks);
+        const uint32_t s1 = (uint32_t)(((uint64_t)spp * (chunk + 1)) / n_chunks);
+        const uint32_t total = 64u * (s1 - s0);       // items: k -> (pixel slot k & 63, sample s0 + (k >> 6))
+
+        acc_lds[lane] = 0.0f; acc_lds[64 + lane] = 0.0f; acc_lds[128 + lane] = 0.0f;
+
+        Lane L;
+        uint32_t q = 0;            // tile-local pixel slot of the lane's current sample
+        bool need = true;          // lane wants a new (pixel, sample)
+        bool active = false;       // lane holds a live path
+        uint32_t next_item = 0;    // wave-uniform
+        for (;;) {
+            // ---- refill: hand the next items of the unit to the lanes that need one
+            unsigned long long need_mask = __ballot(need);
+            if (need_mask) {
+                KArgsC P = kargs_fresh();
+                uint32_t rank = __popcll(need_mask & ((1ull << lane) - 1ull));
+                if (need) {
+                    uint32_t k = next_item + rank;
+                    active = false;
+                    if (k < total) {
+                        q = k & 63u;
+                        uint32_t s = s0 + (k >> 6);
+                        uint32_t px = tx + (q & 7u), py = ty + (q >> 3);
+                        if (px < KARG(P, C.width) && py < KARG(P, C.height)) {   // slots outside the image (edge tiles) are skipped
+                            RenderConsts C = KARG(P, C);
+                            DScene S = KARG(P, S);
+                            start_sample(L, S, C, px, py, s);
+                            active = true;
+                        }
+                    }
+                    need = !active && k < total;
+                }
+                next_item += (uint32_t)__popcll(need_mask);
+            }
+            if (!__any(active)) { if (next_item >= total) break; else continue; }
+            // ---- traverse: one item per lane per iteration until every live lane's segment is done
+            {
+                KArgsC P = kargs_fresh();
+                DScene S = KARG(P, S);
+                Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
+                for (;;) {
+                    bool tr = active && traversing(L);
+                    if (!__any(tr)) break;
+                    if (tr) traverse_step<F, Mem>(L, S, M);
+                }
+            }
+            // ---- shade the finished segments; ended paths deposit their radiance
+            if (active) {
+                KArgsC P = kargs_fresh();
+                RenderConsts C = KARG(P, C);
+                DScene S = KARG(P, S);
+                Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
+                if (!shade<F, Mem>(L, S, M, C)) {
+                    float4 *dbg = KARG(P, debug);
+                    if (dbg) dbg[(size_t)L.pixel * C.spp + L.sample] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(L.rng.ctr));
+                    if (isfinite(L.acc.x) && isfinite(L.acc.y) && isfinite(L.acc.z)) {   // main.rs:192-194
+                        atomicAdd(&acc_lds[q * 3 + 0], L.acc.x);
+                        atomicAdd(&acc_lds[q * 3 + 1], L.acc.y);
+                        atomicAdd(&acc_lds[q * 3 + 2], L.acc.z);
+                    }
+                    active = false;
+                    need = true;
+                }
+            }
+        }
+        // ---- write the unit's pixel sums
+        {
+            KArgsC P = kargs_fresh();
+            uint32_t width = KARG(P, C.width), height = KARG(P, C.height);
+            uint32_t px = tx + (lane & 7u), py = ty + (lane >> 3);
+            if (px < width && py < height) {
+                size_t pix = (size_t)py * width + px;
+                float r = acc_lds[lane * 3 + 0], g = acc_lds[lane * 3 + 1], b = acc_lds[lane * 3 + 2];
+                if (n_chunks == 1) {
+                    float n = (float)KARG(P, C.spp);                         // main.rs:196
+                    float *o = KARG(P, out);
+                    o[pix * 3 + 0] = r / n; o[pix * 3 + 1] = g / n; o[pix * 3 + 2] = b / n;
+                } else {
+                    float *p = KARG(P, partial) + ((size_t)chunk * ((size_t)width * height) + pix) * 3;
+                    p[0] = r; p[1] = g; p[2] = b;
+                }
+            }
+        }
+    }
+}
+
+// sums the sample chunks of each pixel in chunk order (deterministic) and divides by spp
+__global__ void resolve_kernel(const float *partial, float *out, uint32_t width, uint32_t height, uint32_t n_chunks, uint32_t spp,
+                               uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world) {
+    uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_pixels = width * height;
+    if (pix >= n_pixels) return;
+    uint32_t x = pix % width, y = pix / width;
+    uint32_t tile = (y / TILE) * tiles_x + (x / TILE);
+    if (tile % tile_world != tile_rank) return;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        const float *p = partial + ((size_t)c * n_pixels + pix) * 3;
+        r += p[0]; g += p[1]; b += p[2];
+    }
+    float n = (float)spp;
+    out[(size_t)pix * 3 + 0] = r / n; out[(size_t)pix * 3 + 1] = g / n; out[(size_t)pix * 3 + 2] = b / n;
+}
+
+// Vec3::to_color (vec3.rs:54-61) + top-down rows (main.rs:209)
+__global__ void to_color_kernel(const float *rgb, uint32_t width, uint32_t height, uint8_t *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = width * height * 3;
+    if (i >= n) return;
+    uint32_t c = i % 3, pix = i / 3;
+    uint32_t x = pix % width, row = pix / width;
+    uint32_t y = height - 1 - row;
+    float v = sqrtf(rgb[((size_t)y * width + x) * 3 + c]);
+    float cl = v < 0.0f ? 0.0f : (v > 0.999f ? 0.999f : v);      // NaN falls through (vec3.rs:44-52) ...
+    out[i] = (uint8_t)vk::sat_u32(256.0f * cl);                    // ... and `as u32` maps NaN to 0
+}
+
+// device math probe (tests: GPU transcendental/draw functions are bit-identical to the host's)
+__global__ void math_probe_kernel(int op, const float *a, const float *b, float *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0.0f;
+    switch (op) {
+        case 0: r = vk::sinf_(a[i]); break;
+        case 1: r = vk::cosf_(a[i]); break;
+        case 2: r = vk::logf_(a[i]); break;
+        case 3: r = vk::asinf_(a[i]); break;
+        case 4: r = vk::atan2f_(a[i], b[i]); break;
+        case 5: r = vk::pow5f_(a[i]); break;
+        case 6: r = a[i] / b[i]; break;
+        case 7: r = sqrtf(a[i]); break;
+        case 8: { vk::Rng g = vk::rng_for_sample(__float_as_uint(a[i]), (uint32_t)i, 0); r = vk::gen_range(g, -1.0f, 1.0f) + vk::gen_f32(g); break; }
+        case 9: r = a[i] * b[i] + a[i]; break;   // must stay an unfused mul+add
+    }
+    out[i] = r;
+}
+
+}  // namespace
+
+// =========================================================================================
+struct vk_scene {
+    int device = 0;
+    LinearScene host;          // kept for introspection
+    DScene dev;                // device pointers
+    std::vector<void *> allocs;
+    uint32_t *counter = nullptr;
+    float *fb = nullptr; size_t fb_bytes = 0;        // framebuffer for vk_render
+    float *partial = nullptr; size_t partial_bytes = 0;
+    float4 *debug = nullptr; size_t debug_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cus = 256;
+    size_t max_lds = 65536;
+    uint32_t lds_bytes = 0;    // hot-record bytes staged per workgroup (0 = not LDS resident)
+    bool last_timed = false;
+};
+
+namespace {
+
+template <class T>
+int upload(vk_scene *s, const std::vector<T> &v, const T *&dptr) {
+    dptr = nullptr;
+    size_t bytes = v.size() * sizeof(T);
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+    s->allocs.push_back(p);
+    if (bytes) HIP_TRY(hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice));
+    dptr = reinterpret_cast<const T *>(p);
+    return VK_OK;
+}
+
+uint32_t pick_variant(uint32_t features) {
+    const uint32_t F_CORNELL = VKF_RECT | VKF_LIST | VKF_INSTANCE;
+    if (features == 0) return 0u;
+    if ((features & ~F_CORNELL) == 0) return F_CORNELL;
+    return 0x7Fu;
+}
+
+template <uint32_t F>
+int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st) {
+    constexpr int MINW = 4;   // waves per SIMD the register allocation is held to (128 VGPRs)
+    if (lds) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<F, true, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((render_kernel<F, true, MINW>), grid, dim3(WG_THREADS), shmem, st, A);
+    } else {
+        hipLaunchKernelGGL((render_kernel<F, false, MINW>), grid, dim3(WG_THREADS), shmem, st, A);
+    }
+    HIP_TRY(hipGetLastError());
+    (void)s;
+    return VK_OK;
+}
+
+int check_render_args(vk_scene *scene, const vk_camera *cam, const vk_render_params *p) {
+    if (!scene || !cam || !p) return fail(VK_ERR_BAD_ARG, "null argument");
+    if (p->width < 2 || p->height < 2) return fail(VK_ERR_BAD_ARG, "width and height must be >= 2 (u,v divide by width-1/height-1, main.rs:187-188)");
+    if ((uint64_t)p->width * p->height > (1ull << 31) / 3) return fail(VK_ERR_BAD_ARG, "image too large");
+    if (p->samples_per_pixel == 0) return fail(VK_ERR_BAD_ARG, "samples_per_pixel must be > 0");
+    if (!(cam->time0 < cam->time1)) return fail(VK_ERR_BAD_ARG, "camera time0 >= time1 (gen_range panics, main.rs:118)");
+    if (p->integrator > VK_INTEGRATOR_SCATTER || p->background > VK_BACKGROUND_SKY) return fail(VK_ERR_BAD_ARG, "bad integrator/background");
+    uint32_t world = p->tile_world ? p->tile_world : 1;
+    if (p->tile_rank >= world) return fail(VK_ERR_BAD_ARG, "tile_rank >= tile_world");
+    if (p->integrator == VK_INTEGRATOR_PDF && scene->host.lights.empty())
+        return fail(VK_ERR_UNSUPPORTED, "PDF integrator with an empty lights list (Vec::random unwraps None, hittable.rs:431)");
+    if (p->integrator == VK_INTEGRATOR_SCATTER && (scene->host.features & VKF_SPEC_DIFFUSE))
+        return fail(VK_ERR_UNSUPPORTED, "SpecDiffuse has no Material::scatter (default impl unwraps a None specular ray, material.rs:21-28)");
+    return VK_OK;
+}
+
+// number of sample chunks per tile: a function of the image and spp ONLY (never of the tile
+// partition), so 1-GPU and N-GPU renders sum every pixel in the same order
+uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
+    uint32_t tiles = ((p->width + TILE - 1) / TILE) * ((p->height + TILE - 1) / TILE);
+    uint32_t want_units = 256u * 16u * 4u;   // MI355X: 256 CUs x 16 waves, x4 for balance
+    (void)s;
+    uint32_t n = (want_units + tiles - 1) / tiles;
+    uint32_t max_by_spp = p->samples_per_pixel / 8u;
+    if (max_by_spp < 1) max_by_spp = 1;
+    if (n > max_by_spp) n = max_by_spp;
+    if (n < 1) n = 1;
+    if (n > 4096) n = 4096;
+    return n;
+}
+
+int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p, float *d_out, hipStream_t st, bool want_debug, vk_stats *stats) {
+    int rc = check_render_args(s, cam, p);
+    if (rc != VK_OK) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    const uint32_t world = p->tile_world ? p->tile_world : 1;
+    KArgs A;
+    memset(&A, 0, sizeof(A));
+    A.S = s->dev;
+    A.C.cam = *cam;
+    A.C.width = p->width; A.C.height = p->height; A.C.spp = p->samples_per_pixel; A.C.max_depth = p->max_depth;
+    A.C.seed = p->seed; A.C.integrator = p->integrator; A.C.background = p->background;
+    A.C.bg[0] = p->background_color[0]; A.C.bg[1] = p->background_color[1]; A.C.bg[2] = p->background_color[2];
+    A.out = d_out;
+    A.tiles_x = (p->width + TILE - 1) / TILE; A.tiles_y = (p->height + TILE - 1) / TILE;
+    uint32_t tiles = A.tiles_x * A.tiles_y;
+    A.tile_rank = p->tile_rank; A.tile_world = world;
+    A.n_local_tiles = tiles > p->tile_rank ? (tiles - p->tile_rank + world - 1) / world : 0;
+    A.n_chunks = choose_chunks(s, p);
+    A.counter = s->counter;
+    size_t n_pixels = (size_t)p->width * p->height;
+    if (A.n_chunks > 1) {
+        size_t need = (size_t)A.n_chunks * n_pixels * 3 * sizeof(float);
+        if (need > s->partial_bytes) {
+            if (s->partial) HIP_TRY(hipFree(s->partial));
+            s->partial = nullptr; s->partial_bytes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->partial), need));
+            s->partial_bytes = need;
+        }
+        A.partial = s->partial;
+    }
+    if (want_debug) {
+        size_t need = n_pixels * p->samples_per_pixel * sizeof(float4);
+        if (need > s->debug_bytes) {
+            if (s->debug) HIP_TRY(hipFree(s->debug));
+            s->debug = nullptr; s->debug_bytes = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->debug), need));
+            s->debug_bytes = need;
+        }
+        HIP_TRY(hipMemsetAsync(s->debug, 0, need, st));
+        A.debug = s->debug;
+    }
+    // LDS residency of the hot records
+    bool lds = s->lds_bytes != 0;
+    size_t shmem = (size_t)WAVES_PER_WG * 64 * 3 * sizeof(float);
+    if (lds) { A.lds_items = s->dev.n_items; A.lds_spheres = s->dev.n_spheres; shmem += s->lds_bytes; }
+    // persistent grid: enough workgroups to fill the chip, never more than there are units
+    uint32_t n_units = A.n_local_tiles * A.n_chunks;
+    uint32_t wgs_per_cu = lds ? (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(shmem, 1))) : 4u;
+    uint32_t grid = (uint32_t)s->num_cus * wgs_per_cu;
+    uint32_t need_wgs = (n_units + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    if (grid > need_wgs) grid = need_wgs;
+    if (grid < 1) grid = 1;
+
+    HIP_TRY(hipMemsetAsync(s->counter, 0, sizeof(uint32_t), st));
+    HIP_TRY(hipEventRecord(s->ev0, st));
+    uint32_t F = pick_variant(s->host.features) | (p->integrator == VK_INTEGRATOR_PDF ? (uint32_t)VKF_INTEG_PDF : 0u);
+    const uint32_t F_CORNELL = VKF_RECT | VKF_LIST | VKF_INSTANCE;
+    switch (F) {
+        case 0u: rc = launch_variant<0u>(s, A, lds, dim3(grid), shmem, st); break;
+        case VKF_INTEG_PDF: rc = launch_variant<VKF_INTEG_PDF>(s, A, lds, dim3(grid), shmem, st); break;
+        case F_CORNELL: rc = launch_variant<F_CORNELL>(s, A, lds, dim3(grid), shmem, st); break;
+        case F_CORNELL | VKF_INTEG_PDF: rc = launch_variant<(F_CORNELL | VKF_INTEG_PDF)>(s, A, lds, dim3(grid), shmem, st); break;
+        case 0x7Fu: rc = launch_variant<0x7Fu>(s, A, lds, dim3(grid), shmem, st); break;
+        default: rc = launch_variant<(0x7Fu | VKF_INTEG_PDF)>(s, A, lds, dim3(grid), shmem, st); break;
+    }
+    if (rc != VK_OK) return rc;
+    uint32_t launches = 1;
+    if (A.n_chunks > 1) {
+        uint32_t blocks = (uint32_t)((n_pixels + 255) / 256);
+        hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(256), 0, st, (const float *)A.partial, d_out, p->width, p->height, A.n_chunks,
+                           p->samples_per_pixel, A.tiles_x, A.tile_rank, A.tile_world);
+        HIP_TRY(hipGetLastError());
+        launches = 2;
+    }
+    HIP_TRY(hipEventRecord(s->ev1, st));
+    s->last_timed = true;
+    if (stats) {
+        // samples of this partition
+        uint64_t px = 0;
+        for (uint32_t t = p->tile_rank; t < tiles; t += world) {
+            uint32_t tx = (t % A.tiles_x) * TILE, ty = (t / A.tiles_x) * TILE;
+            px += (uint64_t)std::min<uint32_t>(TILE, p->width - tx) * std::min<uint32_t>(TILE, p->height - ty);
+        }
+        stats->samples = px * p->samples_per_pixel;
+        stats->kernel_launches = launches;
+        stats->scene_in_lds = lds ? 1u : 0u;
+        stats->kernel_ms = 0.0; stats->seconds = 0.0;
+    }
+    return VK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vk_abi_version(void) { return VK_ABI_VERSION; }
+
+int vk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, i) == hipSuccess && strncmp(pr.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+const char *vk_last_error(void) { return g_err.c_str(); }
+
+int vk_scene_create(const vk_scene_desc *desc, int device, vk_scene **out) {
+    if (!out) return fail(VK_ERR_BAD_ARG, "null out pointer");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(VK_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= n) return fail(VK_ERR_BAD_ARG, "device index out of range");
+    hipDeviceProp_t pr;
+    HIP_TRY(hipGetDeviceProperties(&pr, device));
+    if (strncmp(pr.gcnArchName, "gfx950", 6) != 0) return fail(VK_ERR_NO_DEVICE, std::string("device is ") + pr.gcnArchName + ", this build targets gfx950 only");
+    vk_scene *s = new vk_scene;
+    s->device = device;
+    std::string err;
+    int rc = linearize(desc, s->host, err);
+    if (rc != VK_OK) { delete s; return fail(rc, err); }
+    HIP_TRY(hipSetDevice(device));
+    s->num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    s->max_lds = 160 * 1024;
+    const LinearScene &H = s->host;
+    DScene &D = s->dev;
+    memset(&D, 0, sizeof(D));
+#define UP(vec, field) do { rc = upload(s, H.vec, D.field); if (rc != VK_OK) { vk_scene_destroy(s); return rc; } } while (0)
+    UP(items, items); UP(spheres, spheres); UP(sphere_mat, sphere_mat); UP(moving, moving); UP(rects, rects);
+    UP(lists, lists); UP(list_refs, list_refs); UP(media, media); UP(instances, instances);
+    UP(materials, materials); UP(textures, textures); UP(images, images); UP(image_bytes, image_bytes);
+    UP(perlins, perlins); UP(lights, lights);
+#undef UP
+    D.n_items = (uint32_t)H.items.size(); D.n_world_items = H.world_items; D.n_spheres = (uint32_t)H.spheres.size();
+    D.n_lights = (uint32_t)H.lights.size(); D.features = H.features;
+    void *c = nullptr;
+    if (hipMalloc(&c, 256) != hipSuccess) { vk_scene_destroy(s); return fail(VK_ERR_OOM, "hipMalloc failed"); }
+    s->counter = reinterpret_cast<uint32_t *>(c);
+    if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { vk_scene_destroy(s); return fail(VK_ERR_HIP, "hipEventCreate failed"); }
+    // LDS residency: items + spheres + accumulators must leave room for >= 2 workgroups per CU
+    size_t hot = H.items.size() * sizeof(DItem) + H.spheres.size() * sizeof(DSphere);
+    size_t accb = (size_t)WAVES_PER_WG * 64 * 3 * sizeof(float);
+    s->lds_bytes = (hot + accb <= 72 * 1024) ? (uint32_t)hot : 0u;
+    *out = s;
+    return VK_OK;
+}
+
+void vk_scene_destroy(vk_scene *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    for (void *p : s->allocs) (void)hipFree(p);
+    if (s->counter) (void)hipFree(s->counter);
+    if (s->fb) (void)hipFree(s->fb);
+    if (s->partial) (void)hipFree(s->partial);
+    if (s->debug) (void)hipFree(s->debug);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+int vk_scene_get_info(const vk_scene *s, vk_scene_info *out) {
+    if (!s || !out) return fail(VK_ERR_BAD_ARG, "null argument");
+    out->n_items = (uint32_t)s->host.items.size();
+    out->n_prims = s->host.n_prims;
+    out->n_instances = (uint32_t)s->host.instances.size();
+    uint64_t b = 0;
+    b += s->host.items.size() * sizeof(DItem) + s->host.spheres.size() * (sizeof(DSphere) + 4) + s->host.moving.size() * sizeof(DMoving) +
+         s->host.rects.size() * sizeof(DRect) + s->host.lists.size() * sizeof(DList) + s->host.list_refs.size() * 4 +
+         s->host.media.size() * sizeof(DMedium) + s->host.instances.size() * sizeof(DInstance) + s->host.materials.size() * sizeof(DMaterial) +
+         s->host.textures.size() * sizeof(DTexture) + s->host.image_bytes.size() + s->host.perlins.size() * sizeof(DPerlin);
+    out->device_bytes = b;
+    out->lds_bytes = s->lds_bytes;
+    out->features = pick_variant(s->host.features);
+    return VK_OK;
+}
+
+int vk_render_device(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, void *d_rgb_out, void *hip_stream, vk_stats *stats_out) {
+    if (!d_rgb_out) return fail(VK_ERR_BAD_ARG, "null device framebuffer");
+    return enqueue_render(scene, cam, params, reinterpret_cast<float *>(d_rgb_out), reinterpret_cast<hipStream_t>(hip_stream), false, stats_out);
+}
+
+// HIP-event time (ms) of the launches enqueued by the last vk_render_device / vk_render on
+// this scene; synchronises on their end event.
+int vk_scene_last_kernel_ms(vk_scene *s, double *ms_out) {
+    if (!s || !ms_out) return fail(VK_ERR_BAD_ARG, "null argument");
+    if (!s->last_timed) return fail(VK_ERR_BAD_ARG, "no render enqueued yet");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    *ms_out = (double)ms;
+    return VK_OK;
+}
+
+static int render_host(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, float *rgb_out, vk_stats *stats_out, float *debug_out) {
+    if (!rgb_out) return fail(VK_ERR_BAD_ARG, "null framebuffer");
+    int rc = check_render_args(scene, cam, params);
+    if (rc != VK_OK) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipSetDevice(scene->device));
+    size_t n_pixels = (size_t)params->width * params->height;
+    size_t bytes = n_pixels * 3 * sizeof(float);
+    if (bytes > scene->fb_bytes) {
+        if (scene->fb) HIP_TRY(hipFree(scene->fb));
+        scene->fb = nullptr; scene->fb_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&scene->fb), bytes));
+        scene->fb_bytes = bytes;
+    }
+    vk_stats st;
+    memset(&st, 0, sizeof(st));
+    rc = enqueue_render(scene, cam, params, scene->fb, nullptr, debug_out != nullptr, &st);
+    if (rc != VK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    double ms = 0.0;
+    rc = vk_scene_last_kernel_ms(scene, &ms);
+    if (rc != VK_OK) return rc;
+    st.kernel_ms = ms;
+    uint32_t world = params->tile_world ? params->tile_world : 1;
+    if (world == 1) {
+        HIP_TRY(hipMemcpy(rgb_out, scene->fb, bytes, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> tmp(n_pixels * 3);
+        HIP_TRY(hipMemcpy(tmp.data(), scene->fb, bytes, hipMemcpyDeviceToHost));
+        uint32_t tiles_x = (params->width + TILE - 1) / TILE;
+        for (uint32_t y = 0; y < params->height; y++)
+            for (uint32_t x = 0; x < params->width; x++) {
+                uint32_t tile = (y / TILE) * tiles_x + (x / TILE);
+                if (tile % world != params->tile_rank) continue;
+                size_t i = ((size_t)y * params->width + x) * 3;
+                rgb_out[i] = tmp[i]; rgb_out[i + 1] = tmp[i + 1]; rgb_out[i + 2] = tmp[i + 2];
+            }
+    }
+    if (debug_out) HIP_TRY(hipMemcpy(debug_out, scene->debug, n_pixels * params->samples_per_pixel * sizeof(float4), hipMemcpyDeviceToHost));
+    st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats_out) *stats_out = st;
+    return VK_OK;
+}
+
+int vk_render(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, float *rgb_out, vk_stats *stats_out) {
+    return render_host(scene, cam, params, rgb_out, stats_out, nullptr);
+}
+
+// test hook: as vk_render, also returning every sample: samples_out[(pixel*spp + s)*4 + 0..2]
+// = radiance before the finite filter, [+3] = the sample's draw count (bit pattern)
+int vk_debug_render_samples(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, float *rgb_out, float *samples_out) {
+    if (!samples_out) return fail(VK_ERR_BAD_ARG, "null samples buffer");
+    return render_host(scene, cam, params, rgb_out, nullptr, samples_out);
+}
+
+int vk_to_color_device(vk_scene *scene, const void *d_rgb, uint32_t width, uint32_t height, void *d_rgb8_out, void *hip_stream) {
+    if (!scene || !d_rgb || !d_rgb8_out) return fail(VK_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(scene->device));
+    uint32_t n = width * height * 3;
+    hipLaunchKernelGGL(to_color_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
+                       reinterpret_cast<const float *>(d_rgb), width, height, reinterpret_cast<uint8_t *>(d_rgb8_out));
+    HIP_TRY(hipGetLastError());
+    return VK_OK;
+}
+
+// test hook: evaluate shared-math functions on the device (host arrays in/out)
+int vk_debug_math(int device, int op, const float *a, const float *b, float *out, size_t n) {
+    if (!a || !b || !out) return fail(VK_ERR_BAD_ARG, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&da), n * 4 + 16));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&db), n * 4 + 16));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dout), n * 4 + 16));
+    HIP_TRY(hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, (const float *)da, (const float *)db, dout, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return VK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// vk_device_scene.h — the linearised scene the megakernel traverses (layout in HBM / LDS).
+//
+// The host lineariser (vk_linearize.cpp) turns the vk_scene_desc graph (one record per
+// reference trait object) into:
+//
+//   items[]   32-byte records in PRE-ORDER of the reference's BVH (accel.rs:58-83 always
+//             descends left first and shrinks tmax, so a fixed-order, stack-free "threaded"
+//             traversal visits exactly the nodes BVHNode::hit visits, in the same order):
+//               INNER  {bbox, w0 = skip index (kind nibble 0), w1 = 0}
+//                      box hit -> next item (= left subtree); box miss -> items[w0]
+//               LEAF   {bbox, w0 = dref A, w1 = dref B or 0}   (both children are objects)
+//               PRIM   {unused bbox, w0 = 0xF0000000, w1 = dref} (an object child next to a
+//                      BVH child, e.g. world leaves of final_scene, scene.rs:760-769)
+//   spheres[] float4 {cx,cy,cz,r} + sphere_mat[]      (SoA-by-type primitive buffers)
+//   moving[], rects[], lists[]+list_refs[], media[], instances[] (transform chains)
+//   materials[], textures[], images, perlin tables, lights[]
+//
+// dref = kind(4) | flip(1) | index(27); flip is the FlipFace parity (hittable.rs:294-312).
+#ifndef VK_DEVICE_SCENE_H
+#define VK_DEVICE_SCENE_H
+#include <stdint.h>
+
+namespace vkd {
+
+enum : uint32_t {
+    DK_NONE = 0, DK_SPHERE = 1, DK_MOVING = 2, DK_RECT = 3, DK_LIST = 4, DK_MEDIUM = 5, DK_INSTANCE = 6,
+    DK_PRIM_ITEM = 15
+};
+constexpr uint32_t DREF_FLIP = 0x08000000u;
+constexpr uint32_t DREF_INDEX = 0x07FFFFFFu;
+#define VKD_KIND(r) ((r) >> 28)
+#define VKD_INDEX(r) ((r) & 0x07FFFFFFu)
+#define VKD_MAKE(kind, idx) (((uint32_t)(kind) << 28) | ((uint32_t)(idx) & 0x07FFFFFFu))
+
+struct alignas(16) DItem {      // 32 B: the canonical BVH node record (24 B box + two 4 B links)
+    float bmin[3];
+    float bmax0;                // bmax[0]
+    float bmax1, bmax2;
+    uint32_t w0, w1;
+};
+
+struct alignas(16) DSphere { float cx, cy, cz, r; };                       // 16 B (hittable.rs:47-51)
+struct alignas(16) DMoving { float c0[3], t0, c1[3], t1, r; uint32_t mat, _p0, _p1; };  // 48 B
+struct alignas(16) DRect { float c0, c1, d0, d1, k; uint32_t axes; uint32_t mat, _p; };  // 32 B; axes = a0 | a1<<2 | a2<<4
+struct DList { uint32_t first, count; };
+struct alignas(16) DMedium { uint32_t boundary; float neg_inv_density; uint32_t mat, _p; };
+
+enum : uint32_t { OP_TRANSLATE = 0, OP_ROTATE_X = 1, OP_ROTATE_Y = 2, OP_ROTATE_Z = 3 };
+struct DOp { uint32_t kind; float a, b, c; };      // translate: offset xyz; rotate: a = sin, b = cos
+constexpr int MAX_OPS = 4;                          // ops per instance record (longer chains nest)
+constexpr int MAX_DEPTH_INST = 4;                   // instance nesting levels
+struct alignas(16) DInstance {
+    uint32_t n_ops;
+    uint32_t child_begin, child_end;   // item range of a BVH child (begin < end), else 0,0
+    uint32_t child_ref;                // dref of a non-BVH child (prim/list/medium/instance), else 0
+    int32_t parent;                    // enclosing instance or -1
+    uint32_t home_next;                // item index to resume at in the parent's range
+    uint32_t home_pend;                // dref still to process in the home LEAF item (its w1) or 0
+    uint32_t depth;                    // number of enclosing instances (0 = directly in world)
+    int32_t chain[MAX_DEPTH_INST];     // ancestors outermost-first, including self at [depth]
+    uint32_t flip;                     // FlipFace parity of the reference to this instance (DREF_FLIP or 0)
+    uint32_t _p[3];
+    DOp ops[MAX_OPS];                  // applied in order to the ray (outermost wrapper first)
+};
+
+struct alignas(16) DMaterial {         // 32 B: material record with its solid colour baked in
+    uint32_t kind;                     // VK_MAT_*
+    uint32_t tex;                      // texture index (for non-solid textures)
+    float param;                       // fuzz / ref_idx / pct
+    uint32_t tex_kind;                 // VK_TEX_* of `tex` (SOLID -> use rgb below, no second fetch)
+    float r, g, b;                     // solid colour
+    uint32_t ab;                       // SPEC_DIFFUSE: specular | diffuse << 16
+};
+struct alignas(16) DTexture { uint32_t kind; float r, g, b; uint32_t a, b_; float scale; uint32_t _p; };
+struct DImage { uint32_t width, height; uint64_t offset; };   // offset into image_bytes
+struct DPerlin { float ranvec[256][3]; uint8_t perm_x[256], perm_y[256], perm_z[256]; };
+
+enum : uint32_t {  // feature bits -> kernel variant selection
+    VKF_MOVING = 1u, VKF_RECT = 2u, VKF_LIST = 4u, VKF_MEDIUM = 8u, VKF_INSTANCE = 16u,
+    VKF_TEXTURES = 32u,   // any non-solid texture (checker/image/noise)
+    VKF_SPEC_DIFFUSE = 64u,
+    VKF_INTEG_PDF = 128u  // not a scene property: selects the HEAD integrator (main.rs:123-153) at compile time
+};
+
+// What the kernel sees.  All pointers are device (or, in the CPU emulator, host) addresses.
+struct DScene {
+    const DItem *items; uint32_t n_items; uint32_t n_world_items;   // world range = items[0, n_world_items); instance ranges follow
+    const DSphere *spheres; const uint32_t *sphere_mat; uint32_t n_spheres;
+    const DMoving *moving;
+    const DRect *rects;
+    const DList *lists; const uint32_t *list_refs;
+    const DMedium *media;
+    const DInstance *instances;
+    const DMaterial *materials;
+    const DTexture *textures;
+    const DImage *images; const uint8_t *image_bytes;
+    const DPerlin *perlins;
+    const uint32_t *lights; uint32_t n_lights;
+    uint32_t features;
+};
+
+}  // namespace vkd
+#endif

@@ -1,0 +1,374 @@
+// vk_linearize.cpp — see vk_linearize.h
+#include "vk_linearize.h"
+
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <map>
+
+namespace vkd {
+
+DScene LinearScene::host_view() const {
+    DScene s;
+    memset(&s, 0, sizeof(s));
+    s.items = items.data(); s.n_items = (uint32_t)items.size(); s.n_world_items = world_items;
+    s.spheres = spheres.data(); s.sphere_mat = sphere_mat.data(); s.n_spheres = (uint32_t)spheres.size();
+    s.moving = moving.data(); s.rects = rects.data();
+    s.lists = lists.data(); s.list_refs = list_refs.data();
+    s.media = media.data(); s.instances = instances.data();
+    s.materials = materials.data(); s.textures = textures.data();
+    s.images = images.data(); s.image_bytes = image_bytes.data();
+    s.perlins = perlins.data();
+    s.lights = lights.data(); s.n_lights = (uint32_t)lights.size();
+    s.features = features;
+    return s;
+}
+
+namespace {
+
+struct Builder {
+    const vk_scene_desc *d;
+    LinearScene &L;
+    std::string &err;
+    int status = VK_OK;
+    std::map<uint32_t, uint32_t> list_memo, medium_memo;
+    struct Pending { uint32_t bvh_index; uint32_t flip; int32_t inst; };
+    std::deque<Pending> pending;   // BVH children of instances, emitted after the current range
+
+    Builder(const vk_scene_desc *d_, LinearScene &l, std::string &e) : d(d_), L(l), err(e) {}
+
+    bool fail(int code, const std::string &m) { if (status == VK_OK) { status = code; err = m; } return false; }
+
+    bool check_ref(vk_ref r) {
+        uint32_t k = VK_REF_KIND(r), i = VK_REF_INDEX(r);
+        switch (k) {
+            case VK_KIND_BVH: return i < d->n_bvh || fail(VK_ERR_BAD_ARG, "bvh index out of range");
+            case VK_KIND_SPHERE: return i < d->n_spheres || fail(VK_ERR_BAD_ARG, "sphere index out of range");
+            case VK_KIND_MOVING_SPHERE: return i < d->n_moving_spheres || fail(VK_ERR_BAD_ARG, "moving sphere index out of range");
+            case VK_KIND_RECT: return i < d->n_rects || fail(VK_ERR_BAD_ARG, "rect index out of range");
+            case VK_KIND_LIST: return i < d->n_lists || fail(VK_ERR_BAD_ARG, "list index out of range");
+            case VK_KIND_MEDIUM: return i < d->n_media || fail(VK_ERR_BAD_ARG, "medium index out of range");
+            case VK_KIND_TRANSLATE: return i < d->n_translates || fail(VK_ERR_BAD_ARG, "translate index out of range");
+            case VK_KIND_ROTATE: return i < d->n_rotates || fail(VK_ERR_BAD_ARG, "rotate index out of range");
+            default: return fail(VK_ERR_BAD_ARG, "unknown hittable kind in reference");
+        }
+    }
+
+    static bool is_simple(uint32_t kind) { return kind == VK_KIND_SPHERE || kind == VK_KIND_MOVING_SPHERE || kind == VK_KIND_RECT; }
+
+    uint32_t simple_dref(vk_ref r, uint32_t flip) {
+        uint32_t k = VK_REF_KIND(r), i = VK_REF_INDEX(r);
+        uint32_t f = ((r & VK_REF_FLIP) ? DREF_FLIP : 0u) ^ flip;
+        uint32_t dk = k == VK_KIND_SPHERE ? DK_SPHERE : (k == VK_KIND_MOVING_SPHERE ? DK_MOVING : DK_RECT);
+        if (k == VK_KIND_MOVING_SPHERE) L.features |= VKF_MOVING;
+        if (k == VK_KIND_RECT) L.features |= VKF_RECT;
+        return VKD_MAKE(dk, i) | f;
+    }
+
+    // list of primitives (Boxy::sides); flip of the list reference is applied by the caller
+    bool convert_list(uint32_t idx, uint32_t &out) {
+        auto it = list_memo.find(idx);
+        if (it != list_memo.end()) { out = it->second; return true; }
+        const vk_list &l = d->lists[idx];
+        if ((uint64_t)l.first + l.count > d->n_list_items) return fail(VK_ERR_BAD_ARG, "list items out of range");
+        DList dl; dl.first = (uint32_t)L.list_refs.size(); dl.count = l.count;
+        for (uint32_t j = 0; j < l.count; j++) {
+            vk_ref r = d->list_items[l.first + j];
+            if (!check_ref(r)) return false;
+            if (!is_simple(VK_REF_KIND(r)))
+                return fail(VK_ERR_UNSUPPORTED, "device path: list items must be Sphere/MovingSphere/Rect (optionally FlipFace-wrapped)");
+            L.list_refs.push_back(simple_dref(r, 0));
+        }
+        L.lists.push_back(dl);
+        L.features |= VKF_LIST;
+        out = (uint32_t)L.lists.size() - 1;
+        list_memo[idx] = out;
+        return true;
+    }
+
+    bool convert_medium(uint32_t idx, uint32_t &out) {
+        auto it = medium_memo.find(idx);
+        if (it != medium_memo.end()) { out = it->second; return true; }
+        const vk_medium &m = d->media[idx];
+        if (!check_ref(m.boundary)) return false;
+        if (m.material >= d->n_materials) return fail(VK_ERR_BAD_ARG, "material index out of range");
+        uint32_t bk = VK_REF_KIND(m.boundary);
+        DMedium dm; memset(&dm, 0, sizeof(dm));
+        if (is_simple(bk)) dm.boundary = simple_dref(m.boundary, 0);
+        else if (bk == VK_KIND_LIST) {
+            uint32_t li;
+            if (!convert_list(VK_REF_INDEX(m.boundary), li)) return false;
+            dm.boundary = VKD_MAKE(DK_LIST, li) | ((m.boundary & VK_REF_FLIP) ? DREF_FLIP : 0u);
+        } else return fail(VK_ERR_UNSUPPORTED, "device path: ConstantMedium boundary must be a Sphere, MovingSphere, Rect or Boxy");
+        dm.neg_inv_density = m.neg_inv_density; dm.mat = m.material;
+        L.media.push_back(dm);
+        L.features |= VKF_MEDIUM;
+        out = (uint32_t)L.media.size() - 1;
+        medium_memo[idx] = out;
+        return true;
+    }
+
+    // Translate / Rotate* chain -> one DInstance (tree-unique: a new record per occurrence)
+    bool convert_instance(vk_ref r, uint32_t flip, int32_t parent_inst, uint32_t &out_dref, int nest) {
+        if (nest > 64) return fail(VK_ERR_BAD_ARG, "transform chain too deep / cyclic");
+        DInstance I; memset(&I, 0, sizeof(I));
+        I.parent = parent_inst;
+        I.flip = ((r & VK_REF_FLIP) ? DREF_FLIP : 0u) ^ flip;
+        uint32_t pdepth = 0;
+        if (parent_inst >= 0) {
+            const DInstance &P = L.instances[parent_inst];
+            pdepth = P.depth + 1;
+            if (pdepth >= (uint32_t)MAX_DEPTH_INST) return fail(VK_ERR_UNSUPPORTED, "device path: instance nesting deeper than 4");
+            for (uint32_t l = 0; l <= P.depth; l++) I.chain[l] = P.chain[l];
+        }
+        I.depth = pdepth;
+        vk_ref cur = r;
+        while (I.n_ops < (uint32_t)MAX_OPS) {
+            uint32_t k = VK_REF_KIND(cur), i = VK_REF_INDEX(cur);
+            if (k == VK_KIND_TRANSLATE) {
+                const vk_translate &t = d->translates[i];
+                DOp op; op.kind = OP_TRANSLATE; op.a = t.offset[0]; op.b = t.offset[1]; op.c = t.offset[2];
+                I.ops[I.n_ops++] = op;
+                cur = t.child;
+            } else if (k == VK_KIND_ROTATE) {
+                const vk_rotate &t = d->rotates[i];
+                if (t.axis > 2) return fail(VK_ERR_BAD_ARG, "rotate axis out of range");
+                DOp op; op.kind = t.axis == 0 ? OP_ROTATE_X : (t.axis == 1 ? OP_ROTATE_Y : OP_ROTATE_Z); op.a = t.sin_theta; op.b = t.cos_theta; op.c = 0.0f;
+                I.ops[I.n_ops++] = op;
+                cur = t.child;
+            } else break;
+            if (!check_ref(cur)) return false;
+            // a FlipFace between two wrappers only negates `front`, which the outer wrapper's
+            // set_face_normal overwrites (hittable.rs:519,618): it has no effect and is dropped
+        }
+        int32_t self = (int32_t)L.instances.size();
+        I.chain[I.depth] = self;
+        L.instances.push_back(I);
+        L.features |= VKF_INSTANCE;
+        uint32_t ck = VK_REF_KIND(cur);
+        // the child's own FlipFace parity is likewise overwritten by this wrapper: dropped
+        if (ck == VK_KIND_BVH) {
+            pending.push_back(Pending{VK_REF_INDEX(cur), 0u, self});
+        } else {
+            uint32_t cref;
+            if (!convert_object(cur & ~VK_REF_FLIP, 0, self, cref, nest + 1)) return false;
+            L.instances[self].child_ref = cref;
+        }
+        out_dref = VKD_MAKE(DK_INSTANCE, self);
+        return true;
+    }
+
+    // any non-BVH hittable -> dref
+    bool convert_object(vk_ref r, uint32_t flip, int32_t inst, uint32_t &out, int nest = 0) {
+        if (!check_ref(r)) return false;
+        uint32_t k = VK_REF_KIND(r), i = VK_REF_INDEX(r);
+        uint32_t f = ((r & VK_REF_FLIP) ? DREF_FLIP : 0u) ^ flip;
+        if (is_simple(k)) { out = simple_dref(r, flip); return true; }
+        if (k == VK_KIND_LIST) { uint32_t li; if (!convert_list(i, li)) return false; out = VKD_MAKE(DK_LIST, li) | f; return true; }
+        if (k == VK_KIND_MEDIUM) { uint32_t mi; if (!convert_medium(i, mi)) return false; out = VKD_MAKE(DK_MEDIUM, mi) | f; return true; }
+        if (k == VK_KIND_TRANSLATE || k == VK_KIND_ROTATE) return convert_instance(r, flip, inst, out, nest);
+        return fail(VK_ERR_UNSUPPORTED, "device path: a BVHNode may only appear as the world, as a BVH child or under Translate/Rotate");
+    }
+
+    void set_home(uint32_t dref, uint32_t home_next, uint32_t home_pend) {
+        if (VKD_KIND(dref) == DK_INSTANCE) {
+            DInstance &I = L.instances[VKD_INDEX(dref)];
+            I.home_next = home_next; I.home_pend = home_pend;
+        }
+    }
+
+    static bool draw_free(uint32_t dref) { uint32_t k = VKD_KIND(dref); return k == DK_SPHERE || k == DK_MOVING || k == DK_RECT || k == DK_LIST; }
+
+    // pre-order emission of one BVH (accel.rs:58-83 order: box, left, right); iterative to
+    // survive 1M-primitive trees and degenerate depth
+    bool emit_bvh(uint32_t root, uint32_t flip0, int32_t inst) {
+        struct Frame { uint32_t node; uint32_t flip; uint32_t item; int stage; };
+        std::vector<Frame> st;
+        st.push_back(Frame{root, flip0, 0, 0});
+        size_t guard = 0;
+        while (!st.empty()) {
+            if (++guard > (size_t)8 * (d->n_bvh + 16) + 1024) return fail(VK_ERR_BAD_ARG, "BVH graph is cyclic");
+            Frame &fr = st.back();
+            const vk_bvh_node &n = d->bvh[fr.node];
+            if (fr.stage == 0) {
+                if (!check_ref(n.left) || !check_ref(n.right)) return false;
+                DItem it; memset(&it, 0, sizeof(it));
+                it.bmin[0] = n.bb_min[0]; it.bmin[1] = n.bb_min[1]; it.bmin[2] = n.bb_min[2];
+                it.bmax0 = n.bb_max[0]; it.bmax1 = n.bb_max[1]; it.bmax2 = n.bb_max[2];
+                uint32_t lk = VK_REF_KIND(n.left), rk = VK_REF_KIND(n.right);
+                uint32_t pos = (uint32_t)L.items.size();
+                if (lk != VK_KIND_BVH && rk != VK_KIND_BVH) {
+                    L.items.push_back(it);
+                    uint32_t a, b = 0;
+                    if (!convert_object(n.left, fr.flip, inst, a)) return false;
+                    bool dup = (n.left == n.right);
+                    if (!(dup && draw_free(a))) { if (!convert_object(n.right, fr.flip, inst, b)) return false; }
+                    L.items[pos].w0 = a; L.items[pos].w1 = b;
+                    set_home(a, pos + 1, b);
+                    set_home(b, pos + 1, 0);
+                    L.n_prims += b ? 2 : 1;
+                    st.pop_back();
+                    continue;
+                }
+                L.items.push_back(it);
+                fr.item = pos; fr.stage = 1;
+                continue;
+            }
+            if (fr.stage == 1 || fr.stage == 2) {
+                vk_ref child = fr.stage == 1 ? n.left : n.right;
+                fr.stage += 1;
+                uint32_t cf = fr.flip ^ ((child & VK_REF_FLIP) ? DREF_FLIP : 0u);
+                if (VK_REF_KIND(child) == VK_KIND_BVH) {
+                    Frame nf{VK_REF_INDEX(child), cf, 0, 0};
+                    st.push_back(nf);   // (fr is invalid after this)
+                } else {
+                    uint32_t pos = (uint32_t)L.items.size();
+                    DItem it; memset(&it, 0, sizeof(it));
+                    it.w0 = VKD_MAKE(DK_PRIM_ITEM, 0);
+                    L.items.push_back(it);
+                    uint32_t a;
+                    if (!convert_object(child, fr.flip, inst, a)) return false;
+                    L.items[pos].w1 = a;
+                    set_home(a, pos + 1, 0);
+                    L.n_prims += 1;
+                }
+                continue;
+            }
+            L.items[fr.item].w0 = (uint32_t)L.items.size();   // skip link: first item after this subtree
+            st.pop_back();
+        }
+        if (L.items.size() >= (size_t)DREF_INDEX) return fail(VK_ERR_UNSUPPORTED, "too many BVH items");
+        return true;
+    }
+
+    bool drain_pending() {
+        while (!pending.empty()) {
+            Pending p = pending.front();
+            pending.pop_front();
+            uint32_t begin = (uint32_t)L.items.size();
+            if (!emit_bvh(p.bvh_index, p.flip, p.inst)) return false;
+            L.instances[p.inst].child_begin = begin;
+            L.instances[p.inst].child_end = (uint32_t)L.items.size();
+        }
+        return true;
+    }
+
+    bool materials_and_textures() {
+        for (uint32_t i = 0; i < d->n_textures; i++) {
+            const vk_texture &t = d->textures[i];
+            DTexture o; memset(&o, 0, sizeof(o));
+            o.kind = t.kind; o.r = t.color[0]; o.g = t.color[1]; o.b = t.color[2]; o.a = t.a; o.b_ = t.b; o.scale = t.scale;
+            if (t.kind == VK_TEX_CHECKER) { if (t.a >= d->n_textures || t.b >= d->n_textures) return fail(VK_ERR_BAD_ARG, "checker child out of range"); }
+            else if (t.kind == VK_TEX_IMAGE) { if (t.a >= d->n_images) return fail(VK_ERR_BAD_ARG, "image index out of range"); }
+            else if (t.kind == VK_TEX_NOISE) { if (t.a >= d->n_perlins) return fail(VK_ERR_BAD_ARG, "perlin index out of range"); }
+            else if (t.kind != VK_TEX_SOLID) return fail(VK_ERR_BAD_ARG, "unknown texture kind");
+            if (t.kind != VK_TEX_SOLID) L.features |= VKF_TEXTURES;
+            L.textures.push_back(o);
+        }
+        for (uint32_t i = 0; i < d->n_images; i++) {
+            const vk_image &im = d->images[i];
+            if (!im.rgb || !im.width || !im.height) return fail(VK_ERR_BAD_ARG, "empty image");
+            DImage o; o.width = im.width; o.height = im.height; o.offset = L.image_bytes.size();
+            size_t n = (size_t)im.width * im.height * 3;
+            L.image_bytes.insert(L.image_bytes.end(), im.rgb, im.rgb + n);
+            while (L.image_bytes.size() % 16) L.image_bytes.push_back(0);
+            L.images.push_back(o);
+        }
+        for (uint32_t i = 0; i < d->n_perlins; i++) {
+            const vk_perlin &p = d->perlins[i];
+            DPerlin o;
+            for (int k = 0; k < 256; k++) {
+                o.ranvec[k][0] = p.ranvec[k][0]; o.ranvec[k][1] = p.ranvec[k][1]; o.ranvec[k][2] = p.ranvec[k][2];
+                o.perm_x[k] = (uint8_t)(p.perm_x[k] & 255u); o.perm_y[k] = (uint8_t)(p.perm_y[k] & 255u); o.perm_z[k] = (uint8_t)(p.perm_z[k] & 255u);
+            }
+            L.perlins.push_back(o);
+        }
+        for (uint32_t i = 0; i < d->n_materials; i++) {
+            const vk_material &m = d->materials[i];
+            DMaterial o; memset(&o, 0, sizeof(o));
+            o.kind = m.kind; o.tex = m.texture; o.param = m.param; o.tex_kind = VK_TEX_SOLID;
+            bool needs_tex = m.kind == VK_MAT_LAMBERTIAN || m.kind == VK_MAT_METAL || m.kind == VK_MAT_DIFFUSE_LIGHT || m.kind == VK_MAT_ISOTROPIC;
+            if (needs_tex) {
+                if (m.texture >= d->n_textures) return fail(VK_ERR_BAD_ARG, "texture index out of range");
+                const vk_texture &t = d->textures[m.texture];
+                o.tex_kind = t.kind; o.r = t.color[0]; o.g = t.color[1]; o.b = t.color[2];
+            } else if (m.kind == VK_MAT_SPEC_DIFFUSE) {
+                if (m.a >= d->n_materials || m.b >= d->n_materials) return fail(VK_ERR_BAD_ARG, "spec_diffuse child out of range");
+                if (m.a >= 65536 || m.b >= 65536) return fail(VK_ERR_UNSUPPORTED, "device path: SpecDiffuse children must have material index < 65536");
+                o.ab = m.a | (m.b << 16);
+                L.features |= VKF_SPEC_DIFFUSE | VKF_TEXTURES;
+            } else if (m.kind != VK_MAT_DIELECTRIC) return fail(VK_ERR_BAD_ARG, "unknown material kind");
+            L.materials.push_back(o);
+        }
+        return true;
+    }
+
+    bool run() {
+        if (!d) return fail(VK_ERR_BAD_ARG, "null scene description");
+        if (d->abi_version != VK_ABI_VERSION) return fail(VK_ERR_BAD_ARG, "abi version mismatch");
+        if (!materials_and_textures()) return false;
+        for (uint32_t i = 0; i < d->n_spheres; i++) {
+            const vk_sphere &s = d->spheres[i];
+            if (s.material >= d->n_materials) return fail(VK_ERR_BAD_ARG, "material index out of range");
+            L.spheres.push_back(DSphere{s.center[0], s.center[1], s.center[2], s.radius});
+            L.sphere_mat.push_back(s.material);
+        }
+        for (uint32_t i = 0; i < d->n_moving_spheres; i++) {
+            const vk_moving_sphere &s = d->moving_spheres[i];
+            if (s.material >= d->n_materials) return fail(VK_ERR_BAD_ARG, "material index out of range");
+            DMoving m; memset(&m, 0, sizeof(m));
+            for (int k = 0; k < 3; k++) { m.c0[k] = s.center0[k]; m.c1[k] = s.center1[k]; }
+            m.t0 = s.time0; m.t1 = s.time1; m.r = s.radius; m.mat = s.material;
+            L.moving.push_back(m);
+        }
+        for (uint32_t i = 0; i < d->n_rects; i++) {
+            const vk_rect &s = d->rects[i];
+            if (s.material >= d->n_materials) return fail(VK_ERR_BAD_ARG, "material index out of range");
+            if (s.axis0 > 2 || s.axis1 > 2 || s.axis2 > 2) return fail(VK_ERR_BAD_ARG, "rect axis out of range");
+            DRect q; memset(&q, 0, sizeof(q));
+            q.c0 = s.c0; q.c1 = s.c1; q.d0 = s.d0; q.d1 = s.d1; q.k = s.k;
+            q.axes = (uint32_t)s.axis0 | ((uint32_t)s.axis1 << 2) | ((uint32_t)s.axis2 << 4); q.mat = s.material;
+            L.rects.push_back(q);
+        }
+        if (!check_ref(d->world)) return false;
+        if (VK_REF_KIND(d->world) == VK_KIND_BVH) {
+            if (!emit_bvh(VK_REF_INDEX(d->world), (d->world & VK_REF_FLIP) ? DREF_FLIP : 0u, -1)) return false;
+        } else {
+            DItem it; memset(&it, 0, sizeof(it));
+            it.w0 = VKD_MAKE(DK_PRIM_ITEM, 0);
+            L.items.push_back(it);
+            uint32_t a;
+            if (!convert_object(d->world, 0, -1, a)) return false;
+            L.items[0].w1 = a;
+            set_home(a, 1, 0);
+            L.n_prims = 1;
+        }
+        uint32_t world_end = (uint32_t)L.items.size();
+        if (!drain_pending()) return false;
+        // the world range must be [0, world_end): the kernel starts with end = n_items only
+        // when nothing follows; otherwise it uses world_end stored in items' owner (see api)
+        world_items = world_end;
+        for (uint32_t i = 0; i < d->n_lights; i++) {
+            vk_ref r = d->lights[i];
+            if (!check_ref(r)) return false;
+            uint32_t k = VK_REF_KIND(r);
+            uint32_t out = 0;   // kinds without pdf_value/random impls behave as the trait defaults
+            if (k == VK_KIND_SPHERE || k == VK_KIND_RECT) out = simple_dref(r, 0);
+            else if (k == VK_KIND_LIST) { uint32_t li; if (!convert_list(VK_REF_INDEX(r), li)) return false; out = VKD_MAKE(DK_LIST, li) | ((r & VK_REF_FLIP) ? DREF_FLIP : 0u); }
+            L.lights.push_back(out);
+        }
+        return status == VK_OK;
+    }
+    uint32_t world_items = 0;
+};
+
+}  // namespace
+
+int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err) {
+    Builder b(desc, out, err);
+    if (!b.run()) return b.status == VK_OK ? VK_ERR_BAD_ARG : b.status;
+    out.world_items = b.world_items;
+    return VK_OK;
+}
+
+}  // namespace vkd

@@ -1,0 +1,42 @@
+// vk_linearize.h — host-side conversion of the vk_scene_desc graph into the linear device
+// scene of vk_device_scene.h (threaded pre-order BVH items, SoA primitives, flattened
+// transform chains, baked material records).  Pure C++ (no HIP): also used by the CPU
+// emulator under tests/emu.
+#ifndef VK_LINEARIZE_H
+#define VK_LINEARIZE_H
+#include <string>
+#include <vector>
+
+#include "../../include/vecchio_amd.h"
+#include "vk_device_scene.h"
+
+namespace vkd {
+
+struct LinearScene {
+    std::vector<DItem> items;
+    std::vector<DSphere> spheres;
+    std::vector<uint32_t> sphere_mat;
+    std::vector<DMoving> moving;
+    std::vector<DRect> rects;
+    std::vector<DList> lists;
+    std::vector<uint32_t> list_refs;
+    std::vector<DMedium> media;
+    std::vector<DInstance> instances;
+    std::vector<DMaterial> materials;
+    std::vector<DTexture> textures;
+    std::vector<DImage> images;
+    std::vector<uint8_t> image_bytes;
+    std::vector<DPerlin> perlins;
+    std::vector<uint32_t> lights;
+    uint32_t features = 0;
+    uint32_t n_prims = 0;
+    uint32_t world_items = 0;   // items[0, world_items) is the world BVH; instance child ranges follow
+
+    DScene host_view() const;   // DScene whose pointers address these vectors
+};
+
+// returns VK_OK or an error code with `err` set
+int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err);
+
+}  // namespace vkd
+#endif

@@ -23,8 +23,13 @@
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define VK_HD __host__ __device__ __forceinline__
+// The f64 transcendental kernels are called once per bounce at most.  Kept out of line on the
+// device so that their ~60 double constants are not hoisted into (and spilled across) the
+// megakernel's persistent loop; arguments and results travel in registers.
+#define VK_COLD __host__ __device__ inline __attribute__((noinline))
 #else
 #define VK_HD inline
+#define VK_COLD inline
 #endif
 
 namespace vk {
@@ -153,7 +158,7 @@ VK_HD double k_cos(double r) {
     return (1.0 - 0.5 * z) + z * p;
 }
 
-VK_HD float sinf_(float xf) {
+VK_COLD float sinf_(float xf) {
     double x = (double)xf;
     if (!(x > -1.0e9 && x < 1.0e9)) return xf - xf;  // inf/NaN -> NaN; |x|>=1e9 unsupported -> 0
     double r;
@@ -163,7 +168,7 @@ VK_HD float sinf_(float xf) {
     return (float)v;
 }
 
-VK_HD float cosf_(float xf) {
+VK_COLD float cosf_(float xf) {
     double x = (double)xf;
     if (!(x > -1.0e9 && x < 1.0e9)) return xf - xf;
     double r;
@@ -173,8 +178,27 @@ VK_HD float cosf_(float xf) {
     return (float)v;
 }
 
+// sin and cos of the same angle, bit-identical to sinf_(x) and cosf_(x) (one reduction, one
+// evaluation of each kernel polynomial)
+struct SinCos { float s, c; };
+VK_COLD SinCos sincosf_(float xf) {
+    SinCos o;
+    double x = (double)xf;
+    if (!(x > -1.0e9 && x < 1.0e9)) { o.s = xf - xf; o.c = xf - xf; return o; }
+    double r;
+    int q = rem_pio2(x, r);
+    double ks = k_sin(r), kc = k_cos(r);
+    double vs = (q & 1) ? kc : ks;
+    double vc = (q & 1) ? ks : kc;
+    if (q & 2) vs = -vs;
+    if ((q + 1) & 2) vc = -vc;
+    o.s = (float)vs;
+    o.c = (float)vc;
+    return o;
+}
+
 // natural log (hittable.rs:473); x is a 24-bit draw in [0,1) there, general f32 supported
-VK_HD float logf_(float xf) {
+VK_COLD float logf_(float xf) {
     if (xf != xf) return xf;
     if (xf < 0.0f) return (xf - xf) / (xf - xf);  // NaN
     if (xf == 0.0f) return -INFINITY;
@@ -257,10 +281,10 @@ VK_HD double atan2_d(double y, double x) {
     return yneg ? -a : a;
 }
 
-VK_HD float atan2f_(float y, float x) { return (float)atan2_d((double)y, (double)x); }
+VK_COLD float atan2f_(float y, float x) { return (float)atan2_d((double)y, (double)x); }
 
 // asin(x) = atan2(x, sqrt((1-x)(1+x))); |x| > 1 -> NaN (hittable.rs:57)
-VK_HD float asinf_(float xf) {
+VK_COLD float asinf_(float xf) {
     double x = (double)xf;
     double c2 = (1.0 - x) * (1.0 + x);
     if (!(c2 >= 0.0)) return (float)((x - x) / (x - x));  // NaN

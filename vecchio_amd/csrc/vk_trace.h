@@ -1,0 +1,801 @@
+// vk_trace.h — per-lane path tracing logic of the megakernel (one ray per lane).
+//
+// This is NOT a translation of the reference's recursion: ray_color (main.rs:123-153) is
+// an iterative throughput loop, BVHNode::hit (accel.rs:58-83) is a stack-free threaded
+// pre-order walk over 32-byte items, hit records are DEFERRED (only t, primitive ref and
+// instance are tracked during traversal; p/normal/uv/front are built once for the closest
+// hit), AxisBB::hit (accel.rs:16-35) is decided with reciprocal multiplies and falls back to
+// the reference's divisions only when the decision is within rounding distance.  What is
+// kept bit-for-bit is every value that feeds control flow: t of every accepted hit, the hit
+// record of the closest hit, every draw (order and count) and every scatter direction.
+// Radiance arithmetic is re-associated (it never feeds control flow).
+//
+// Compiled for gfx950 by hipcc and for the host by g++ (tests/emu only), both with
+// -ffp-contract=off.  F = compile-time feature mask (VKF_*) selecting the kernel variant.
+#ifndef VK_TRACE_H
+#define VK_TRACE_H
+
+#include "../../include/vecchio_amd.h"
+#include "vk_device_scene.h"
+#include "vk_math.h"
+
+namespace vkd {
+
+using vk::Rng;
+
+// ------------------------------------------------------------------ vec3.rs (value semantics identical)
+struct V3 { float x, y, z; };
+VK_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+VK_HD V3 v3s(float s) { return v3(s, s, s); }
+VK_HD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+VK_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+VK_HD V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+VK_HD V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+VK_HD V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+VK_HD V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+VK_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+VK_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+VK_HD float length2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+VK_HD V3 unit(V3 a) { float n = sqrtf(length2(a)); return v3(a.x / n, a.y / n, a.z / n); }
+VK_HD float comp(V3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+VK_HD V3 ld3(const float *p) { return v3(p[0], p[1], p[2]); }
+
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr float T_MIN = 0.001f;  // main.rs:130
+
+struct RenderConsts {   // per-launch constants (camera + params)
+    vk_camera cam;
+    uint32_t width, height, spp, max_depth;
+    uint64_t seed;
+    uint32_t integrator, background;
+    float bg[3];
+};
+
+// ------------------------------------------------------------------ memory policies
+// Hot records (items, spheres) come either from HBM/L2 (GlobalMem) or from the workgroup's
+// LDS copy of the scene (LdsMem, set up by the kernel).
+struct GlobalMem {
+    const DItem *items; const DSphere *spheres; const uint32_t *sphere_mat;
+    VK_HD DItem item(uint32_t i) const { return items[i]; }
+    VK_HD DSphere sphere(uint32_t i) const { return spheres[i]; }
+    VK_HD uint32_t smat(uint32_t i) const { return sphere_mat[i]; }
+};
+
+// ------------------------------------------------------------------ per-lane state
+struct Lane {
+    // current-space ray (object space while inside an instance)
+    V3 o, d; float time;
+    V3 inv; float a; uint32_t exact_only;
+    V3 wo, wd;                 // world-space ray of this segment
+    // traversal cursor
+    uint32_t i, end, pend; int32_t cur_inst;
+    // closest hit so far (deferred record)
+    float T; uint32_t best_prim; int32_t best_inst; float best_aux;
+    // path
+    V3 thr, acc; uint32_t depth;
+    Rng rng;
+    uint32_t pixel, sample;
+};
+
+VK_HD void set_space(Lane &L, V3 o, V3 d) {
+    L.o = o; L.d = d;
+    L.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    L.a = length2(d);
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    // reciprocal-multiply slab test is only trusted when 1/d is a full-precision normal number
+    bool ok = ax > 1e-30f && ax < 1e30f && ay > 1e-30f && ay < 1e30f && az > 1e-30f && az < 1e30f;
+    L.exact_only = ok ? 0u : 1u;
+}
+
+// ------------------------------------------------------------------ instance transforms (hittable.rs:507-524,579-624,676-713,765-802)
+VK_HD void apply_op(const DOp &op, V3 &o, V3 &d) {
+    float s = op.a, c = op.b;
+    switch (op.kind) {
+        case OP_TRANSLATE: o = o - v3(op.a, op.b, op.c); break;                      // hittable.rs:508
+        case OP_ROTATE_Y: {                                                          // hittable.rs:591-595
+            float ox = c * o.x - s * o.z, oz = s * o.x + c * o.z; o.x = ox; o.z = oz;
+            float dx = c * d.x - s * d.z, dz = s * d.x + c * d.z; d.x = dx; d.z = dz; break; }
+        case OP_ROTATE_X: {                                                          // hittable.rs:680-684
+            float oy = c * o.y + s * o.z, oz = -s * o.y + c * o.z; o.y = oy; o.z = oz;
+            float dy = c * d.y + s * d.z, dz = -s * d.y + c * d.z; d.y = dy; d.z = dz; break; }
+        default: {                                                                   // hittable.rs:769-773
+            float ox = c * o.x + s * o.y, oy = -s * o.x + c * o.y; o.x = ox; o.y = oy;
+            float dx = c * d.x + s * d.y, dy = -s * d.x + c * d.y; d.x = dx; d.y = dy; break; }
+    }
+}
+VK_HD void unapply_op(const DOp &op, V3 &p, V3 &n) {
+    float s = op.a, c = op.b;
+    switch (op.kind) {
+        case OP_TRANSLATE: p = p + v3(op.a, op.b, op.c); break;                      // hittable.rs:511
+        case OP_ROTATE_Y: {                                                          // hittable.rs:603-607
+            float px = c * p.x + s * p.z, pz = -s * p.x + c * p.z; p.x = px; p.z = pz;
+            float nx = c * n.x + s * n.z, nz = -s * n.x + c * n.z; n.x = nx; n.z = nz; break; }
+        case OP_ROTATE_X: {                                                          // hittable.rs:692-696
+            float py = c * p.y - s * p.z, pz = s * p.y + c * p.z; p.y = py; p.z = pz;
+            float ny = c * n.y - s * n.z, nz = s * n.y + c * n.z; n.y = ny; n.z = nz; break; }
+        default: {                                                                   // hittable.rs:781-785
+            float px = c * p.x - s * p.y, py = s * p.x + c * p.y; p.x = px; p.y = py;
+            float nx = c * n.x - s * n.y, ny = s * n.x + c * n.y; n.x = nx; n.y = ny; break; }
+    }
+}
+// ray of instance `inst` (-1 = world) re-derived from the world ray: same ops, same order,
+// hence the same bits as when the instance was entered
+VK_HD void ray_in_instance(const DScene &S, int32_t inst, V3 wo, V3 wd, V3 &o, V3 &d) {
+    o = wo; d = wd;
+    if (inst < 0) return;
+    const DInstance &I = S.instances[inst];
+    for (uint32_t l = 0; l <= I.depth; l++) {
+        const DInstance &J = S.instances[I.chain[l]];
+        for (uint32_t k = 0; k < J.n_ops; k++) apply_op(J.ops[k], o, d);
+    }
+}
+
+// ------------------------------------------------------------------ primitive tests (t only)
+// Sphere::hit, hittable.rs:65-95: half-b quadratic, strict bounds, near root first
+VK_HD bool sphere_t(float cx, float cy, float cz, float r, V3 o, V3 d, float a, float tmin, float tmax, float &t) {
+    V3 oc = o - v3(cx, cy, cz);
+    float half_b = dot(oc, d);
+    float c = length2(oc) - r * r;
+    float disc = half_b * half_b - a * c;
+    if (disc > 0.0f) {
+        float root = sqrtf(disc);
+        float t1 = (-half_b - root) / a;
+        if (tmin < t1 && t1 < tmax) { t = t1; return true; }
+        float t2 = (-half_b + root) / a;
+        if (tmin < t2 && t2 < tmax) { t = t2; return true; }
+    }
+    return false;
+}
+VK_HD V3 moving_center(const DMoving &m, float time) {  // hittable.rs:147-150
+    V3 c0 = ld3(m.c0), c1 = ld3(m.c1);
+    return c0 + (c1 - c0) * ((time - m.t0) / (m.t1 - m.t0));
+}
+// Rect::hit, hittable.rs:230-239: inclusive bounds
+VK_HD bool rect_t(const DRect &q, V3 o, V3 d, float tmin, float tmax, float &t_out) {
+    uint32_t a0 = q.axes & 3u, a1 = (q.axes >> 2) & 3u, a2 = (q.axes >> 4) & 3u;
+    float t = (q.k - comp(o, a2)) / comp(d, a2);
+    if (t < tmin || t > tmax) return false;
+    float a = comp(o, a0) + t * comp(d, a0);
+    float b = comp(o, a1) + t * comp(d, a1);
+    if (a < q.c0 || a > q.c1 || b < q.d0 || b > q.d1) return false;
+    t_out = t;
+    return true;
+}
+// Sphere / MovingSphere / Rect by dref
+template <class Mem>
+VK_HD bool simple_t(const DScene &S, const Mem &M, uint32_t ref, V3 o, V3 d, float a, float time, float tmin, float tmax, float &t) {
+    uint32_t k = VKD_KIND(ref), idx = VKD_INDEX(ref);
+    if (k == DK_SPHERE) { DSphere s = M.sphere(idx); return sphere_t(s.cx, s.cy, s.cz, s.r, o, d, a, tmin, tmax, t); }
+    if (k == DK_RECT) return rect_t(S.rects[idx], o, d, tmin, tmax, t);
+    if (k == DK_MOVING) { const DMoving &m = S.moving[idx]; V3 c = moving_center(m, time); return sphere_t(c.x, c.y, c.z, m.r, o, d, a, tmin, tmax, t); }
+    return false;
+}
+// impl Hittable for Vec<Arc<..>>, hittable.rs:381-394: first wins ties (strict <)
+template <class Mem>
+VK_HD bool list_t(const DScene &S, const Mem &M, uint32_t list_ref, V3 o, V3 d, float a, float time, float tmin, float tmax, float &t, uint32_t &item) {
+    DList l = S.lists[VKD_INDEX(list_ref)];
+    float closest = tmax;
+    bool found = false;
+    for (uint32_t j = 0; j < l.count; j++) {
+        uint32_t r = S.list_refs[l.first + j];
+        float tt;
+        if (simple_t(S, M, r, o, d, a, time, tmin, closest, tt)) {
+            if (tt < closest) { closest = tt; item = r; found = true; }
+        }
+    }
+    t = closest;
+    return found;
+}
+// boundary.hit() for ConstantMedium (boundary is a Sphere, MovingSphere, Rect or a Boxy list)
+template <class Mem>
+VK_HD bool boundary_t(const DScene &S, const Mem &M, uint32_t ref, V3 o, V3 d, float a, float time, float tmin, float tmax, float &t, uint32_t &item) {
+    if (VKD_KIND(ref) == DK_LIST) {
+        bool h = list_t(S, M, ref, o, d, a, time, tmin, tmax, t, item);
+        if (h) item ^= (ref & DREF_FLIP);
+        return h;
+    }
+    item = ref;
+    return simple_t(S, M, ref, o, d, a, time, tmin, tmax, t);
+}
+
+// ------------------------------------------------------------------ AxisBB::hit (accel.rs:16-35)
+VK_HD bool slab_exact(const DItem &n, V3 o, V3 d, float tmin, float tmax) {
+    float lo = tmin, hi = tmax;
+    {
+        float q0 = (n.bmin[0] - o.x) / d.x, q1 = (n.bmax0 - o.x) / d.x;
+        lo = fmaxf(fminf(q0, q1), lo); hi = fminf(fmaxf(q0, q1), hi);
+        if (hi <= lo) return false;
+    }
+    {
+        float q0 = (n.bmin[1] - o.y) / d.y, q1 = (n.bmax1 - o.y) / d.y;
+        lo = fmaxf(fminf(q0, q1), lo); hi = fminf(fmaxf(q0, q1), hi);
+        if (hi <= lo) return false;
+    }
+    {
+        float q0 = (n.bmin[2] - o.z) / d.z, q1 = (n.bmax2 - o.z) / d.z;
+        lo = fmaxf(fminf(q0, q1), lo); hi = fminf(fmaxf(q0, q1), hi);
+        if (hi <= lo) return false;
+    }
+    return true;
+}
+// Same boolean as slab_exact, decided from reciprocal multiplies when the margin is clear:
+// both forms compute fl(b-o) identically; q~ = fl(fl(b-o)*fl(1/d)) differs from the
+// reference's fl(fl(b-o)/d) by < 3*2^-24 relative, and the three per-axis early-outs are
+// equivalent to one test max(lo..) < min(hi..) because lo only grows and hi only shrinks.
+VK_HD bool slab(const DItem &n, const Lane &L, float tmax) {
+    if (!L.exact_only) {
+        float x0 = (n.bmin[0] - L.o.x) * L.inv.x, x1 = (n.bmax0 - L.o.x) * L.inv.x;
+        float y0 = (n.bmin[1] - L.o.y) * L.inv.y, y1 = (n.bmax1 - L.o.y) * L.inv.y;
+        float z0 = (n.bmin[2] - L.o.z) * L.inv.z, z1 = (n.bmax2 - L.o.z) * L.inv.z;
+        float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));
+        float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
+        const float EP = 1.000002f;  // >> 2*(3*2^-24)
+        if (hi > lo * EP) return true;      // lo >= T_MIN > 0
+        if (hi * EP < lo) return false;     // also covers hi <= 0
+    }
+    return slab_exact(n, L.o, L.d, T_MIN, tmax);  // NaN/inf or within rounding distance: reference arithmetic
+}
+
+// ------------------------------------------------------------------ traversal
+VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time) {
+    L.wo = o; L.wd = d; L.time = time;
+    set_space(L, o, d);
+    L.i = 0; L.end = S.n_world_items; L.pend = 0; L.cur_inst = -1;
+    L.T = INFINITY; L.best_prim = 0; L.best_inst = -1; L.best_aux = 0.0f;
+}
+
+template <uint32_t F, class Mem>
+VK_HD void accept(Lane &L, float t, uint32_t prim, float aux) {
+    L.T = t; L.best_prim = prim; L.best_inst = L.cur_inst; L.best_aux = aux;
+}
+
+// ConstantMedium::hit, hittable.rs:453-493 (draws ONE number inside traversal)
+template <uint32_t F, class Mem>
+VK_HD void medium_test(Lane &L, const DScene &S, const Mem &M, uint32_t ref) {
+    const DMedium &m = S.media[VKD_INDEX(ref)];
+    float t1, t2; uint32_t it;
+    if (!boundary_t(S, M, m.boundary, L.o, L.d, L.a, L.time, -INFINITY, INFINITY, t1, it)) return;
+    if (!boundary_t(S, M, m.boundary, L.o, L.d, L.a, L.time, t1 + 0.0001f, INFINITY, t2, it)) return;
+    float e = t1, x = t2;
+    if (e < T_MIN) e = T_MIN;
+    if (x > L.T) x = L.T;
+    if (e >= x) return;
+    if (e < 0.0f) e = 0.0f;
+    float ray_length = sqrtf(length2(L.d));
+    float distance_inside = (x - e) * ray_length;
+    float hit_distance = m.neg_inv_density * vk::logf_(vk::gen_f32(L.rng));
+    if (hit_distance > distance_inside) return;
+    float t = e + hit_distance / ray_length;
+    // BVHNode::hit keeps the earlier hit only when l.t < r.t (accel.rs:73-77)
+    if (L.best_prim != 0 && L.T < t) return;
+    accept<F, Mem>(L, t, ref, t1);
+}
+
+template <uint32_t F, class Mem>
+VK_HD void enter_instance(Lane &L, const DScene &S, uint32_t ref) {
+    int32_t idx = (int32_t)VKD_INDEX(ref);
+    const DInstance &I = S.instances[idx];
+    V3 o = L.o, d = L.d;
+    for (uint32_t k = 0; k < I.n_ops; k++) apply_op(I.ops[k], o, d);
+    set_space(L, o, d);
+    L.cur_inst = idx;
+    if (I.child_end > I.child_begin) { L.i = I.child_begin; L.end = I.child_end; L.pend = 0; }
+    else { L.i = 0; L.end = 0; L.pend = I.child_ref; }
+}
+template <uint32_t F, class Mem>
+VK_HD void leave_instance(Lane &L, const DScene &S) {
+    const DInstance &I = S.instances[L.cur_inst];
+    int32_t P = I.parent;
+    L.i = I.home_next; L.pend = I.home_pend;
+    L.end = P < 0 ? S.n_world_items : S.instances[P].child_end;
+    L.cur_inst = P;
+    V3 o, d;
+    ray_in_instance(S, P, L.wo, L.wd, o, d);
+    set_space(L, o, d);
+}
+
+template <uint32_t F, class Mem>
+VK_HD void process_ref(Lane &L, const DScene &S, const Mem &M, uint32_t ref) {
+    uint32_t k = VKD_KIND(ref), idx = VKD_INDEX(ref);
+    float t;
+    bool is_sphere = (k == DK_SPHERE);
+    if (is_sphere || ((F & VKF_MOVING) && k == DK_MOVING)) {
+        float cx, cy, cz, r;
+        if (is_sphere) { DSphere s = M.sphere(idx); cx = s.cx; cy = s.cy; cz = s.cz; r = s.r; }
+        else { const DMoving &m = S.moving[idx]; V3 c = moving_center(m, L.time); cx = c.x; cy = c.y; cz = c.z; r = m.r; }
+        if (sphere_t(cx, cy, cz, r, L.o, L.d, L.a, T_MIN, L.T, t)) accept<F, Mem>(L, t, ref, 0.0f);
+        return;
+    }
+    if ((F & VKF_RECT) && k == DK_RECT) {
+        if (rect_t(S.rects[idx], L.o, L.d, T_MIN, L.T, t)) accept<F, Mem>(L, t, ref, 0.0f);
+        return;
+    }
+    if ((F & VKF_LIST) && k == DK_LIST) {
+        uint32_t item;
+        if (list_t(S, M, ref, L.o, L.d, L.a, L.time, T_MIN, L.T, t, item)) accept<F, Mem>(L, t, item ^ (ref & DREF_FLIP), 0.0f);
+        return;
+    }
+    if ((F & VKF_MEDIUM) && k == DK_MEDIUM) { medium_test<F, Mem>(L, S, M, ref); return; }
+    if ((F & VKF_INSTANCE) && k == DK_INSTANCE) { enter_instance<F, Mem>(L, S, ref); return; }
+}
+
+VK_HD bool traversing(const Lane &L) { return L.i < L.end || L.pend != 0 || L.cur_inst >= 0; }
+
+// One step of the threaded pre-order walk; call while traversing(L).  A step is either one
+// 32-byte item (box test; for a leaf also its first object) or one pending object (a leaf's
+// second child, which must see the tmax its sibling left behind: accel.rs:64-70).
+template <uint32_t F, class Mem>
+VK_HD void traverse_step(Lane &L, const DScene &S, const Mem &M) {
+    uint32_t ref = L.pend;
+    L.pend = 0;
+    if (ref == 0) {
+        if (L.i >= L.end) {
+            if (F & VKF_INSTANCE) { if (L.cur_inst >= 0) leave_instance<F, Mem>(L, S); }
+            return;
+        }
+        DItem n = M.item(L.i);
+        uint32_t k0 = n.w0 >> 28;
+        bool prim_item = (k0 == DK_PRIM_ITEM);               // object child beside a BVH child: no box of its own
+        bool h = prim_item ? true : slab(n, L, L.T);
+        if (k0 == 0) { L.i = h ? L.i + 1 : n.w0; return; }   // inner node: hit -> left subtree, miss -> skip link
+        L.i += 1;
+        if (!h) return;
+        ref = prim_item ? n.w1 : n.w0;                        // leaf: left object now, right object next step
+        L.pend = prim_item ? 0u : n.w1;
+    }
+    process_ref<F, Mem>(L, S, M, ref);
+}
+
+// ------------------------------------------------------------------ deferred hit record
+struct Rec { V3 p, n; float u, v; bool front; uint32_t mat; };
+
+VK_HD void spherical(V3 p, float &u, float &v) {  // hittable.rs:54-61
+    float phi = vk::atan2f_(p.z, p.x);
+    float theta = vk::asinf_(p.y);
+    u = 1.0f - ((phi + PI_F) / (2.0f * PI_F));
+    v = (theta + PI_F / 2.0f) / PI_F;
+}
+VK_HD void face(V3 d, V3 outward, V3 &n, bool &front) {  // hittable.rs:23-30
+    front = dot(d, outward) < 0.0f;
+    n = front ? outward : -outward;
+}
+
+// record of a Sphere/MovingSphere/Rect hit at t in the ray's own space
+template <class Mem>
+VK_HD void simple_record(const DScene &S, const Mem &M, uint32_t ref, V3 o, V3 d, float time, float t, bool want_uv, Rec &R) {
+    uint32_t k = VKD_KIND(ref), idx = VKD_INDEX(ref);
+    R.u = 0.0f; R.v = 0.0f;
+    if (k == DK_RECT) {
+        const DRect &q = S.rects[idx];
+        uint32_t a0 = q.axes & 3u, a1 = (q.axes >> 2) & 3u, a2 = (q.axes >> 4) & 3u;
+        float a = comp(o, a0) + t * comp(d, a0);
+        float b = comp(o, a1) + t * comp(d, a1);
+        R.u = (a - q.c0) / (q.c1 - q.c0);
+        R.v = (b - q.d0) / (q.d1 - q.d0);
+        R.p = o + d * t;
+        V3 outward = v3(a2 == 0 ? 1.0f : 0.0f, a2 == 1 ? 1.0f : 0.0f, a2 == 2 ? 1.0f : 0.0f);
+        face(d, outward, R.n, R.front);
+        R.mat = q.mat;
+    } else {
+        V3 c; float r;
+        if (k == DK_SPHERE) { DSphere s = M.sphere(idx); c = v3(s.cx, s.cy, s.cz); r = s.r; R.mat = M.smat(idx); }
+        else { const DMoving &m = S.moving[idx]; c = moving_center(m, time); r = m.r; R.mat = m.mat; }
+        R.p = o + d * t;
+        V3 outward = (R.p - c) / r;
+        face(d, outward, R.n, R.front);
+        if (want_uv) spherical(outward, R.u, R.v);
+    }
+    if (ref & DREF_FLIP) R.front = !R.front;
+}
+
+VK_HD bool mat_wants_uv(const DMaterial &m) {
+    return m.kind == VK_MAT_SPEC_DIFFUSE || (m.kind != VK_MAT_DIELECTRIC && (m.tex_kind == VK_TEX_IMAGE || m.tex_kind == VK_TEX_CHECKER));
+}
+
+template <uint32_t F, class Mem>
+VK_HD void build_record(const Lane &L, const DScene &S, const Mem &M, Rec &R) {
+    V3 o = L.wo, d = L.wd;
+    if (F & VKF_INSTANCE) ray_in_instance(S, L.best_inst, L.wo, L.wd, o, d);
+    uint32_t ref = L.best_prim;
+    uint32_t k = VKD_KIND(ref);
+    if ((F & VKF_MEDIUM) && k == DK_MEDIUM) {       // hittable.rs:479-489
+        const DMedium &m = S.media[VKD_INDEX(ref)];
+        R.p = o + d * L.T;
+        R.n = v3(1.0f, 0.0f, 0.0f);
+        R.front = true;
+        R.mat = m.mat;
+        R.u = 0.0f; R.v = 0.0f;
+        if ((F & VKF_TEXTURES) && mat_wants_uv(S.materials[m.mat])) {   // rec1.u, rec1.v of the boundary's entry hit
+            float a = length2(d), t1; uint32_t it;
+            if (boundary_t(S, M, m.boundary, o, d, a, L.time, -INFINITY, INFINITY, t1, it)) {
+                Rec B;
+                simple_record(S, M, it, o, d, L.time, t1, true, B);
+                R.u = B.u; R.v = B.v;
+            }
+        }
+        if (ref & DREF_FLIP) R.front = !R.front;
+    } else {
+        bool want_uv = false;
+        if (F & VKF_TEXTURES) {
+            uint32_t mi = (k == DK_SPHERE) ? M.smat(VKD_INDEX(ref)) : (k == DK_RECT ? S.rects[VKD_INDEX(ref)].mat : S.moving[VKD_INDEX(ref)].mat);
+            want_uv = mat_wants_uv(S.materials[mi]);
+        }
+        simple_record(S, M, ref, o, d, L.time, L.T, want_uv, R);
+    }
+    if (F & VKF_INSTANCE) {
+        if (L.best_inst >= 0) {
+            const DInstance &I = S.instances[L.best_inst];
+            for (int32_t l = (int32_t)I.depth; l >= 0; l--) {
+                const DInstance &J = S.instances[I.chain[l]];
+                for (int32_t kk = (int32_t)J.n_ops - 1; kk >= 0; kk--) {
+                    unapply_op(J.ops[kk], R.p, R.n);
+                    // direction of the ray AFTER op (l,kk), re-derived from the world direction
+                    V3 oo = L.wo, dd = L.wd;
+                    for (int32_t l2 = 0; l2 <= l; l2++) {
+                        const DInstance &J2 = S.instances[I.chain[l2]];
+                        int32_t last = (l2 == l) ? kk : (int32_t)J2.n_ops - 1;
+                        for (int32_t k2 = 0; k2 <= last; k2++) apply_op(J2.ops[k2], oo, dd);
+                    }
+                    face(dd, R.n, R.n, R.front);   // set_face_normal(&moved_r / &rotated_r, normal)
+                }
+                if (J.flip) R.front = !R.front;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ textures (material.rs:228-434)
+VK_HD float perlin_noise(const DPerlin &P, V3 p) {  // material.rs:392-413 + perlin_interp 331-352
+    float u = p.x - floorf(p.x), v = p.y - floorf(p.y), w = p.z - floorf(p.z);
+    uint32_t i = vk::usize_low8(floorf(p.x)), j = vk::usize_low8(floorf(p.y)), k = vk::usize_low8(floorf(p.z));
+    float uu = u * u * (3.0f - 2.0f * u), vv = v * v * (3.0f - 2.0f * v), ww = w * w * (3.0f - 2.0f * w);
+    float accum = 0.0f;
+    for (uint32_t di = 0; di < 2; di++)
+        for (uint32_t dj = 0; dj < 2; dj++)
+            for (uint32_t dk = 0; dk < 2; dk++) {
+                uint32_t h = (uint32_t)P.perm_x[(i + di) & 255u] ^ (uint32_t)P.perm_y[(j + dj) & 255u] ^ (uint32_t)P.perm_z[(k + dk) & 255u];
+                V3 c = ld3(P.ranvec[h]);
+                float fi = (float)di, fj = (float)dj, fk = (float)dk;
+                V3 wv = v3(u - fi, v - fj, w - fk);
+                accum += (fi * uu + (1.0f - fi) * (1.0f - uu)) * (fj * vv + (1.0f - fj) * (1.0f - vv)) *
+                         (fk * ww + (1.0f - fk) * (1.0f - ww)) * dot(c, wv);
+            }
+    return accum;
+}
+VK_HD float perlin_turb(const DPerlin &P, V3 p, int depth) {  // material.rs:379-390
+    float accum = 0.0f, weight = 1.0f;
+    V3 tp = p;
+    for (int i = 0; i < depth; i++) {
+        accum += weight * perlin_noise(P, tp);
+        weight *= 0.5f;
+        tp = tp * 2.0f;
+    }
+    return fabsf(accum);
+}
+VK_HD V3 texture_value(const DScene &S, uint32_t tex, float u, float v, V3 p) {
+    for (int guard = 0; guard < 16; guard++) {
+        const DTexture &t = S.textures[tex];
+        if (t.kind == VK_TEX_SOLID) return v3(t.r, t.g, t.b);
+        if (t.kind == VK_TEX_CHECKER) {  // material.rs:250-258
+            float sins = vk::sinf_(10.0f * p.x) * vk::sinf_(10.0f * p.y) * vk::sinf_(10.0f * p.z);
+            tex = sins < 0.0f ? t.a : t.b_;
+            continue;
+        }
+        if (t.kind == VK_TEX_IMAGE) {  // material.rs:283-303
+            const DImage &im = S.images[t.a];
+            float uc = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
+            float vc0 = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+            float vc = 1.0f - vc0;
+            uint32_t i = vk::sat_u32(uc * (float)im.width), j = vk::sat_u32(vc * (float)im.height);
+            if (i >= im.width) i = im.width - 1;
+            if (j >= im.height) j = im.height - 1;
+            const uint8_t *pix = S.image_bytes + im.offset + ((uint64_t)j * im.width + i) * 3u;
+            float cs = 1.0f / 255.0f;
+            return v3(cs * (float)pix[0], cs * (float)pix[1], cs * (float)pix[2]);
+        }
+        // VK_TEX_NOISE, material.rs:430-434: Vec3::new_const(1.0) * 0.5 * (1.0 + sin(..))
+        const DPerlin &P = S.perlins[t.a];
+        float s = 1.0f + vk::sinf_(t.scale * p.z + 10.0f * perlin_turb(P, p, 7));
+        return (v3s(1.0f) * 0.5f) * s;
+    }
+    return v3s(0.0f);
+}
+VK_HD V3 material_color(const DScene &S, const DMaterial &m, const Rec &R) {
+    if (m.tex_kind == VK_TEX_SOLID) return v3(m.r, m.g, m.b);
+    return texture_value(S, m.tex, R.u, R.v, R.p);
+}
+
+// ------------------------------------------------------------------ samplers (util.rs:31-63, material.rs:51-58)
+VK_HD V3 random_in_unit_sphere(Rng &g) {
+    for (;;) {
+        float x = vk::gen_range(g, -1.0f, 1.0f), y = vk::gen_range(g, -1.0f, 1.0f), z = vk::gen_range(g, -1.0f, 1.0f);
+        V3 p = v3(x, y, z);
+        if (length2(p) >= 1.0f) continue;
+        return p;
+    }
+}
+VK_HD V3 random_in_unit_disk(Rng &g) {
+    for (;;) {
+        float x = vk::gen_range(g, -1.0f, 1.0f), y = vk::gen_range(g, -1.0f, 1.0f);
+        V3 p = v3(x, y, 0.0f);
+        if (length2(p) >= 1.0f) continue;
+        return p;
+    }
+}
+VK_HD V3 random_cosine_direction(Rng &g) {
+    float r1 = vk::gen_f32(g), r2 = vk::gen_f32(g);
+    float z = sqrtf(1.0f - r2);
+    float phi = 2.0f * r1 * PI_F;
+    vk::SinCos sc = vk::sincosf_(phi);
+    float x = sc.c * sqrtf(r2);
+    float y = sc.s * sqrtf(r2);
+    return v3(x, y, z);
+}
+VK_HD V3 lambertian_random(Rng &g) {
+    float a = vk::gen_range(g, 0.0f, 2.0f * PI_F);
+    float z = vk::gen_range(g, -1.0f, 1.0f);
+    float r = sqrtf(1.0f - z * z);
+    vk::SinCos sc = vk::sincosf_(a);
+    return v3(r * sc.c, r * sc.s, z);
+}
+VK_HD V3 reflect(V3 v, V3 n) { return v - n * dot(v, n) * 2.0f; }  // util.rs:14-16
+VK_HD V3 refract(V3 uv, V3 n, float eta) {                          // util.rs:18-23
+    float cos_theta = -dot(uv, n);
+    V3 par = (uv + n * cos_theta) * eta;
+    V3 perp = n * -sqrtf(1.0f - length2(par));
+    return par + perp;
+}
+VK_HD float schlick(float cosine, float ref_idx) {                   // util.rs:25-29
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * vk::pow5f_(1.0f - cosine);
+}
+struct Onb { V3 u, v, w; };
+VK_HD Onb onb_from_w(V3 n) {                                         // util.rs:99-110
+    Onb o;
+    o.w = unit(n);
+    V3 a = fabsf(o.w.x) > 0.9f ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f);
+    o.v = unit(cross(o.w, a));
+    o.u = cross(o.w, o.v);
+    return o;
+}
+VK_HD V3 onb_local(const Onb &o, V3 a) { return o.u * a.x + o.v * a.y + o.w * a.z; }
+
+// ------------------------------------------------------------------ light sampling (hittable.rs pdf_value / random)
+// pdf_value of an un-flipped Rect / Sphere
+template <class Mem>
+VK_HD float leaf_pdf_value(const DScene &S, const Mem &M, uint32_t ref, V3 o, V3 v) {
+    uint32_t k = VKD_KIND(ref), idx = VKD_INDEX(ref);
+    float t;
+    if (k == DK_RECT) {                            // hittable.rs:271-282
+        const DRect &q = S.rects[idx];
+        if (rect_t(q, o, v, T_MIN, INFINITY, t)) {
+            uint32_t a2 = (q.axes >> 4) & 3u;
+            V3 outward = v3(a2 == 0 ? 1.0f : 0.0f, a2 == 1 ? 1.0f : 0.0f, a2 == 2 ? 1.0f : 0.0f), n; bool fr;
+            face(v, outward, n, fr);
+            float area = (q.c1 - q.c0) * (q.d1 - q.d0);
+            float distance_squared = t * t * length2(v);
+            float cosine = fabsf(dot(v, n)) / sqrtf(length2(v));
+            return distance_squared / (cosine * area);
+        }
+        return 0.0f;
+    }
+    if (k == DK_SPHERE) {                          // hittable.rs:104-113
+        DSphere s = M.sphere(idx);
+        if (sphere_t(s.cx, s.cy, s.cz, s.r, o, v, length2(v), T_MIN, INFINITY, t)) {
+            float cos_theta_max = sqrtf(1.0f - s.r * s.r / length2(v3(s.cx, s.cy, s.cz) - o));
+            float solid_angle = 2.0f * PI_F * (1.0f - cos_theta_max);
+            return 1.0f / solid_angle;
+        }
+        return 0.0f;
+    }
+    return 0.0f;                                   // trait default, hittable.rs:36-38
+}
+template <class Mem>
+VK_HD float object_pdf_value(const DScene &S, const Mem &M, uint32_t ref, V3 o, V3 v) {
+    if (ref & DREF_FLIP) return 0.0f;              // FlipFace does not forward pdf_value (trait default)
+    if (VKD_KIND(ref) == DK_LIST) {                // Boxy::pdf_value -> Vec::pdf_value, hittable.rs:371-373,420-427
+        DList l = S.lists[VKD_INDEX(ref)];
+        float weight = 1.0f / (float)l.count;
+        float sum = 0.0f;
+        for (uint32_t j = 0; j < l.count; j++) {
+            uint32_t r = S.list_refs[l.first + j];
+            float pv = (r & DREF_FLIP) ? 0.0f : leaf_pdf_value(S, M, r, o, v);
+            sum += weight * pv;
+        }
+        return sum;
+    }
+    return leaf_pdf_value(S, M, ref, o, v);
+}
+VK_HD V3 random_to_sphere(Rng &g, float radius, float distance_squared) {  // hittable.rs:123-134 (sic: 1-z*z)
+    float r1 = vk::gen_f32(g), r2 = vk::gen_f32(g);
+    float z = 1.0f + r2 * (sqrtf(1.0f - radius * radius / distance_squared) - 1.0f);
+    float phi = 2.0f * PI_F * r1;
+    vk::SinCos sc = vk::sincosf_(phi);
+    float x = sc.c * (1.0f - z * z);
+    float y = sc.s * (1.0f - z * z);
+    return v3(x, y, z);
+}
+template <class Mem>
+VK_HD V3 object_random(const DScene &S, const Mem &M, Rng &g, uint32_t ref, V3 o) {
+    if (!(ref & DREF_FLIP)) {
+        uint32_t k = VKD_KIND(ref), idx = VKD_INDEX(ref);
+        if (k == DK_LIST) {                        // Vec::random, hittable.rs:429-433
+            DList l = S.lists[idx];
+            if (l.count == 0) return v3(1.0f, 0.0f, 0.0f);
+            ref = S.list_refs[l.first + vk::gen_index(g, l.count)];
+            if (ref & DREF_FLIP) return v3(1.0f, 0.0f, 0.0f);
+            k = VKD_KIND(ref); idx = VKD_INDEX(ref);
+        }
+        if (k == DK_RECT) {                        // hittable.rs:284-292
+            const DRect &q = S.rects[idx];
+            uint32_t a0 = q.axes & 3u, a1 = (q.axes >> 2) & 3u;
+            float ra = vk::gen_range(g, q.c0, q.c1);
+            float rb = vk::gen_range(g, q.d0, q.d1);
+            float px = a0 == 0 ? ra : (a1 == 0 ? rb : q.k);
+            float py = a0 == 1 ? ra : (a1 == 1 ? rb : q.k);
+            float pz = a0 == 2 ? ra : (a1 == 2 ? rb : q.k);
+            return v3(px, py, pz) - o;
+        }
+        if (k == DK_SPHERE) {                      // hittable.rs:115-120
+            DSphere s = M.sphere(idx);
+            V3 direction = v3(s.cx, s.cy, s.cz) - o;
+            float distance_squared = length2(direction);
+            Onb uvw = onb_from_w(direction);
+            return onb_local(uvw, random_to_sphere(g, s.r, distance_squared));
+        }
+    }
+    return v3(1.0f, 0.0f, 0.0f);                   // trait default, hittable.rs:39-41
+}
+
+// ------------------------------------------------------------------ camera + sample start (main.rs:111-120,187-189)
+VK_HD void start_sample(Lane &L, const DScene &S, const RenderConsts &C, uint32_t x, uint32_t y, uint32_t sample) {
+    uint32_t pixel = y * C.width + x;                         // main.rs:182-183
+    L.pixel = pixel; L.sample = sample;
+    L.rng = vk::rng_for_sample(C.seed, pixel, sample);
+    float u = ((float)x + vk::gen_f32(L.rng)) / (float)(C.width - 1);
+    float v = ((float)y + vk::gen_f32(L.rng)) / (float)(C.height - 1);
+    V3 rd = random_in_unit_disk(L.rng) * C.cam.lens_radius;
+    V3 offset = ld3(C.cam.u) * rd.x + ld3(C.cam.v) * rd.y;
+    V3 org = ld3(C.cam.origin);
+    V3 o = org + offset;
+    V3 d = ld3(C.cam.lower_left_corner) + ld3(C.cam.horizontal) * u + ld3(C.cam.vertical) * v - org - offset;
+    float time = vk::gen_range(L.rng, C.cam.time0, C.cam.time1);
+    L.thr = v3s(1.0f); L.acc = v3s(0.0f); L.depth = 1;
+    begin_segment(L, S, o, d, time);
+}
+
+VK_HD V3 background_of(const RenderConsts &C, V3 d) {
+    if (C.background == VK_BACKGROUND_SKY) {
+        V3 ud = unit(d);
+        float t = 0.5f * (ud.y + 1.0f);
+        return v3s(1.0f) * (1.0f - t) + v3(0.5f, 0.7f, 1.0f) * t;
+    }
+    return v3(C.bg[0], C.bg[1], C.bg[2]);
+}
+
+// Called when traversal of the current segment has finished.  Returns true when a new
+// segment was set up (keep traversing), false when the path ended (L.acc is its radiance).
+template <uint32_t F, class Mem>
+VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) {
+    if (L.best_prim == 0) {                                   // miss: main.rs:150-152
+        L.acc = L.acc + L.thr * background_of(C, L.wd);
+        return false;
+    }
+    Rec R;
+    build_record<F, Mem>(L, S, M, R);
+    V3 rd = L.wd;                                             // `r` of ray_color is the world-space ray
+    const DMaterial *m = &S.materials[R.mat];
+    V3 ndir; float ntime = L.time;
+    if (!(F & VKF_INTEG_PDF)) {
+        // emitted + attenuation * ray_color(scattered): Material::emitted + Material::scatter
+        V3 emitted = v3s(0.0f);
+        V3 atten;
+        bool scattered = true;
+        uint32_t kind = m->kind;
+        if (kind == VK_MAT_LAMBERTIAN) {                      // material.rs:85-90
+            ndir = R.n + lambertian_random(L.rng);
+            atten = material_color(S, *m, R);
+        } else if (kind == VK_MAT_METAL) {                    // material.rs:118-132
+            V3 reflected = reflect(unit(rd), R.n);
+            ndir = reflected + random_in_unit_sphere(L.rng) * m->param;
+            atten = material_color(S, *m, R);
+            scattered = dot(ndir, R.n) > 0.0f;
+        } else if (kind == VK_MAT_DIELECTRIC) {               // material.rs:150-175
+            atten = v3s(1.0f);
+            float eta = R.front ? 1.0f / m->param : m->param;
+            V3 ud = unit(rd);
+            float cos_theta = fminf(dot(-ud, R.n), 1.0f);
+            float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+            if (eta * sin_theta > 1.0f) ndir = reflect(ud, R.n);
+            else {
+                float reflect_prob = schlick(cos_theta, eta);
+                if (vk::gen_f32(L.rng) < reflect_prob) ndir = reflect(ud, R.n);
+                else ndir = refract(ud, R.n, eta);
+            }
+        } else if (kind == VK_MAT_ISOTROPIC) {                // material.rs:442-446
+            ndir = random_in_unit_sphere(L.rng);
+            atten = material_color(S, *m, R);
+        } else {                                              // DiffuseLight: material.rs:215-225
+            scattered = false;
+            if (kind == VK_MAT_DIFFUSE_LIGHT && R.front) emitted = material_color(S, *m, R);
+        }
+        L.acc = L.acc + L.thr * emitted;
+        if (!scattered) return false;
+        L.thr = L.thr * atten;
+    } else {
+        // HEAD integrator, main.rs:131-149
+        V3 emitted = v3s(0.0f);
+        if (m->kind == VK_MAT_DIFFUSE_LIGHT) {
+            if (R.front) emitted = material_color(S, *m, R);
+            L.acc = L.acc + L.thr * emitted;                  // scatter_with_pdf is None: return emitted
+            return false;
+        }
+        const DMaterial *outer = m;
+        if (F & VKF_SPEC_DIFFUSE) {
+            for (int guard = 0; guard < 8 && m->kind == VK_MAT_SPEC_DIFFUSE; guard++) {   // material.rs:475-483
+                uint32_t pick = vk::gen_f32(L.rng) < m->param ? (m->ab & 0xFFFFu) : (m->ab >> 16);
+                m = &S.materials[pick];
+            }
+            if (m->kind == VK_MAT_DIFFUSE_LIGHT) { L.acc = L.acc + L.thr * emitted; return false; }
+        }
+        uint32_t kind = m->kind;
+        if (kind == VK_MAT_METAL) {                           // material.rs:134-141 (Ray::new: time 0, never absorbs)
+            V3 reflected = reflect(unit(rd), R.n);
+            ndir = reflected + random_in_unit_sphere(L.rng) * m->param;
+            ntime = 0.0f;
+            L.thr = L.thr * material_color(S, *m, R);         // specular: emitted is NOT added (main.rs:134-137)
+        } else if (kind == VK_MAT_DIELECTRIC) {               // material.rs:177-206
+            float eta = R.front ? 1.0f / m->param : m->param;
+            V3 ud = unit(rd);
+            float cos_theta = fminf(dot(-ud, R.n), 1.0f);
+            float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+            if (eta * sin_theta > 1.0f) ndir = reflect(ud, R.n);
+            else {
+                float reflect_prob = schlick(cos_theta, eta);
+                if (vk::gen_f32(L.rng) < reflect_prob) ndir = reflect(ud, R.n);
+                else ndir = refract(ud, R.n, eta);
+            }
+        } else {                                              // Lambertian / Isotropic: material.rs:92-98,448-454
+            V3 atten = material_color(S, *m, R);
+            Onb uvw = onb_from_w(R.n);                        // CosinePDF::new(rec.normal)
+            // MixturePDF::generate, util.rs:177-185
+            if (vk::gen_f32(L.rng) < 0.5f) {
+                // HittablePDF::generate -> lights.random(o): Vec::random, hittable.rs:429-433
+                uint32_t li = vk::gen_index(L.rng, S.n_lights);
+                ndir = object_random(S, M, L.rng, S.lights[li], R.p);
+            } else {
+                ndir = onb_local(uvw, random_cosine_direction(L.rng));
+            }
+            // MixturePDF::value, util.rs:173-175
+            float weight = 1.0f / (float)S.n_lights;          // Vec::pdf_value, hittable.rs:420-427
+            float lsum = 0.0f;
+            for (uint32_t j = 0; j < S.n_lights; j++) lsum += weight * object_pdf_value(S, M, S.lights[j], R.p, ndir);
+            float cosv = dot(unit(ndir), uvw.w);              // CosinePDF::value, util.rs:134-142
+            float cpdf = cosv <= 0.0f ? 0.0f : cosv / PI_F;
+            float pdf = 0.5f * lsum + 0.5f * cpdf;
+            // scattering_pdf of the OUTER material (main.rs:145; SpecDiffuse forwards to its diffuse child)
+            const DMaterial *sm = outer;
+            if (F & VKF_SPEC_DIFFUSE) {
+                for (int guard = 0; guard < 8 && sm->kind == VK_MAT_SPEC_DIFFUSE; guard++) sm = &S.materials[sm->ab >> 16];
+            }
+            float spdf = 0.0f;
+            if (sm->kind == VK_MAT_LAMBERTIAN || sm->kind == VK_MAT_ISOTROPIC) {   // material.rs:100-108,456-464
+                float cs = dot(R.n, unit(ndir));
+                spdf = cs < 0.0f ? 0.0f : cs / PI_F;
+            }
+            L.acc = L.acc + L.thr * emitted;
+            L.thr = (L.thr * (atten * spdf)) / pdf;
+        }
+    }
+    L.depth += 1;
+    if (L.depth > C.max_depth) {                              // main.rs:126-128: the next call returns 0
+        L.acc = L.acc + L.thr * v3s(0.0f);                    // keeps the reference's 0*inf / 0/0 -> NaN drops
+        return false;
+    }
+    begin_segment(L, S, R.p, ndir, ntime);
+    return true;
+}
+
+}  // namespace vkd
+#endif
