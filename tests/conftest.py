@@ -1,0 +1,62 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Build (if stale) every native library; hipcc cross-compiles gfx950 without a GPU."""
+    from vecchio_amd import build
+    build.build_host()
+    build.build_oracle()
+    build.build_emu()
+    build.build_device()
+    return True
+
+
+@pytest.fixture(scope="session")
+def oracle(built):
+    import oracle_ffi
+    oracle_ffi.load()
+    return oracle_ffi
+
+
+@pytest.fixture(scope="session")
+def emu(built):
+    import emu_ffi
+    emu_ffi.load()
+    return emu_ffi
+
+
+@pytest.fixture(scope="session")
+def host_scenes(built):
+    from vecchio_amd import HostScene
+    cache = {}
+
+    def get(name, seed=1):
+        key = (name, seed)
+        if key not in cache:
+            hs = HostScene(name, seed)
+            cache[key] = (hs, hs.next_camera())
+        return cache[key]
+
+    return get
+
+
+@pytest.fixture(scope="session")
+def device(built):
+    """The HIP library on a real GPU; fails loudly (never falls back) when it is unusable."""
+    from vecchio_amd import ffi
+    lib = ffi.load_device_lib()
+    n = lib.vk_device_count()
+    assert n >= 1, "no gfx950 device visible: -m gpu tests need the MI355X box"
+    return lib

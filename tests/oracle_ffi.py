@@ -58,6 +58,20 @@ def render(desc, cam, params, threads=None):
     return out, cnt
 
 
+def render_samples(desc, cam, params, threads=None):
+    """returns (image, per_sample[n,4]) — per_sample[:,3] is the draw count bit pattern"""
+    lib = load()
+    lib.oracle_render_samples.restype = C.c_int
+    lib.oracle_render_samples.argtypes = [C.POINTER(ffi.SceneDesc), C.POINTER(ffi.Camera), C.POINTER(ffi.RenderParams),
+                                          C.c_void_p, C.c_void_p, C.c_int]
+    img = np.zeros((params.height, params.width, 3), dtype=np.float32)
+    ps = np.zeros((params.width * params.height * params.samples_per_pixel, 4), dtype=np.float32)
+    st = lib.oracle_render_samples(desc, C.byref(cam), C.byref(params), img.ctypes.data, ps.ctypes.data, threads or (os.cpu_count() or 1))
+    if st != 0:
+        raise RuntimeError(f"oracle status {st}: {lib.oracle_last_error().decode()}")
+    return img, ps
+
+
 def sample(desc, cam, params, pixel, s):
     lib = load()
     rgb = (C.c_float * 3)()

@@ -1,0 +1,118 @@
+"""Small hand-built scenes that exercise the corners of the scene graph the reference's own
+builders do not (or only barely) reach: nested transform chains, mixed BVH children, flipped
+subtrees, a Boxy light, a sphere light, SpecDiffuse, box-bounded media, image-textured media."""
+import numpy as np
+
+from descs import Desc, camera, params
+from vecchio_amd import ffi
+
+
+def _room(d, light_ref_list):
+    """a closed grey box room with an XZ light near the ceiling; returns list of world refs"""
+    white = d.lambertian(0.73, 0.73, 0.73)
+    red = d.lambertian(0.65, 0.05, 0.05)
+    refs = [
+        Desc.flip(d.yz_rect(0, 10, 0, 10, 10, red)), d.yz_rect(0, 10, 0, 10, 0, white),
+        Desc.flip(d.xz_rect(0, 10, 0, 10, 0, white)), d.xz_rect(0, 10, 0, 10, 10, white),
+        Desc.flip(d.xy_rect(0, 10, 0, 10, 10, white)),
+    ]
+    lm = d.light(12, 12, 12)
+    ls = d.xz_rect(3, 7, 3, 7, 9.9, lm)
+    refs.append(Desc.flip(ls))
+    light_ref_list.append(ls)
+    return refs
+
+
+def _bvh_chain(d, refs):
+    """left-deep BVH with huge boxes: exercises traversal order/tie rules, not culling"""
+    node = d.big_box(refs[0], refs[1]) if len(refs) > 1 else d.big_box(refs[0], refs[0])
+    for r in refs[2:]:
+        node = d.big_box(node, r)          # BVH child on the left, object child on the right (mixed)
+    return node
+
+
+def nested_transforms():
+    d = Desc()
+    lights = []
+    refs = _room(d, lights)
+    glass = d.mat(ffi.VK_MAT_DIELECTRIC, 0, 1.5)
+    metal = d.mat(ffi.VK_MAT_METAL, d.solid(0.8, 0.8, 0.9), 0.3)
+    box = d.boxy((0, 0, 0), (2, 3, 2), d.lambertian(0.2, 0.6, 0.3))
+    # 5 wrappers -> splits into nested instance records (MAX_OPS = 4)
+    chain = d.translate(d.rotate(d.rotate(d.rotate(d.translate(box, (0.5, 0, 0.5)), 0, 10.0), 2, -7.0), 1, 25.0), (3, 0, 4))
+    refs.append(chain)
+    # an instanced BVH of spheres, itself containing an instance
+    inner = d.big_box(d.sphere((0, 0, 0), 0.7, glass), d.translate(d.sphere((0, 0, 0), 0.5, metal), (0, 1.4, 0)))
+    refs.append(d.translate(d.rotate(inner, 1, 40.0), (7, 1.0, 6)))
+    refs.append(Desc.flip(d.translate(d.sphere((0, 0, 0), 0.6, d.lambertian(0.9, 0.5, 0.1)), (2, 0.6, 8))))
+    world = _bvh_chain(d, refs)
+    desc = d.finish(world, lights)
+    cam = camera((5, 5, -12), (5, 5, 0), vfov=40.0)
+    return d, desc, cam, params(48, 48, 8)
+
+
+def lights_and_specdiffuse():
+    d = Desc()
+    lights = []
+    refs = _room(d, lights)
+    # a sphere light and a Boxy light in the lights list (hittable.rs:104-134, 371-377)
+    sl = d.sphere((2, 8, 2), 0.5, d.light(20, 18, 15))
+    refs.append(sl)
+    lights.append(sl)
+    bl = d.boxy((7, 7, 7), (8, 8, 8), d.light(10, 10, 14))
+    refs.append(bl)
+    lights.append(bl)
+    lights.append(Desc.flip(lights[0]))     # a FlipFace in lights: trait defaults (pdf 0, direction (1,0,0))
+    spec = d.mat(ffi.VK_MAT_METAL, d.solid(0.9, 0.9, 0.9), 0.05)
+    diff = d.lambertian(0.3, 0.3, 0.8)
+    sd = d.mat(ffi.VK_MAT_SPEC_DIFFUSE, 0, 0.4, spec, diff)
+    refs.append(d.sphere((5, 2, 5), 2.0, sd))
+    world = _bvh_chain(d, refs)
+    desc = d.finish(world, lights)
+    cam = camera((5, 5, -12), (5, 5, 0), vfov=40.0)
+    return d, desc, cam, params(48, 48, 8)
+
+
+def media_and_textures():
+    d = Desc()
+    lights = []
+    refs = _room(d, lights)
+    rng = np.random.default_rng(5)
+    tex = d.image(rng.integers(0, 256, (16, 32, 3)))
+    iso_img = d.mat(ffi.VK_MAT_ISOTROPIC, tex)
+    iso = d.mat(ffi.VK_MAT_ISOTROPIC, d.solid(0.9, 0.9, 0.9))
+    glass = d.mat(ffi.VK_MAT_DIELECTRIC, 0, 1.5)
+    b1 = d.sphere((3, 3, 5), 2.0, glass)
+    refs.append(d.medium(b1, 0.6, iso_img))                      # image-textured phase function: needs rec1.u/v
+    bx = d.boxy((6, 0, 2), (9, 4, 6), d.lambertian(1, 1, 1))
+    refs.append(d.medium(bx, 0.4, iso))                          # Boxy boundary
+    refs.append(d.translate(d.medium(d.sphere((0, 0, 0), 1.0, glass), 1.5, iso), (5, 7, 7)))   # medium under a transform
+    chk = d.checker(d.solid(0.1, 0.1, 0.1), tex)
+    refs.append(d.sphere((5, 1.0, 2), 1.0, d.mat(ffi.VK_MAT_LAMBERTIAN, chk)))
+    refs.append(d.moving_sphere((1, 6, 8), (2, 6, 8), 0.0, 1.0, 0.8, d.lambertian(0.7, 0.3, 0.1)))
+    # a single-object BVH node holding a medium: tested (and drawn) twice (accel.rs:102-107)
+    single = d.medium(d.sphere((8, 8, 8), 1.0, glass), 2.0, iso)
+    refs.append(d.big_box(single, single))
+    world = _bvh_chain(d, refs)
+    desc = d.finish(world, lights)
+    cam = camera((5, 5, -12), (5, 5, 0), vfov=40.0)
+    return d, desc, cam, params(48, 48, 8)
+
+
+def scatter_sky():
+    """IOW-style: scatter integrator + sky, metal/dielectric/negative radius, defocus blur"""
+    d = Desc()
+    refs = [d.sphere((0, -100.5, -1), 100.0, d.lambertian(0.8, 0.8, 0.0)),
+            d.sphere((0, 0, -1), 0.5, d.lambertian(0.1, 0.2, 0.5)),
+            d.sphere((1, 0, -1), 0.5, d.mat(ffi.VK_MAT_METAL, d.solid(0.8, 0.6, 0.2), 0.3)),
+            d.sphere((-1, 0, -1), 0.5, d.mat(ffi.VK_MAT_DIELECTRIC, 0, 1.5)),
+            d.sphere((-1, 0, -1), -0.45, d.mat(ffi.VK_MAT_DIELECTRIC, 0, 1.5)),
+            d.sphere((0, 1.2, -1), 0.3, d.light(4, 4, 4))]
+    world = _bvh_chain(d, refs)
+    desc = d.finish(world, [])
+    cam = camera((3, 3, 2), (0, 0, -1), vfov=20.0, aspect=1.5, aperture=0.5, focus=5.2)
+    return d, desc, cam, params(48, 32, 8, integrator=ffi.VK_INTEGRATOR_SCATTER, background=ffi.VK_BACKGROUND_SKY)
+
+
+ALL = {"nested_transforms": nested_transforms, "lights_and_specdiffuse": lights_and_specdiffuse,
+       "media_and_textures": media_and_textures, "scatter_sky": scatter_sky}

@@ -1,0 +1,78 @@
+"""The C-ABI library: loads, exports every symbol include/vecchio_amd.h declares, agrees with the
+ctypes mirror on struct layout, and FAILS LOUDLY without a GPU (there is no CPU path).
+No compute calls here — those are the -m gpu tests."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+from vecchio_amd import ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "vecchio_amd.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vk_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_exports_every_declared_symbol(built):
+    names = declared_functions()
+    assert {"vk_scene_create", "vk_render", "vk_render_device", "vk_scene_destroy", "vk_last_error", "vk_abi_version",
+            "vk_device_count", "vk_to_color_device"} <= set(names)
+    lib = C.CDLL(ffi.device_lib_path())
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in include/vecchio_amd.h but not exported: {missing}"
+    assert set(ffi.DEVICE_SYMBOLS) <= set(names)
+
+
+def test_abi_version_and_error_string(built):
+    lib = ffi.load_device_lib()
+    assert lib.vk_abi_version() == ffi.VK_ABI_VERSION
+    assert isinstance(lib.vk_last_error(), bytes)
+
+
+def test_struct_layout_matches_header(built, tmp_path):
+    names = {"vk_bvh_node": ffi.BvhNode, "vk_sphere": ffi.Sphere, "vk_moving_sphere": ffi.MovingSphere, "vk_rect": ffi.Rect,
+             "vk_list": ffi.List, "vk_medium": ffi.Medium, "vk_translate": ffi.Translate, "vk_rotate": ffi.Rotate,
+             "vk_material": ffi.Material, "vk_texture": ffi.Texture, "vk_image": ffi.Image, "vk_perlin": ffi.Perlin,
+             "vk_scene_desc": ffi.SceneDesc, "vk_camera": ffi.Camera, "vk_render_params": ffi.RenderParams,
+             "vk_stats": ffi.Stats, "vk_scene_info": ffi.SceneInfo}
+    src = tmp_path / "sz.c"
+    body = "\n".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names)
+    src.write_text(f'#include <stdio.h>\n#include "{HEADER}"\nint main(){{ {body} return 0; }}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-o", str(exe), str(src)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    sizes = dict(zip(out[0::2], map(int, out[1::2])))
+    for n, T in names.items():
+        assert C.sizeof(T) == sizes[n], f"{n}: ctypes {C.sizeof(T)} vs C {sizes[n]}"
+    assert sizes["vk_bvh_node"] == 32      # the canonical 32-byte node record
+
+
+def test_no_cpu_fallback(built):
+    """Without a usable gfx950 device scene creation must fail with an error, never render."""
+    lib = ffi.load_device_lib()
+    if lib.vk_device_count() > 0:
+        return   # on the GPU box the -m gpu tests cover the real path
+    from vecchio_amd import HostScene
+    hs = HostScene("cornell_box", 1)
+    h = C.c_void_p()
+    st = lib.vk_scene_create(hs.desc, 0, C.byref(h))
+    assert st in (ffi.VK_ERR_NO_DEVICE, ffi.VK_ERR_HIP) and not h.value
+    assert len(lib.vk_last_error()) > 0
+
+
+def test_product_does_not_reference_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/ (or tests/emu)."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "vecchio_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".rs")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r'#include\s*"[^"\n]*(oracle|emu)|import\s+(oracle|emu)|liboracle|libemu|dlopen', txt):
+                    if f != "build.py":       # build.py only COMPILES the checker (allowed: build() builds it)
+                        bad.append(os.path.join(base, f))
+    assert not bad, bad

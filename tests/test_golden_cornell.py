@@ -1,0 +1,37 @@
+"""Pins the oracle to the reference's only known-answer artefact: sample/therestofyourlife.png,
+the HEAD cornell_box() (scene.rs:630-730) rendered by HEAD main.rs (900x900, 1000 spp assumed,
+depth 100).  tests/golden/cornell_blocks.json holds its 6x6 block means in linear RGB (made by
+tests/golden/make_cornell_blocks.py from the reference's PNG).  The comparison is statistical —
+the reference is unseeded — so tolerances cover Monte-Carlo noise of both images."""
+import json
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cornell_blocks.json")
+
+
+def quantise_like_png(img):
+    """Vec3::to_color (vec3.rs:54-61) then back to linear, as the fixture was made"""
+    q = np.floor(256.0 * np.clip(np.sqrt(np.clip(img, 0, None)), 0, 0.999))
+    return ((q + 0.5) / 256.0) ** 2
+
+
+def test_oracle_matches_reference_cornell_image(oracle, host_scenes):
+    g = json.load(open(GOLD))
+    hs, cam = host_scenes("cornell_box")
+    p = hs.params(300, 96, 100)        # HEAD: MAX_DEPTH 100 (main.rs:29)
+    img, cnt = oracle.render(hs.desc, cam, p)
+    lin = quantise_like_png(img)[::-1]  # PNG rows are top-down (main.rs:209)
+    nb = g["blocks"]
+    b = 300 // nb
+    mine = np.array([[lin[r * b:(r + 1) * b, c * b:(c + 1) * b].reshape(-1, 3).mean(0) for c in range(nb)] for r in range(nb)])
+    ref = np.array(g["block_mean_linear_rgb"])
+    mean_rel = np.abs(lin.reshape(-1, 3).mean(0) - np.array(g["mean_linear_rgb"])) / np.array(g["mean_linear_rgb"])
+    assert mean_rel.max() < 0.02, f"whole-image mean differs by {mean_rel}"
+    rel = np.abs(mine - ref) / (ref + 0.01)
+    assert rel.max() < 0.10, f"block means differ by up to {rel.max():.3f}"
+    assert np.median(rel) < 0.02
+    # the 21-px black border of the 900-px reference (vfov 40 from z=-800 sees past the box): background is 0
+    assert lin[:5].max() < 1e-4 and lin[:, :5].max() < 1e-4
+    assert cnt.n_dropped < cnt.samples * 1e-3

@@ -1,0 +1,199 @@
+"""-m gpu: the HIP megakernel, called through the C ABI, against the oracle.
+
+Exact tier: same seed => every sample takes the same path (equal draw counts),
+per-pixel |dRGB| < 1e-4 (north_star's stated f32 tolerance; observed ~1e-6).  Plus bit-exact
+host/device arithmetic, tile-partition invariance, determinism, error codes, and properties at
+the BASELINE sizes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import special_scenes
+from vecchio_amd import DeviceScene, HostScene, ffi
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # north_star: per-pixel f32 RGB delta vs the seeded CPU reference
+
+BUILDER_SCENES = ["random_spheres_iow", "cornell_box", "final_scene", "random_spheres_demo", "perlin_demo", "balls_demo"]
+
+
+def device_samples(ds, cam, p):
+    lib = ffi.load_device_lib()
+    lib.vk_debug_render_samples.restype = C.c_int
+    lib.vk_debug_render_samples.argtypes = [C.c_void_p, C.POINTER(ffi.Camera), C.POINTER(ffi.RenderParams), C.c_void_p, C.c_void_p]
+    img = np.zeros((p.height, p.width, 3), np.float32)
+    ps = np.zeros((p.width * p.height * p.samples_per_pixel, 4), np.float32)
+    st = lib.vk_debug_render_samples(ds._h, C.byref(cam), C.byref(p), img.ctypes.data, ps.ctypes.data)
+    assert st == 0, lib.vk_last_error().decode()
+    return img, ps
+
+
+def compare_samples(ps_o, ps_d, img_o, img_d):
+    d_o, d_d = ps_o[:, 3].view(np.uint32), ps_d[:, 3].view(np.uint32)
+    assert np.array_equal(d_o, d_d), f"{int((d_o != d_d).sum())} samples took a different path on the GPU"
+    fo, fd = np.isfinite(ps_o[:, :3]).all(1), np.isfinite(ps_d[:, :3]).all(1)
+    assert np.array_equal(fo, fd)
+    rel = np.abs(ps_o[fo, :3] - ps_d[fo, :3]) / (np.abs(ps_o[fo, :3]) + 1e-3)
+    assert rel.max() < 2e-5
+    assert np.abs(img_o - img_d).max() < TOL
+
+
+def test_device_arithmetic_is_bit_identical_to_host(device, oracle):
+    lib = device
+    lib.vk_debug_math.restype = C.c_int
+    lib.vk_debug_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(11)
+    n = 1 << 18
+    a = np.concatenate([rng.uniform(-1e4, 1e4, n // 2), rng.uniform(-1, 1, n // 2)]).astype(np.float32)
+    b = rng.normal(size=n).astype(np.float32)
+
+    def dev(op, x, y):
+        out = np.empty_like(x)
+        assert lib.vk_debug_math(0, op, x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size) == 0, lib.vk_last_error()
+        return out
+
+    for op in (0, 1, 4, 5):                               # sin, cos, atan2, pow5
+        assert np.array_equal(dev(op, a, b).view(np.uint32), oracle.math(op, a, b).view(np.uint32)), f"op {op}"
+    u = (rng.integers(0, 1 << 24, n).astype(np.float32)) * np.float32(2.0 ** -24)
+    assert np.array_equal(dev(2, u, b).view(np.uint32), oracle.math(2, u, b).view(np.uint32))           # ln of 24-bit draws
+    c = rng.uniform(-1.0000001, 1.0000001, n).astype(np.float32)
+    assert np.array_equal(dev(3, c, b).view(np.uint32), oracle.math(3, c, b).view(np.uint32))           # asin incl. NaN domain
+    # IEEE division / sqrt correctly rounded on the device; a*b+a NOT fused (-ffp-contract=off)
+    assert np.array_equal(dev(6, a, b), (a / b).astype(np.float32))
+    pos = np.abs(a)
+    assert np.array_equal(dev(7, pos, b), np.sqrt(pos))
+    assert np.array_equal(dev(9, a, b), (a * b).astype(np.float32) + a)
+
+
+@pytest.mark.parametrize("name", BUILDER_SCENES)
+def test_builder_scene_per_sample(name, device, oracle, host_scenes):
+    hs, cam = host_scenes(name)
+    p = hs.params(72, 8, 50)
+    ds = DeviceScene(hs.desc)
+    img_d, ps_d = device_samples(ds, cam, p)
+    img_o, ps_o = oracle.render_samples(hs.desc, cam, p)
+    compare_samples(ps_o, ps_d, img_o, img_d)
+    ds.close()
+
+
+@pytest.mark.parametrize("name", sorted(special_scenes.ALL))
+def test_special_scene_per_sample(name, device, oracle):
+    d, desc, cam, p = special_scenes.ALL[name]()
+    ds = DeviceScene(desc)
+    img_d, ps_d = device_samples(ds, cam, p)
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    compare_samples(ps_o, ps_d, img_o, img_d)
+    ds.close()
+
+
+def test_sample_chunking_and_odd_sizes(device, oracle, host_scenes):
+    """spp > 256 splits pixels into sample chunks (partial sums + resolve); odd image sizes give edge tiles"""
+    hs, cam = host_scenes("cornell_box")
+    ds = DeviceScene(hs.desc)
+    p = hs.params(37, 600, 30, height=29)
+    img_d, _ = ds.render(cam, p)
+    img_o, _ = oracle.render(hs.desc, cam, p)
+    assert np.abs(img_o - img_d).max() < TOL
+    ds.close()
+
+
+def test_tile_partition_and_determinism(device, host_scenes):
+    hs, cam = host_scenes("random_spheres_iow")
+    ds = DeviceScene(hs.desc)
+    p = hs.params(200, 300, 50)                           # 2 chunks
+    full, st = ds.render(cam, p)
+    again, _ = ds.render(cam, p)
+    assert np.array_equal(full, again)                    # deterministic run to run
+    for world in (2, 8):
+        acc = np.zeros_like(full)
+        for r in range(world):
+            pr = hs.params(200, 300, 50, tile_rank=r, tile_world=world)
+            ds.render(cam, pr, out=acc)
+        assert np.array_equal(acc, full), f"{world}-way tile partition changed pixel values"
+    ds.close()
+
+
+def test_to_color_matches_reference_quantisation(device, host_scenes):
+    import torch
+    hs, cam = host_scenes("cornell_box")
+    ds = DeviceScene(hs.desc)
+    p = hs.params(64, 16, 20)
+    fb = torch.zeros((p.height, p.width, 3), dtype=torch.float32, device="cuda")
+    ds.render_device(cam, p, fb.data_ptr())
+    rgb8 = torch.zeros((p.height, p.width, 3), dtype=torch.uint8, device="cuda")
+    ds.to_color_device(fb.data_ptr(), p.width, p.height, rgb8.data_ptr())
+    torch.cuda.synchronize()
+    host = fb.cpu().numpy()
+    want = np.zeros((p.height, p.width, 3), np.uint8)
+    ffi.load_host_lib().vkh_to_color(host.ctypes.data, p.width, p.height, want.ctypes.data)
+    assert np.array_equal(rgb8.cpu().numpy(), want)
+    ds.close()
+
+
+def test_error_codes(device, host_scenes):
+    hs, cam = host_scenes("cornell_box")
+    ds = DeviceScene(hs.desc)
+    lib = device
+    out = np.zeros((8, 8, 3), np.float32)
+    st = ffi.Stats()
+
+    def status(p, c=cam):
+        return lib.vk_render(ds._h, C.byref(c), C.byref(p), out.ctypes.data, C.byref(st))
+
+    assert status(hs.params(1, 4, 10, height=8)) == ffi.VK_ERR_BAD_ARG            # width-1 == 0 divisor
+    assert status(hs.params(8, 0, 10, height=8)) == ffi.VK_ERR_BAD_ARG
+    bad = ffi.Camera.from_buffer_copy(cam)
+    bad.time1 = bad.time0
+    assert status(hs.params(8, 4, 10, height=8), bad) == ffi.VK_ERR_BAD_ARG       # gen_range(time0,time1) would panic
+    p = hs.params(8, 4, 10, height=8, tile_rank=3, tile_world=2)
+    assert status(p) == ffi.VK_ERR_BAD_ARG
+    assert lib.vk_render(None, C.byref(cam), C.byref(hs.params(8, 4, 10, height=8)), out.ctypes.data, None) == ffi.VK_ERR_BAD_ARG
+    assert b"" != lib.vk_last_error()
+    h = C.c_void_p()
+    assert lib.vk_scene_create(hs.desc, 99, C.byref(h)) == ffi.VK_ERR_BAD_ARG
+    ds.close()
+
+
+def test_full_size_properties_c2(device, oracle, host_scenes):
+    """BASELINE C2 geometry at full 1920x1080 (spp reduced to keep the suite short): finite,
+    non-negative, deterministic under an 8-way tile split, and the image mean agrees with an
+    oracle estimate of the same integral."""
+    hs, cam = host_scenes("random_spheres_iow")
+    ds = DeviceScene(hs.desc)
+    p = hs.params(1920, 32, 50)
+    assert p.height == 1080
+    img, st = ds.render(cam, p)
+    assert st.scene_in_lds == 1 and st.samples == 1920 * 1080 * 32
+    assert np.isfinite(img).all() and img.min() >= 0.0
+    acc = np.zeros_like(img)
+    for r in range(8):
+        ds.render(cam, hs.params(1920, 32, 50, tile_rank=r, tile_world=8), out=acc)
+    assert np.array_equal(acc, img)
+    po = hs.params(240, 32, 50)                          # same camera, coarser pixel grid, independent samples
+    io, _ = oracle.render(hs.desc, cam, po)
+    assert np.abs(img.mean(axis=(0, 1)) - io.mean(axis=(0, 1))).max() < 0.01
+    ds.close()
+
+
+def test_full_size_properties_c4_c3(device, oracle, host_scenes):
+    """C4 (Cornell 1024x1024) and C3 (final scene 800x800) at full resolution, reduced spp: a band of
+    rows compared pixel-exactly with the oracle, whole image finite."""
+    for name, w in (("cornell_box", 1024), ("final_scene", 800)):
+        hs, cam = host_scenes(name)
+        ds = DeviceScene(hs.desc)
+        p = hs.params(w, 4, 50)
+        img, _ = ds.render(cam, p)
+        assert np.isfinite(img).all() and img.min() >= 0.0
+        # oracle on tiles of one 8-row band only (tile partition = every (w/8)-th... use rank/world to pick a sparse subset)
+        world = 61
+        po = hs.params(w, 4, 50, tile_rank=7, tile_world=world)
+        ref = np.full_like(img, -1.0)
+        lib = oracle.load()
+        stt = lib.oracle_render(hs.desc, C.byref(cam), C.byref(po), ref.ctypes.data, 16, None)
+        assert stt == 0
+        mask = ref[..., 0] >= 0
+        assert mask.sum() > 1000
+        assert np.abs(img[mask] - ref[mask]).max() < TOL
+        ds.close()

@@ -1,0 +1,80 @@
+"""Shared host/device arithmetic (vecchio_amd/csrc/vk_math.h) checked against libm/numpy, and the
+rand-0.7.3 draw mappings it restates.  CPU only."""
+import numpy as np
+
+
+def ulp_diff(a, b):
+    ia = a.view(np.int32).astype(np.int64)
+    ib = b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)
+
+
+def check(got, want_f64, max_ulp=1, max_mismatch_frac=2e-6):
+    want = want_f64.astype(np.float32)
+    ok = np.isfinite(want)
+    d = ulp_diff(got[ok], want[ok])
+    assert d.max() <= max_ulp, f"max ulp {d.max()}"
+    assert (d != 0).mean() <= max_mismatch_frac, f"mismatch fraction {(d != 0).mean()}"
+
+
+def test_sin_cos(oracle):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-1e4, 1e4, 400000), rng.uniform(0, 2 * np.pi, 400000), np.linspace(-10, 10, 100001)]).astype(np.float32)
+    check(oracle.math(0, x), np.sin(x.astype(np.float64)))
+    check(oracle.math(1, x), np.cos(x.astype(np.float64)))
+    assert np.isnan(oracle.math(0, np.array([np.inf, np.nan], np.float32))).all()
+
+
+def test_log(oracle):
+    rng = np.random.default_rng(2)
+    u = (rng.integers(1, 1 << 24, 500000).astype(np.float32)) * np.float32(2.0 ** -24)   # the 24-bit draws of hittable.rs:473
+    x = np.concatenate([u, rng.uniform(1e-30, 1e30, 200000).astype(np.float32)])
+    check(oracle.math(2, x), np.log(x.astype(np.float64)))
+    r = oracle.math(2, np.array([0.0, -1.0, np.inf], np.float32))
+    assert r[0] == -np.inf and np.isnan(r[1]) and r[2] == np.inf
+
+
+def test_asin_atan2(oracle):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-1, 1, 400000), [-1.0, 1.0, 0.0], 1 - np.logspace(-8, -1, 1000)]).astype(np.float32)
+    check(oracle.math(3, x), np.arcsin(x.astype(np.float64)), max_ulp=1, max_mismatch_frac=1e-4)
+    assert np.isnan(oracle.math(3, np.array([1.0000001, -1.5], np.float32))).all()       # hittable.rs:57 on |p.y| > 1
+    y = rng.normal(size=400000).astype(np.float32)
+    xx = rng.normal(size=400000).astype(np.float32)
+    check(oracle.math(4, y, xx), np.arctan2(y.astype(np.float64), xx.astype(np.float64)))
+    sp = oracle.math(4, np.array([0.0, 0.0, 1.0, -1.0], np.float32), np.array([1.0, -1.0, 0.0, 0.0], np.float32))
+    assert np.allclose(sp, [0.0, np.pi, np.pi / 2, -np.pi / 2])
+
+
+def test_pow5(oracle):
+    x = np.random.default_rng(4).uniform(0, 1, 200000).astype(np.float32)
+    check(oracle.math(5, x), x.astype(np.float64) ** 5)      # powf(5.0) of util.rs:28
+
+
+def test_gen_f32_mapping(oracle):
+    v = oracle.draws(7, 3, 5, 0, 200000)
+    assert v.min() >= 0.0 and v.max() < 1.0
+    assert np.all(v * 2 ** 24 == np.floor(v * 2 ** 24))          # 24-bit grid (rand 0.7.3 Standard)
+    assert abs(v.mean() - 0.5) < 0.005 and abs(v.var() - 1 / 12) < 0.003
+    assert np.array_equal(v, oracle.draws(7, 3, 5, 0, 200000))   # deterministic
+    assert not np.array_equal(v[:100], oracle.draws(7, 3, 6, 0, 100))
+    assert not np.array_equal(v[:100], oracle.draws(8, 3, 5, 0, 100))
+
+
+def test_gen_range_mapping(oracle):
+    v = oracle.draws(1, 0, 0, 1, 200000, lo=-1.0, hi=1.0)
+    assert v.min() >= -1.0 and v.max() < 1.0 and abs(v.mean()) < 0.01
+    v = oracle.draws(1, 0, 0, 1, 100000, lo=0.0, hi=float(np.float32(2 * np.pi)))
+    assert v.min() >= 0.0 and v.max() < np.float32(2 * np.pi)
+    v = oracle.draws(1, 0, 0, 1, 100000, lo=213.0, hi=343.0)     # Rect::random of the Cornell light (scene.rs:690-692)
+    assert v.min() >= 213.0 and v.max() < 343.0 and abs(v.mean() - 278.0) < 1.0
+
+
+def test_gen_index_mapping(oracle):
+    for n in (1, 2, 3, 6, 7):
+        v = oracle.draws(9, 1, 2, 2, 60000, n_index=n)
+        assert v.min() >= 0 and v.max() <= n - 1
+        counts = np.bincount(v.astype(np.int64), minlength=n) / len(v)
+        assert np.abs(counts - 1.0 / n).max() < 0.01

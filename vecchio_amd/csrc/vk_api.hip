@@ -357,15 +357,13 @@ int check_render_args(vk_scene *scene, const vk_camera *cam, const vk_render_par
 // number of sample chunks per tile: a function of the image and spp ONLY (never of the tile
 // partition), so 1-GPU and N-GPU renders sum every pixel in the same order
 uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
-    uint32_t tiles = ((p->width + TILE - 1) / TILE) * ((p->height + TILE - 1) / TILE);
-    uint32_t want_units = 256u * 16u * 4u;   // MI355X: 256 CUs x 16 waves, x4 for balance
     (void)s;
-    uint32_t n = (want_units + tiles - 1) / tiles;
-    uint32_t max_by_spp = p->samples_per_pixel / 8u;
-    if (max_by_spp < 1) max_by_spp = 1;
-    if (n > max_by_spp) n = max_by_spp;
+    // 256 samples per pixel per unit: 16K lane-paths per wave-unit keeps the end-of-unit tail
+    // (lanes idling while the last long paths finish) near 2 %, and C2 still splits into
+    // 130K units (16K per GPU at 8 GPUs, ~4 per resident wave) for load balance.
+    const uint32_t CHUNK_SPP = 256;
+    uint32_t n = (p->samples_per_pixel + CHUNK_SPP - 1) / CHUNK_SPP;
     if (n < 1) n = 1;
-    if (n > 4096) n = 4096;
     return n;
 }
 

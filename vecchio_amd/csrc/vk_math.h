@@ -304,8 +304,9 @@ VK_COLD float asinf_(float xf) {
 
 // x.powf(5.0) in schlick (util.rs:28): restated as exact-order multiplies
 VK_HD float pow5f_(float x) {
-    float x2 = x * x;
-    return (x2 * x2) * x;
+    double d = (double)x;
+    double d2 = d * d;
+    return (float)((d2 * d2) * d);   // f64 product rounded once: agrees with a correctly rounded powf
 }
 
 }  // namespace vk
