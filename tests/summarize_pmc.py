@@ -1,0 +1,38 @@
+"""Condenses the rocprofv3 PMC passes of tests/prof_*.sh into one JSON under profiles/."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+src, dst, samples = sys.argv[1], sys.argv[2], float(sys.argv[3])
+out = {"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu (separate passes; see tests/prof_r01.sh)",
+       "samples_per_dispatch": samples, "counters_per_dispatch": {}}
+for f in sorted(glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv")):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "render_kernel" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            out["dispatch"] = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+    for k, v in agg.items():
+        out["counters_per_dispatch"][k] = sum(v) / len(v)
+c = out["counters_per_dispatch"]
+d = {}
+if "FETCH_SIZE" in c:
+    d["hbm_read_bytes_per_dispatch"] = {"FETCH_SIZE_KB_x1024": c["FETCH_SIZE"] * 1024, "with_gfx950_x2_correction_upper_bound": 2 * c["FETCH_SIZE"] * 1024}
+if "WRITE_SIZE" in c:
+    d["hbm_write_bytes_per_dispatch"] = c["WRITE_SIZE"] * 1024
+if "SQ_THREAD_CYCLES_VALU" in c:
+    d["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64)
+if "SQ_WAVE_CYCLES" in c and "SQ_WAIT_ANY" in c:
+    w = c["SQ_WAVE_CYCLES"]
+    d["wave_time_split"] = {"issuing": c["SQ_ACTIVE_INST_ANY"] / w, "waiting(s_waitcnt)": c["SQ_WAIT_ANY"] / w, "issue_stall": c["SQ_WAIT_INST_ANY"] / w}
+if "SQ_LDS_BANK_CONFLICT" in c:
+    d["lds_bank_conflict_fraction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_FLAT"):
+    if k in c:
+        d[k + "_per_sample"] = c[k] / samples
+out["derived"] = d
+json.dump(out, open(dst, "w"), indent=1)
+print(json.dumps(d, indent=1))
+print(out.get("dispatch"))
