@@ -43,7 +43,7 @@ int fail(int code, const std::string &m) { g_err = m; return code; }
         if (_e != hipSuccess) return fail(VK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
-constexpr int WG_THREADS = 256;
+constexpr int WG_THREADS = 512;
 constexpr int WAVES_PER_WG = WG_THREADS / 64;
 constexpr int TILE = 8;   // 8x8 pixels = one wave
 
@@ -110,6 +110,49 @@ __device__ __forceinline__ typename std::conditional<LDS_SCENE, LdsMem, GlobalMe
     return M;
 }
 
+// Cold per-lane path state (throughput, radiance, RNG, pixel/sample ids, world ray) lives in
+// LDS between SHADE phases, SoA by field (word f of lane l at cold[f*64 + l]: conflict-free),
+// so that the box/primitive loops keep only the traversal state in VGPRs.
+constexpr int NCOLD_BASE = 13;      // thr3 acc3 depth key2 ctr pixel sample q
+constexpr int NCOLD_INST = 19;      // + world-space ray (o3 d3) for scenes with instances
+template <uint32_t F> constexpr int ncold() { return (F & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE; }
+
+template <uint32_t F>
+__device__ __forceinline__ void cold_store(float *c, uint32_t lane, const Lane &L, uint32_t q) {
+    c[0 * 64 + lane] = L.thr.x; c[1 * 64 + lane] = L.thr.y; c[2 * 64 + lane] = L.thr.z;
+    c[3 * 64 + lane] = L.acc.x; c[4 * 64 + lane] = L.acc.y; c[5 * 64 + lane] = L.acc.z;
+    c[6 * 64 + lane] = __uint_as_float(L.depth);
+    c[7 * 64 + lane] = __uint_as_float((uint32_t)L.rng.key); c[8 * 64 + lane] = __uint_as_float((uint32_t)(L.rng.key >> 32));
+    c[9 * 64 + lane] = __uint_as_float(L.rng.ctr);
+    c[10 * 64 + lane] = __uint_as_float(L.pixel); c[11 * 64 + lane] = __uint_as_float(L.sample); c[12 * 64 + lane] = __uint_as_float(q);
+    if (F & VKF_INSTANCE) {
+        c[13 * 64 + lane] = L.wo.x; c[14 * 64 + lane] = L.wo.y; c[15 * 64 + lane] = L.wo.z;
+        c[16 * 64 + lane] = L.wd.x; c[17 * 64 + lane] = L.wd.y; c[18 * 64 + lane] = L.wd.z;
+    }
+}
+template <uint32_t F>
+__device__ __forceinline__ void cold_load(const float *c, uint32_t lane, Lane &L, uint32_t &q) {
+    L.thr = v3(c[0 * 64 + lane], c[1 * 64 + lane], c[2 * 64 + lane]);
+    L.acc = v3(c[3 * 64 + lane], c[4 * 64 + lane], c[5 * 64 + lane]);
+    L.depth = __float_as_uint(c[6 * 64 + lane]);
+    L.rng.key = (uint64_t)__float_as_uint(c[7 * 64 + lane]) | ((uint64_t)__float_as_uint(c[8 * 64 + lane]) << 32);
+    L.rng.ctr = __float_as_uint(c[9 * 64 + lane]);
+    L.pixel = __float_as_uint(c[10 * 64 + lane]); L.sample = __float_as_uint(c[11 * 64 + lane]); q = __float_as_uint(c[12 * 64 + lane]);
+    if (F & VKF_INSTANCE) {
+        L.wo = v3(c[13 * 64 + lane], c[14 * 64 + lane], c[15 * 64 + lane]);
+        L.wd = v3(c[16 * 64 + lane], c[17 * 64 + lane], c[18 * 64 + lane]);
+    } else {
+        L.wo = L.o; L.wd = L.d;       // no instances: the current space IS world space
+    }
+}
+template <uint32_t F>
+__device__ __forceinline__ void cold_load_world_ray(const float *c, uint32_t lane, Lane &L) {
+    if (F & VKF_INSTANCE) {
+        L.wo = v3(c[13 * 64 + lane], c[14 * 64 + lane], c[15 * 64 + lane]);
+        L.wd = v3(c[16 * 64 + lane], c[17 * 64 + lane], c[18 * 64 + lane]);
+    }
+}
+
 template <uint32_t F, bool LDS_SCENE, int MINW>
 __global__ __launch_bounds__(WG_THREADS, MINW) void render_kernel(KArgs A_byval) {
     (void)A_byval;
@@ -117,14 +160,16 @@ __global__ __launch_bounds__(WG_THREADS, MINW) void render_kernel(KArgs A_byval)
     const uint32_t wave = threadIdx.x >> 6;
     using Mem = typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type;
 
-    // ---- LDS layout: [items][spheres][per-wave accumulators]
+    // ---- LDS layout: [items][spheres][per-wave pixel accumulators][per-wave cold lane state]
     uint32_t lds_items = 0;
-    float *acc_lds;
+    float *acc_lds, *cold;
     {
         KArgsC P = kargs_fresh();
         lds_items = LDS_SCENE ? KARG(P, lds_items) : 0u;
         uint32_t lds_spheres = LDS_SCENE ? KARG(P, lds_spheres) : 0u;
-        acc_lds = reinterpret_cast<float *>(smem + (2u * lds_items + lds_spheres)) + wave * (64 * 3);
+        float *dyn = reinterpret_cast<float *>(smem + (2u * lds_items + lds_spheres));
+        acc_lds = dyn + wave * (64 * 3);
+        cold = dyn + WAVES_PER_WG * (64 * 3) + wave * (64 * ncold<F>());
         if (LDS_SCENE) {
             const uint4 *gi = reinterpret_cast<const uint4 *>(KARG(P, S.items));
             for (uint32_t k = threadIdx.x; k < 2u * lds_items; k += WG_THREADS) smem[k] = gi[k];
@@ -153,63 +198,102 @@ __global__ __launch_bounds__(WG_THREADS, MINW) void render_kernel(KArgs A_byval)
         acc_lds[lane] = 0.0f; acc_lds[64 + lane] = 0.0f; acc_lds[128 + lane] = 0.0f;
 
         Lane L;
-        uint32_t q = 0;            // tile-local pixel slot of the lane's current sample
+        memset(&L, 0, sizeof(L));
         bool need = true;          // lane wants a new (pixel, sample)
         bool active = false;       // lane holds a live path
         uint32_t next_item = 0;    // wave-uniform
+        // Wave-level phase scheduler.  Every lane is in one of four states; each round the
+        // wave runs the code of the most populated state with the lanes in it (64-bit ballots
+        // + s_bcnt1), so the long box loop, the primitive tests and the (expensive, rare)
+        // shading / ray-generation code each execute with as many lanes as possible instead
+        // of all being paid for on every iteration:
+        //   BOX    pend == 0 and items (or an instance to leave) remain  -> box_step
+        //   PRIM   pend != 0                                             -> prim_step
+        //   SHADE  live path whose segment is fully traversed            -> shade
+        //   NEED   no path; the unit still has (pixel, sample) items     -> start_sample
+        // SHADE and NEED run as one phase: a path that ends hands its lane straight to the
+        // next item (ballot + prefix popcount = active-ray compaction).
         for (;;) {
-            // ---- refill: hand the next items of the unit to the lanes that need one
-            unsigned long long need_mask = __ballot(need);
-            if (need_mask) {
-                KArgsC P = kargs_fresh();
-                uint32_t rank = __popcll(need_mask & ((1ull << lane) - 1ull));
-                if (need) {
-                    uint32_t k = next_item + rank;
-                    active = false;
-                    if (k < total) {
-                        q = k & 63u;
-                        uint32_t s = s0 + (k >> 6);
-                        uint32_t px = tx + (q & 7u), py = ty + (q >> 3);
-                        if (px < KARG(P, C.width) && py < KARG(P, C.height)) {   // slots outside the image (edge tiles) are skipped
-                            RenderConsts C = KARG(P, C);
-                            DScene S = KARG(P, S);
-                            start_sample(L, S, C, px, py, s);
-                            active = true;
-                        }
-                    }
-                    need = !active && k < total;
-                }
-                next_item += (uint32_t)__popcll(need_mask);
-            }
-            if (!__any(active)) { if (next_item >= total) break; else continue; }
-            // ---- traverse: one item per lane per iteration until every live lane's segment is done
-            {
+            bool is_prim = active && has_prim_work(L);
+            bool is_box = active && !is_prim && traversing(L);
+            bool is_shade = active && !is_prim && !is_box;
+            uint32_t n_box = (uint32_t)__popcll(__ballot(is_box)), n_prim = (uint32_t)__popcll(__ballot(is_prim));
+            uint32_t n_sn = (uint32_t)__popcll(__ballot(is_shade || need));
+            if ((n_box | n_prim | n_sn) == 0) break;
+            if (n_box >= n_prim && n_box >= n_sn) {
+                // ---- BOX: predicated steps (full EXEC), two per exit test, while box lanes are the plurality
                 KArgsC P = kargs_fresh();
                 DScene S = KARG(P, S);
                 Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
+                cold_load_world_ray<F>(cold, lane, L);
+                const uint32_t live = n_box + n_prim + n_sn;         // lanes only change state here, none appear or vanish
                 for (;;) {
-                    bool tr = active && traversing(L);
-                    if (!__any(tr)) break;
-                    if (tr) traverse_step<F, Mem>(L, S, M);
+                    box_step<F, Mem>(L, S, M, is_box);
+                    is_box = active && !has_prim_work(L) && traversing(L);
+                    box_step<F, Mem>(L, S, M, is_box);
+                    is_box = active && !has_prim_work(L) && traversing(L);
+                    uint32_t nb = (uint32_t)__popcll(__ballot(is_box));
+                    uint32_t np = (uint32_t)__popcll(__ballot(active && has_prim_work(L)));
+                    uint32_t ns = live - nb - np;
+                    if (nb == 0 || nb < np || nb < ns) break;          // another state now has more lanes parked than are stepping
                 }
-            }
-            // ---- shade the finished segments; ended paths deposit their radiance
-            if (active) {
+            } else if (n_prim >= n_sn) {
+                // ---- PRIM: intersect / enter the pending object
+                KArgsC P = kargs_fresh();
+                DScene S = KARG(P, S);
+                Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
+                if (is_prim) {
+                    if (F & VKF_MEDIUM) {    // ConstantMedium::hit draws inside traversal (hittable.rs:473)
+                        L.rng.key = (uint64_t)__float_as_uint(cold[7 * 64 + lane]) | ((uint64_t)__float_as_uint(cold[8 * 64 + lane]) << 32);
+                        L.rng.ctr = __float_as_uint(cold[9 * 64 + lane]);
+                    }
+                    prim_step<F, Mem>(L, S, M);
+                    if (F & VKF_MEDIUM) cold[9 * 64 + lane] = __uint_as_float(L.rng.ctr);
+                }
+            } else {
+                // ---- SHADE + REFILL
                 KArgsC P = kargs_fresh();
                 RenderConsts C = KARG(P, C);
                 DScene S = KARG(P, S);
                 Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
-                if (!shade<F, Mem>(L, S, M, C)) {
-                    float4 *dbg = KARG(P, debug);
-                    if (dbg) dbg[(size_t)L.pixel * C.spp + L.sample] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(L.rng.ctr));
-                    if (isfinite(L.acc.x) && isfinite(L.acc.y) && isfinite(L.acc.z)) {   // main.rs:192-194
-                        atomicAdd(&acc_lds[q * 3 + 0], L.acc.x);
-                        atomicAdd(&acc_lds[q * 3 + 1], L.acc.y);
-                        atomicAdd(&acc_lds[q * 3 + 2], L.acc.z);
+                uint32_t q = 0;
+                bool touched = is_shade;      // lanes whose cold state is in registers during this phase
+                if (is_shade) {
+                    cold_load<F>(cold, lane, L, q);
+                    if (!shade<F, Mem>(L, S, M, C)) {
+                        float4 *dbg = KARG(P, debug);
+                        if (dbg) dbg[(size_t)L.pixel * C.spp + L.sample] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(L.rng.ctr));
+                        if (isfinite(L.acc.x) && isfinite(L.acc.y) && isfinite(L.acc.z)) {   // main.rs:192-194
+                            atomicAdd(&acc_lds[q * 3 + 0], L.acc.x);
+                            atomicAdd(&acc_lds[q * 3 + 1], L.acc.y);
+                            atomicAdd(&acc_lds[q * 3 + 2], L.acc.z);
+                        }
+                        active = false;
+                        need = true;
                     }
-                    active = false;
-                    need = true;
                 }
+                unsigned long long need_mask = __ballot(need);
+                if (need_mask) {
+                    uint32_t rank = __popcll(need_mask & ((1ull << lane) - 1ull));
+                    if (need) {
+                        uint32_t k = next_item + rank;
+                        if (k < total) {
+                            q = k & 63u;
+                            uint32_t s = s0 + (k >> 6);
+                            uint32_t px = tx + (q & 7u), py = ty + (q >> 3);
+                            if (px < C.width && py < C.height) {   // slots outside the image (edge tiles) are skipped
+                                start_sample(L, S, C, px, py, s);
+                                active = true;
+                                need = false;
+                                touched = true;
+                            }
+                        } else {
+                            need = false;                           // unit exhausted: this lane idles until the wave drains
+                        }
+                    }
+                    next_item += (uint32_t)__popcll(need_mask);
+                }
+                if (active && touched) cold_store<F>(cold, lane, L, q);
             }
         }
         // ---- write the unit's pixel sums
@@ -326,11 +410,12 @@ uint32_t pick_variant(uint32_t features) {
 
 template <uint32_t F>
 int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st) {
-    constexpr int MINW = 4;   // waves per SIMD the register allocation is held to (128 VGPRs)
+    constexpr int MINW = 4;   // 512-thread workgroups, 2 per CU = 4 waves per SIMD (<= 128 VGPRs)
     if (lds) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<F, true, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL((render_kernel<F, true, MINW>), grid, dim3(WG_THREADS), shmem, st, A);
     } else {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<F, false, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL((render_kernel<F, false, MINW>), grid, dim3(WG_THREADS), shmem, st, A);
     }
     HIP_TRY(hipGetLastError());
@@ -410,11 +495,12 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
     }
     // LDS residency of the hot records
     bool lds = s->lds_bytes != 0;
-    size_t shmem = (size_t)WAVES_PER_WG * 64 * 3 * sizeof(float);
+    uint32_t Fsel = pick_variant(s->host.features);
+    size_t shmem = (size_t)WAVES_PER_WG * 64 * (3 + ((Fsel & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE)) * sizeof(float);
     if (lds) { A.lds_items = s->dev.n_items; A.lds_spheres = s->dev.n_spheres; shmem += s->lds_bytes; }
     // persistent grid: enough workgroups to fill the chip, never more than there are units
     uint32_t n_units = A.n_local_tiles * A.n_chunks;
-    uint32_t wgs_per_cu = lds ? (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / std::max<size_t>(shmem, 1))) : 4u;
+    uint32_t wgs_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / WG_THREADS, (160 * 1024) / std::max<size_t>(shmem, 1)));
     uint32_t grid = (uint32_t)s->num_cus * wgs_per_cu;
     uint32_t need_wgs = (n_units + WAVES_PER_WG - 1) / WAVES_PER_WG;
     if (grid > need_wgs) grid = need_wgs;
@@ -511,8 +597,8 @@ int vk_scene_create(const vk_scene_desc *desc, int device, vk_scene **out) {
     if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { vk_scene_destroy(s); return fail(VK_ERR_HIP, "hipEventCreate failed"); }
     // LDS residency: items + spheres + accumulators must leave room for >= 2 workgroups per CU
     size_t hot = H.items.size() * sizeof(DItem) + H.spheres.size() * sizeof(DSphere);
-    size_t accb = (size_t)WAVES_PER_WG * 64 * 3 * sizeof(float);
-    s->lds_bytes = (hot + accb <= 72 * 1024) ? (uint32_t)hot : 0u;
+    size_t accb = (size_t)WAVES_PER_WG * 64 * (3 + NCOLD_INST) * sizeof(float);
+    s->lds_bytes = (hot + accb <= 80 * 1024) ? (uint32_t)hot : 0u;   // two 512-thread workgroups per CU must fit in 160 KB
     *out = s;
     return VK_OK;
 }

@@ -68,7 +68,7 @@ struct Lane {
     V3 inv; float a; uint32_t exact_only;
     V3 wo, wd;                 // world-space ray of this segment
     // traversal cursor
-    uint32_t i, end, pend; int32_t cur_inst;
+    uint32_t i, end, pend, pend2; int32_t cur_inst;
     // closest hit so far (deferred record)
     float T; uint32_t best_prim; int32_t best_inst; float best_aux;
     // path
@@ -240,7 +240,7 @@ VK_HD bool slab(const DItem &n, const Lane &L, float tmax) {
 VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time) {
     L.wo = o; L.wd = d; L.time = time;
     set_space(L, o, d);
-    L.i = 0; L.end = S.n_world_items; L.pend = 0; L.cur_inst = -1;
+    L.i = 0; L.end = S.n_world_items; L.pend = 0; L.pend2 = 0; L.cur_inst = -1;
     L.T = INFINITY; L.best_prim = 0; L.best_inst = -1; L.best_aux = 0.0f;
 }
 
@@ -279,6 +279,7 @@ VK_HD void enter_instance(Lane &L, const DScene &S, uint32_t ref) {
     for (uint32_t k = 0; k < I.n_ops; k++) apply_op(I.ops[k], o, d);
     set_space(L, o, d);
     L.cur_inst = idx;
+    L.pend2 = 0;   // the home leaf's right object is restored from home_pend on leave
     if (I.child_end > I.child_begin) { L.i = I.child_begin; L.end = I.child_end; L.pend = 0; }
     else { L.i = 0; L.end = 0; L.pend = I.child_ref; }
 }
@@ -286,7 +287,7 @@ template <uint32_t F, class Mem>
 VK_HD void leave_instance(Lane &L, const DScene &S) {
     const DInstance &I = S.instances[L.cur_inst];
     int32_t P = I.parent;
-    L.i = I.home_next; L.pend = I.home_pend;
+    L.i = I.home_next; L.pend = I.home_pend; L.pend2 = 0;
     L.end = P < 0 ? S.n_world_items : S.instances[P].child_end;
     L.cur_inst = P;
     V3 o, d;
@@ -319,31 +320,68 @@ VK_HD void process_ref(Lane &L, const DScene &S, const Mem &M, uint32_t ref) {
     if ((F & VKF_INSTANCE) && k == DK_INSTANCE) { enter_instance<F, Mem>(L, S, ref); return; }
 }
 
+// The threaded pre-order walk is split into two kinds of step so that a wave can run each
+// kind with the lanes that need it (vk_api.hip schedules them by ballot):
+//   box_step   one 32-byte item: box test, then advance / take the skip link; a leaf whose
+//              box is hit queues its objects in pend (left) and pend2 (right)
+//   prim_step  the object in pend: intersect it (or enter it, if it is an instance); the
+//              right object runs after the left one and sees the tmax it left behind
+//              (accel.rs:64-70)
+// A lane has box work when pend == 0 and prim work when pend != 0; objects are always
+// finished before the next item is fetched, which is the reference's order.
 VK_HD bool traversing(const Lane &L) { return L.i < L.end || L.pend != 0 || L.cur_inst >= 0; }
+VK_HD bool has_prim_work(const Lane &L) { return L.pend != 0; }
 
-// One step of the threaded pre-order walk; call while traversing(L).  A step is either one
-// 32-byte item (box test; for a leaf also its first object) or one pending object (a leaf's
-// second child, which must see the tmax its sibling left behind: accel.rs:64-70).
+// `on` = this lane has box work.  Written with selects instead of branches: on gfx950 the one
+// scalar unit per CU is what a divergent traversal loop saturates first (every divergent `if`
+// costs s_and_saveexec / s_cbranch / s_or), so the whole wave runs the step with full EXEC and
+// lanes that are not `on` (or are past their range) redo item 0 and discard the result.
+template <uint32_t F, class Mem>
+VK_HD void box_step(Lane &L, const DScene &S, const Mem &M, bool on) {
+    bool at_end = L.i >= L.end;
+    if (F & VKF_INSTANCE) {
+        if (on && at_end) { if (L.cur_inst >= 0) leave_instance<F, Mem>(L, S); return; }   // rare
+    }
+    bool go = on && !at_end;
+    DItem n = M.item(go ? L.i : 0u);
+    uint32_t k0 = n.w0 >> 28;
+    bool inner = (k0 == 0);
+    bool prim_item = (k0 == DK_PRIM_ITEM);               // object child beside a BVH child: no box of its own
+    // AxisBB::hit decided from reciprocal multiplies (see slab()); same boolean as the reference's
+    float x0 = (n.bmin[0] - L.o.x) * L.inv.x, x1 = (n.bmax0 - L.o.x) * L.inv.x;
+    float y0 = (n.bmin[1] - L.o.y) * L.inv.y, y1 = (n.bmax1 - L.o.y) * L.inv.y;
+    float z0 = (n.bmin[2] - L.o.z) * L.inv.z, z1 = (n.bmax2 - L.o.z) * L.inv.z;
+    float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));
+    float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), L.T));
+    const float EP = 1.000002f;
+    bool hit_safe = hi > lo * EP;
+    bool miss_safe = hi * EP < lo;
+    bool h = hit_safe;
+    if (go && !prim_item && (L.exact_only != 0u || !(hit_safe || miss_safe)))
+        h = slab_exact(n, L.o, L.d, T_MIN, L.T);         // within rounding distance / NaN / inf: the reference's divisions
+    h = h || prim_item;
+    uint32_t next_i = inner ? (h ? L.i + 1u : n.w0) : L.i + 1u;   // inner: hit -> left subtree, miss -> skip link
+    bool leaf_hit = h && !inner;
+    uint32_t p1 = leaf_hit ? (prim_item ? n.w1 : n.w0) : 0u;     // leaf: left object first ...
+    uint32_t p2 = (leaf_hit && !prim_item) ? n.w1 : 0u;          // ... then the right one
+    L.i = go ? next_i : L.i;
+    L.pend = go ? p1 : L.pend;
+    L.pend2 = go ? p2 : L.pend2;
+}
+
+template <uint32_t F, class Mem>
+VK_HD void prim_step(Lane &L, const DScene &S, const Mem &M) {
+    uint32_t ref = L.pend;
+    L.pend = L.pend2;
+    L.pend2 = 0;
+    process_ref<F, Mem>(L, S, M, ref);
+}
+
+// sequential form (CPU emulator): one step of whichever kind is due
 template <uint32_t F, class Mem>
 VK_HD void traverse_step(Lane &L, const DScene &S, const Mem &M) {
-    uint32_t ref = L.pend;
-    L.pend = 0;
-    if (ref == 0) {
-        if (L.i >= L.end) {
-            if (F & VKF_INSTANCE) { if (L.cur_inst >= 0) leave_instance<F, Mem>(L, S); }
-            return;
-        }
-        DItem n = M.item(L.i);
-        uint32_t k0 = n.w0 >> 28;
-        bool prim_item = (k0 == DK_PRIM_ITEM);               // object child beside a BVH child: no box of its own
-        bool h = prim_item ? true : slab(n, L, L.T);
-        if (k0 == 0) { L.i = h ? L.i + 1 : n.w0; return; }   // inner node: hit -> left subtree, miss -> skip link
-        L.i += 1;
-        if (!h) return;
-        ref = prim_item ? n.w1 : n.w0;                        // leaf: left object now, right object next step
-        L.pend = prim_item ? 0u : n.w1;
-    }
-    process_ref<F, Mem>(L, S, M, ref);
+    if (has_prim_work(L)) prim_step<F, Mem>(L, S, M);
+    else box_step<F, Mem>(L, S, M, true);
 }
 
 // ------------------------------------------------------------------ deferred hit record
@@ -465,6 +503,9 @@ VK_HD float perlin_noise(const DPerlin &P, V3 p) {  // material.rs:392-413 + per
 VK_HD float perlin_turb(const DPerlin &P, V3 p, int depth) {  // material.rs:379-390
     float accum = 0.0f, weight = 1.0f;
     V3 tp = p;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
     for (int i = 0; i < depth; i++) {
         accum += weight * perlin_noise(P, tp);
         weight *= 0.5f;
@@ -472,9 +513,14 @@ VK_HD float perlin_turb(const DPerlin &P, V3 p, int depth) {  // material.rs:379
     }
     return fabsf(accum);
 }
-VK_HD V3 texture_value(const DScene &S, uint32_t tex, float u, float v, V3 p) {
+// Non-solid textures (checker / image / Perlin noise).  Out of line on the device: it is
+// reached at most once per bounce, and inlining its 7x8-corner noise and f64 trigonometry
+// into the megakernel is what pushes the whole kernel into spilling.
+VK_COLD V3 texture_value(const DTexture *textures, const DImage *images, const uint8_t *image_bytes, const DPerlin *perlins,
+                         uint32_t tex, float u, float v, float px, float py, float pz) {
+    V3 p = v3(px, py, pz);
     for (int guard = 0; guard < 16; guard++) {
-        const DTexture &t = S.textures[tex];
+        const DTexture &t = textures[tex];
         if (t.kind == VK_TEX_SOLID) return v3(t.r, t.g, t.b);
         if (t.kind == VK_TEX_CHECKER) {  // material.rs:250-258
             float sins = vk::sinf_(10.0f * p.x) * vk::sinf_(10.0f * p.y) * vk::sinf_(10.0f * p.z);
@@ -482,27 +528,28 @@ VK_HD V3 texture_value(const DScene &S, uint32_t tex, float u, float v, V3 p) {
             continue;
         }
         if (t.kind == VK_TEX_IMAGE) {  // material.rs:283-303
-            const DImage &im = S.images[t.a];
+            const DImage &im = images[t.a];
             float uc = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
             float vc0 = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
             float vc = 1.0f - vc0;
             uint32_t i = vk::sat_u32(uc * (float)im.width), j = vk::sat_u32(vc * (float)im.height);
             if (i >= im.width) i = im.width - 1;
             if (j >= im.height) j = im.height - 1;
-            const uint8_t *pix = S.image_bytes + im.offset + ((uint64_t)j * im.width + i) * 3u;
+            const uint8_t *pix = image_bytes + im.offset + ((uint64_t)j * im.width + i) * 3u;
             float cs = 1.0f / 255.0f;
             return v3(cs * (float)pix[0], cs * (float)pix[1], cs * (float)pix[2]);
         }
         // VK_TEX_NOISE, material.rs:430-434: Vec3::new_const(1.0) * 0.5 * (1.0 + sin(..))
-        const DPerlin &P = S.perlins[t.a];
+        const DPerlin &P = perlins[t.a];
         float s = 1.0f + vk::sinf_(t.scale * p.z + 10.0f * perlin_turb(P, p, 7));
         return (v3s(1.0f) * 0.5f) * s;
     }
     return v3s(0.0f);
 }
+template <uint32_t F>
 VK_HD V3 material_color(const DScene &S, const DMaterial &m, const Rec &R) {
-    if (m.tex_kind == VK_TEX_SOLID) return v3(m.r, m.g, m.b);
-    return texture_value(S, m.tex, R.u, R.v, R.p);
+    if (!(F & VKF_TEXTURES) || m.tex_kind == VK_TEX_SOLID) return v3(m.r, m.g, m.b);
+    return texture_value(S.textures, S.images, S.image_bytes, S.perlins, m.tex, R.u, R.v, R.p.x, R.p.y, R.p.z);
 }
 
 // ------------------------------------------------------------------ samplers (util.rs:31-63, material.rs:51-58)
@@ -695,11 +742,11 @@ VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) 
         uint32_t kind = m->kind;
         if (kind == VK_MAT_LAMBERTIAN) {                      // material.rs:85-90
             ndir = R.n + lambertian_random(L.rng);
-            atten = material_color(S, *m, R);
+            atten = material_color<F>(S, *m, R);
         } else if (kind == VK_MAT_METAL) {                    // material.rs:118-132
             V3 reflected = reflect(unit(rd), R.n);
             ndir = reflected + random_in_unit_sphere(L.rng) * m->param;
-            atten = material_color(S, *m, R);
+            atten = material_color<F>(S, *m, R);
             scattered = dot(ndir, R.n) > 0.0f;
         } else if (kind == VK_MAT_DIELECTRIC) {               // material.rs:150-175
             atten = v3s(1.0f);
@@ -715,10 +762,10 @@ VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) 
             }
         } else if (kind == VK_MAT_ISOTROPIC) {                // material.rs:442-446
             ndir = random_in_unit_sphere(L.rng);
-            atten = material_color(S, *m, R);
+            atten = material_color<F>(S, *m, R);
         } else {                                              // DiffuseLight: material.rs:215-225
             scattered = false;
-            if (kind == VK_MAT_DIFFUSE_LIGHT && R.front) emitted = material_color(S, *m, R);
+            if (kind == VK_MAT_DIFFUSE_LIGHT && R.front) emitted = material_color<F>(S, *m, R);
         }
         L.acc = L.acc + L.thr * emitted;
         if (!scattered) return false;
@@ -727,7 +774,7 @@ VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) 
         // HEAD integrator, main.rs:131-149
         V3 emitted = v3s(0.0f);
         if (m->kind == VK_MAT_DIFFUSE_LIGHT) {
-            if (R.front) emitted = material_color(S, *m, R);
+            if (R.front) emitted = material_color<F>(S, *m, R);
             L.acc = L.acc + L.thr * emitted;                  // scatter_with_pdf is None: return emitted
             return false;
         }
@@ -744,7 +791,7 @@ VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) 
             V3 reflected = reflect(unit(rd), R.n);
             ndir = reflected + random_in_unit_sphere(L.rng) * m->param;
             ntime = 0.0f;
-            L.thr = L.thr * material_color(S, *m, R);         // specular: emitted is NOT added (main.rs:134-137)
+            L.thr = L.thr * material_color<F>(S, *m, R);         // specular: emitted is NOT added (main.rs:134-137)
         } else if (kind == VK_MAT_DIELECTRIC) {               // material.rs:177-206
             float eta = R.front ? 1.0f / m->param : m->param;
             V3 ud = unit(rd);
@@ -757,7 +804,7 @@ VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) 
                 else ndir = refract(ud, R.n, eta);
             }
         } else {                                              // Lambertian / Isotropic: material.rs:92-98,448-454
-            V3 atten = material_color(S, *m, R);
+            V3 atten = material_color<F>(S, *m, R);
             Onb uvw = onb_from_w(R.n);                        // CosinePDF::new(rec.normal)
             // MixturePDF::generate, util.rs:177-185
             if (vk::gen_f32(L.rng) < 0.5f) {
