@@ -273,6 +273,10 @@ int vk_scene_last_kernel_ms(vk_scene *scene, double *ms_out);
  * before the finite filter (main.rs:192), [+3] = the sample's u32 draw count (bit pattern) */
 int vk_debug_render_samples(vk_scene *scene, const vk_camera *cam, const vk_render_params *params,
                             float *rgb_out, float *samples_out);
+/* render with the instrumented build of the sphere-only kernel and return the wave scheduler's
+ * counters: [0] box steps (wave level) [1] lanes with box work summed over them [2] PRIM phases
+ * [3] lanes with primitive work in them [4] SHADE+REFILL phases [5] lanes in them [6] rounds  */
+int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, uint64_t out[8]);
 /* evaluate the shared host/device arithmetic ON THE DEVICE (host arrays in/out):
  * op 0 sin, 1 cos, 2 ln, 3 asin, 4 atan2(a,b), 5 pow5, 6 a/b, 7 sqrt(a), 8 draws, 9 a*b+a  */
 int vk_debug_math(int device, int op, const float *a, const float *b, float *out, size_t n);

@@ -75,6 +75,19 @@ def main():
         p = hs.params(w, spp, 50)
         img, st = ds.render(cam, p)
         print(f"timing {w}x{p.height} spp={spp}: kernel {st.kernel_ms:.2f} ms -> {st.samples / st.kernel_ms / 1e3:.1f} Msamples/s (lds={st.scene_in_lds})", flush=True)
+    # phase scheduler statistics (instrumented kernel build)
+    lib = ffi.load_device_lib()
+    lib.vk_debug_phase_stats.restype = C.c_int
+    lib.vk_debug_phase_stats.argtypes = [C.c_void_p, C.POINTER(ffi.Camera), C.POINTER(ffi.RenderParams), C.POINTER(C.c_uint64 * 8)]
+    p = hs.params(1920, 64, 50)
+    out = (C.c_uint64 * 8)()
+    if lib.vk_debug_phase_stats(ds._h, C.byref(cam), C.byref(p), C.byref(out)) == 0:
+        v = list(out)
+        ns = p.width * p.height * p.samples_per_pixel
+        print(f"phase stats per sample: box wave-steps {v[0]/ns:.3f} (lane fill {v[1]/max(1,v[0])/64:.3f}), prim phases {v[2]/ns:.3f} (fill {v[3]/max(1,v[2])/64:.3f}), "
+              f"shade phases {v[4]/ns:.3f} (fill {v[5]/max(1,v[4])/64:.3f}), rounds {v[6]/ns:.3f}; lane box steps/sample {v[1]/ns:.1f} prim {v[3]/ns:.1f} shade+need {v[5]/ns:.1f}", flush=True)
+    else:
+        print("phase stats failed:", lib.vk_last_error().decode())
     print("ALL OK" if ok else "SOME FAILED")
     return 0 if ok else 1
 

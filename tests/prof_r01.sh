@@ -2,7 +2,7 @@
 # rocprofv3 runs for the round-1 profile (run on the GPU box via gpurun from the repo root)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/prof_r01
+OUT=${OUT:-gpurun_out/prof_r01}
 mkdir -p $OUT
 ARGS="bench.py --steps 2 --warmup 1 --no-cpu"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || exit 1

@@ -59,6 +59,7 @@ struct KArgs {
     uint32_t tile_rank, tile_world;
     uint32_t n_chunks;
     uint32_t lds_items, lds_spheres;   // counts staged into LDS (LDS variant)
+    unsigned long long *phase_stats;   // optional (diagnostic build of the kernel): 8 counters, see vk_debug_phase_stats
 };
 
 // LDS-resident hot records
@@ -153,12 +154,14 @@ __device__ __forceinline__ void cold_load_world_ray(const float *c, uint32_t lan
     }
 }
 
-template <uint32_t F, bool LDS_SCENE, int MINW>
+template <uint32_t F, bool LDS_SCENE, int MINW, bool STATS>
 __global__ __launch_bounds__(WG_THREADS, MINW) void render_kernel(KArgs A_byval) {
     (void)A_byval;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     using Mem = typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type;
+    // diagnostic counters (STATS build only): phase executions and the lanes that had work in them
+    unsigned long long st_box_steps = 0, st_box_lanes = 0, st_prim_execs = 0, st_prim_lanes = 0, st_shade_execs = 0, st_shade_lanes = 0, st_sched = 0;
 
     // ---- LDS layout: [items][spheres][per-wave pixel accumulators][per-wave cold lane state]
     uint32_t lds_items = 0;
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(WG_THREADS, MINW) void render_kernel(KArgs A_byval)
             uint32_t n_box = (uint32_t)__popcll(__ballot(is_box)), n_prim = (uint32_t)__popcll(__ballot(is_prim));
             uint32_t n_sn = (uint32_t)__popcll(__ballot(is_shade || need));
             if ((n_box | n_prim | n_sn) == 0) break;
+            if (STATS) st_sched++;
             if (n_box >= n_prim && n_box >= n_sn) {
                 // ---- BOX: predicated steps (full EXEC), two per exit test, while box lanes are the plurality
                 KArgsC P = kargs_fresh();
@@ -228,8 +232,10 @@ __global__ __launch_bounds__(WG_THREADS, MINW) void render_kernel(KArgs A_byval)
                 cold_load_world_ray<F>(cold, lane, L);
                 const uint32_t live = n_box + n_prim + n_sn;         // lanes only change state here, none appear or vanish
                 for (;;) {
+                    if (STATS) { st_box_steps += 2; st_box_lanes += __popcll(__ballot(is_box)); }
                     box_step<F, Mem>(L, S, M, is_box);
                     is_box = active && !has_prim_work(L) && traversing(L);
+                    if (STATS) st_box_lanes += __popcll(__ballot(is_box));
                     box_step<F, Mem>(L, S, M, is_box);
                     is_box = active && !has_prim_work(L) && traversing(L);
                     uint32_t nb = (uint32_t)__popcll(__ballot(is_box));
@@ -242,6 +248,7 @@ __global__ __launch_bounds__(WG_THREADS, MINW) void render_kernel(KArgs A_byval)
                 KArgsC P = kargs_fresh();
                 DScene S = KARG(P, S);
                 Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
+                if (STATS) { st_prim_execs++; st_prim_lanes += n_prim; }
                 if (is_prim) {
                     if (F & VKF_MEDIUM) {    // ConstantMedium::hit draws inside traversal (hittable.rs:473)
                         L.rng.key = (uint64_t)__float_as_uint(cold[7 * 64 + lane]) | ((uint64_t)__float_as_uint(cold[8 * 64 + lane]) << 32);
@@ -256,6 +263,7 @@ __global__ __launch_bounds__(WG_THREADS, MINW) void render_kernel(KArgs A_byval)
                 RenderConsts C = KARG(P, C);
                 DScene S = KARG(P, S);
                 Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
+                if (STATS) { st_shade_execs++; st_shade_lanes += n_sn; }
                 uint32_t q = 0;
                 bool touched = is_shade;      // lanes whose cold state is in registers during this phase
                 if (is_shade) {
@@ -313,6 +321,14 @@ __global__ __launch_bounds__(WG_THREADS, MINW) void render_kernel(KArgs A_byval)
                     p[0] = r; p[1] = g; p[2] = b;
                 }
             }
+        }
+    }
+    if (STATS) {
+        KArgsC P = kargs_fresh();
+        unsigned long long *ps = KARG(P, phase_stats);
+        if (ps && lane == 0) {
+            atomicAdd(&ps[0], st_box_steps); atomicAdd(&ps[1], st_box_lanes); atomicAdd(&ps[2], st_prim_execs); atomicAdd(&ps[3], st_prim_lanes);
+            atomicAdd(&ps[4], st_shade_execs); atomicAdd(&ps[5], st_shade_lanes); atomicAdd(&ps[6], st_sched);
         }
     }
 }
@@ -385,6 +401,8 @@ struct vk_scene {
     size_t max_lds = 65536;
     uint32_t lds_bytes = 0;    // hot-record bytes staged per workgroup (0 = not LDS resident)
     bool last_timed = false;
+    unsigned long long *phase_stats = nullptr;   // device, 8 counters (diagnostic kernel build)
+    bool want_phase_stats = false;
 };
 
 namespace {
@@ -412,11 +430,11 @@ template <uint32_t F>
 int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st) {
     constexpr int MINW = 4;   // 512-thread workgroups, 2 per CU = 4 waves per SIMD (<= 128 VGPRs)
     if (lds) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<F, true, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL((render_kernel<F, true, MINW>), grid, dim3(WG_THREADS), shmem, st, A);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<F, true, MINW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((render_kernel<F, true, MINW, false>), grid, dim3(WG_THREADS), shmem, st, A);
     } else {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<F, false, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL((render_kernel<F, false, MINW>), grid, dim3(WG_THREADS), shmem, st, A);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<F, false, MINW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((render_kernel<F, false, MINW, false>), grid, dim3(WG_THREADS), shmem, st, A);
     }
     HIP_TRY(hipGetLastError());
     (void)s;
@@ -509,8 +527,19 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
     HIP_TRY(hipMemsetAsync(s->counter, 0, sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(s->ev0, st));
     uint32_t F = pick_variant(s->host.features) | (p->integrator == VK_INTEGRATOR_PDF ? (uint32_t)VKF_INTEG_PDF : 0u);
+    if (s->want_phase_stats) {
+        if (F != 0u || !lds) return fail(VK_ERR_UNSUPPORTED, "phase statistics are only built for the sphere-only, LDS-resident variant");
+        if (!s->phase_stats) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->phase_stats), 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(s->phase_stats, 0, 8 * sizeof(unsigned long long), st));
+        A.phase_stats = s->phase_stats;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<0u, true, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((render_kernel<0u, true, 4, true>), dim3(grid), dim3(WG_THREADS), shmem, st, A);
+        HIP_TRY(hipGetLastError());
+        F = 0xFFFFFFFFu;   // launched
+    }
     const uint32_t F_CORNELL = VKF_RECT | VKF_LIST | VKF_INSTANCE;
     switch (F) {
+        case 0xFFFFFFFFu: break;
         case 0u: rc = launch_variant<0u>(s, A, lds, dim3(grid), shmem, st); break;
         case VKF_INTEG_PDF: rc = launch_variant<VKF_INTEG_PDF>(s, A, lds, dim3(grid), shmem, st); break;
         case F_CORNELL: rc = launch_variant<F_CORNELL>(s, A, lds, dim3(grid), shmem, st); break;
@@ -611,6 +640,7 @@ void vk_scene_destroy(vk_scene *s) {
     if (s->fb) (void)hipFree(s->fb);
     if (s->partial) (void)hipFree(s->partial);
     if (s->debug) (void)hipFree(s->debug);
+    if (s->phase_stats) (void)hipFree(s->phase_stats);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -712,6 +742,29 @@ int vk_to_color_device(vk_scene *scene, const void *d_rgb, uint32_t width, uint3
     hipLaunchKernelGGL(to_color_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream),
                        reinterpret_cast<const float *>(d_rgb), width, height, reinterpret_cast<uint8_t *>(d_rgb8_out));
     HIP_TRY(hipGetLastError());
+    return VK_OK;
+}
+
+// diagnostic: render with the instrumented kernel build and return the phase scheduler's counters:
+// [0] box steps executed (wave level), [1] lanes that had box work summed over those steps,
+// [2] PRIM phase executions, [3] lanes with prim work in them, [4] SHADE+REFILL executions,
+// [5] lanes shading or refilling in them, [6] scheduler rounds, [7] unused
+int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, uint64_t out[8]) {
+    if (!scene || !out) return fail(VK_ERR_BAD_ARG, "null argument");
+    size_t bytes = (size_t)params->width * params->height * 3 * sizeof(float);
+    HIP_TRY(hipSetDevice(scene->device));
+    if (bytes > scene->fb_bytes) {
+        if (scene->fb) HIP_TRY(hipFree(scene->fb));
+        scene->fb = nullptr; scene->fb_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&scene->fb), bytes));
+        scene->fb_bytes = bytes;
+    }
+    scene->want_phase_stats = true;
+    int rc = enqueue_render(scene, cam, params, scene->fb, nullptr, false, nullptr);
+    scene->want_phase_stats = false;
+    if (rc != VK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(out, scene->phase_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return VK_OK;
 }
 
