@@ -43,8 +43,8 @@ int fail(int code, const std::string &m) { g_err = m; return code; }
         if (_e != hipSuccess) return fail(VK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
-constexpr int WG_THREADS = 512;
-constexpr int WAVES_PER_WG = WG_THREADS / 64;
+constexpr int MAX_WG_THREADS = 1024;   // 16 waves = 4 per SIMD: the register budget (<= 128 VGPRs) every variant is held to
+constexpr size_t LDS_PER_CU = 160 * 1024;
 constexpr int TILE = 8;   // 8x8 pixels = one wave
 
 struct KArgs {
@@ -155,7 +155,7 @@ __device__ __forceinline__ void cold_load_world_ray(const float *c, uint32_t lan
 }
 
 template <uint32_t F, bool LDS_SCENE, int MINW, bool STATS>
-__global__ __launch_bounds__(WG_THREADS, MINW) void render_kernel(KArgs A_byval) {
+__global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : 768)), MINW) void render_kernel(KArgs A_byval) {
     (void)A_byval;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -172,12 +172,12 @@ __global__ __launch_bounds__(WG_THREADS, MINW) void render_kernel(KArgs A_byval)
         uint32_t lds_spheres = LDS_SCENE ? KARG(P, lds_spheres) : 0u;
         float *dyn = reinterpret_cast<float *>(smem + (2u * lds_items + lds_spheres));
         acc_lds = dyn + wave * (64 * 3);
-        cold = dyn + WAVES_PER_WG * (64 * 3) + wave * (64 * ncold<F>());
+        cold = dyn + (blockDim.x >> 6) * (64 * 3) + wave * (64 * ncold<F>());
         if (LDS_SCENE) {
             const uint4 *gi = reinterpret_cast<const uint4 *>(KARG(P, S.items));
-            for (uint32_t k = threadIdx.x; k < 2u * lds_items; k += WG_THREADS) smem[k] = gi[k];
+            for (uint32_t k = threadIdx.x; k < 2u * lds_items; k += blockDim.x) smem[k] = gi[k];
             const uint4 *gs = reinterpret_cast<const uint4 *>(KARG(P, S.spheres));
-            for (uint32_t k = threadIdx.x; k < lds_spheres; k += WG_THREADS) smem[2u * lds_items + k] = gs[k];
+            for (uint32_t k = threadIdx.x; k < lds_spheres; k += blockDim.x) smem[2u * lds_items + k] = gs[k];
             __syncthreads();
         }
     }
@@ -398,8 +398,9 @@ struct vk_scene {
     float4 *debug = nullptr; size_t debug_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cus = 256;
-    size_t max_lds = 65536;
     uint32_t lds_bytes = 0;    // hot-record bytes staged per workgroup (0 = not LDS resident)
+    uint32_t wg_threads = 512; // workgroup size chosen by plan_residency()
+    uint32_t wgs_per_cu = 2;
     bool last_timed = false;
     unsigned long long *phase_stats = nullptr;   // device, 8 counters (diagnostic kernel build)
     bool want_phase_stats = false;
@@ -421,23 +422,53 @@ int upload(vk_scene *s, const std::vector<T> &v, const T *&dptr) {
 
 uint32_t pick_variant(uint32_t features) {
     const uint32_t F_CORNELL = VKF_RECT | VKF_LIST | VKF_INSTANCE;
+    if (const char *e = getenv("VK_FORCE_FULL_VARIANT")) { if (e[0] == '1') return 0x7Fu; }   // diagnostics: cost of the general kernel
     if (features == 0) return 0u;
     if ((features & ~F_CORNELL) == 0) return F_CORNELL;
     return 0x7Fu;
 }
 
+size_t per_wave_lds_bytes(uint32_t F) {   // pixel accumulators + cold lane state of one wave
+    return (size_t)64 * (3 + ((F & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE)) * sizeof(float);
+}
+
+// LDS residency plan.  `hot` = bytes of items + spheres.  The traversal is a chain of dependent
+// 32-byte gathers: from LDS a step costs ~100 cycles of latency, from L2 ~500+, so residency is
+// worth a lot of occupancy.  Choose the workgroup size (waves share one LDS copy of the scene)
+// and workgroups per CU that give the most waves per CU (cap 16 = the 128-VGPR budget) with
+// the scene resident; fall back to the global-memory variant when fewer than 6 waves would fit.
+void plan_residency(vk_scene *s, size_t hot) {
+    const size_t pw = per_wave_lds_bytes(pick_variant(s->host.features));
+    uint32_t best_waves = 0, best_wg = 0, best_n = 0;
+    uint32_t cap = (pick_variant(s->host.features) == 0u) ? 24 : 16;   // waves per CU the variant's register budget admits
+    const uint32_t max_wg_waves = cap == 24 ? 12 : 16;                       // = the variant's __launch_bounds__ thread limit / 64
+    if (const char *e = getenv("VK_MAX_WAVES_PER_CU")) { int v = atoi(e); if (v >= 4 && (uint32_t)v < cap) cap = (uint32_t)v; }   // diagnostics: lower the occupancy
+    for (uint32_t n_wg = 1; n_wg <= 4; n_wg++) {
+        size_t budget = LDS_PER_CU / n_wg;
+        if (hot + 4 * pw > budget) break;
+        uint32_t w = (uint32_t)std::min<size_t>(std::min<uint32_t>(max_wg_waves, cap / n_wg), (budget - hot) / pw);
+        if (w < 1) break;
+        if (w * n_wg > best_waves) { best_waves = w * n_wg; best_wg = w; best_n = n_wg; }
+    }
+    if (best_waves >= 6) {
+        s->lds_bytes = (uint32_t)hot; s->wg_threads = best_wg * 64; s->wgs_per_cu = best_n;
+    } else {
+        s->lds_bytes = 0; s->wg_threads = 512; s->wgs_per_cu = cap / 8;
+    }
+}
+
 template <uint32_t F>
 int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st) {
-    constexpr int MINW = 4;   // 512-thread workgroups, 2 per CU = 4 waves per SIMD (<= 128 VGPRs)
+    // register budget: the sphere-only kernels fit 80 VGPRs (6 waves per SIMD, 24 per CU), the others are held to 128 (4 per SIMD)
+    constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? 6 : 4;
     if (lds) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<F, true, MINW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL((render_kernel<F, true, MINW, false>), grid, dim3(WG_THREADS), shmem, st, A);
+        hipLaunchKernelGGL((render_kernel<F, true, MINW, false>), grid, dim3(s->wg_threads), shmem, st, A);
     } else {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<F, false, MINW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL((render_kernel<F, false, MINW, false>), grid, dim3(WG_THREADS), shmem, st, A);
+        hipLaunchKernelGGL((render_kernel<F, false, MINW, false>), grid, dim3(s->wg_threads), shmem, st, A);
     }
     HIP_TRY(hipGetLastError());
-    (void)s;
     return VK_OK;
 }
 
@@ -513,14 +544,13 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
     }
     // LDS residency of the hot records
     bool lds = s->lds_bytes != 0;
-    uint32_t Fsel = pick_variant(s->host.features);
-    size_t shmem = (size_t)WAVES_PER_WG * 64 * (3 + ((Fsel & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE)) * sizeof(float);
+    const uint32_t waves_per_wg = s->wg_threads / 64;
+    size_t shmem = (size_t)waves_per_wg * per_wave_lds_bytes(pick_variant(s->host.features));
     if (lds) { A.lds_items = s->dev.n_items; A.lds_spheres = s->dev.n_spheres; shmem += s->lds_bytes; }
     // persistent grid: enough workgroups to fill the chip, never more than there are units
     uint32_t n_units = A.n_local_tiles * A.n_chunks;
-    uint32_t wgs_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / WG_THREADS, (160 * 1024) / std::max<size_t>(shmem, 1)));
-    uint32_t grid = (uint32_t)s->num_cus * wgs_per_cu;
-    uint32_t need_wgs = (n_units + WAVES_PER_WG - 1) / WAVES_PER_WG;
+    uint32_t grid = (uint32_t)s->num_cus * s->wgs_per_cu;
+    uint32_t need_wgs = (n_units + waves_per_wg - 1) / waves_per_wg;
     if (grid > need_wgs) grid = need_wgs;
     if (grid < 1) grid = 1;
 
@@ -528,12 +558,18 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
     HIP_TRY(hipEventRecord(s->ev0, st));
     uint32_t F = pick_variant(s->host.features) | (p->integrator == VK_INTEGRATOR_PDF ? (uint32_t)VKF_INTEG_PDF : 0u);
     if (s->want_phase_stats) {
-        if (F != 0u || !lds) return fail(VK_ERR_UNSUPPORTED, "phase statistics are only built for the sphere-only, LDS-resident variant");
+        const uint32_t FULLPDF = 0x7Fu | VKF_INTEG_PDF;
+        if ((F != 0u && F != FULLPDF) || !lds) return fail(VK_ERR_UNSUPPORTED, "phase statistics are only built for the LDS-resident sphere-only and full/PDF variants");
         if (!s->phase_stats) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->phase_stats), 8 * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(s->phase_stats, 0, 8 * sizeof(unsigned long long), st));
         A.phase_stats = s->phase_stats;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<0u, true, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL((render_kernel<0u, true, 4, true>), dim3(grid), dim3(WG_THREADS), shmem, st, A);
+        if (F == 0u) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<0u, true, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            hipLaunchKernelGGL((render_kernel<0u, true, 6, true>), dim3(grid), dim3(s->wg_threads), shmem, st, A);
+        } else {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<FULLPDF, true, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            hipLaunchKernelGGL((render_kernel<FULLPDF, true, 4, true>), dim3(grid), dim3(s->wg_threads), shmem, st, A);
+        }
         HIP_TRY(hipGetLastError());
         F = 0xFFFFFFFFu;   // launched
     }
@@ -608,7 +644,6 @@ int vk_scene_create(const vk_scene_desc *desc, int device, vk_scene **out) {
     if (rc != VK_OK) { delete s; return fail(rc, err); }
     HIP_TRY(hipSetDevice(device));
     s->num_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-    s->max_lds = 160 * 1024;
     const LinearScene &H = s->host;
     DScene &D = s->dev;
     memset(&D, 0, sizeof(D));
@@ -626,8 +661,7 @@ int vk_scene_create(const vk_scene_desc *desc, int device, vk_scene **out) {
     if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { vk_scene_destroy(s); return fail(VK_ERR_HIP, "hipEventCreate failed"); }
     // LDS residency: items + spheres + accumulators must leave room for >= 2 workgroups per CU
     size_t hot = H.items.size() * sizeof(DItem) + H.spheres.size() * sizeof(DSphere);
-    size_t accb = (size_t)WAVES_PER_WG * 64 * (3 + NCOLD_INST) * sizeof(float);
-    s->lds_bytes = (hot + accb <= 80 * 1024) ? (uint32_t)hot : 0u;   // two 512-thread workgroups per CU must fit in 160 KB
+    plan_residency(s, hot);
     *out = s;
     return VK_OK;
 }
