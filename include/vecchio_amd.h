@@ -275,8 +275,10 @@ int vk_debug_render_samples(vk_scene *scene, const vk_camera *cam, const vk_rend
                             float *rgb_out, float *samples_out);
 /* render with the instrumented build of the sphere-only kernel and return the wave scheduler's
  * counters: [0] box steps (wave level) [1] lanes with box work summed over them [2] PRIM phases
- * [3] lanes with primitive work in them [4] SHADE+REFILL phases [5] lanes in them [6] rounds  */
-int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, uint64_t out[8]);
+ * [3] lanes with primitive work in them [4] SHADE+REFILL phases [5] lanes in them [6] rounds
+ * [7] heavy-primitive phases; wave clocks spent in [8] BOX [9] light PRIM [10] heavy PRIM
+ * [11] SHADE+REFILL phases, [12] total wave clocks                                           */
+int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, uint64_t out[16]);
 /* evaluate the shared host/device arithmetic ON THE DEVICE (host arrays in/out):
  * op 0 sin, 1 cos, 2 ln, 3 asin, 4 atan2(a,b), 5 pow5, 6 a/b, 7 sqrt(a), 8 draws, 9 a*b+a  */
 int vk_debug_math(int device, int op, const float *a, const float *b, float *out, size_t n);

@@ -42,8 +42,8 @@ extern "C" {
 const char *emu_last_error(void) { return g_err.c_str(); }
 
 // full-feature variant only (the GPU picks leaner variants; logic is the same code)
-static const uint32_t FALL = 0x7Fu;
-static const uint32_t FPDF = 0x7Fu | VKF_INTEG_PDF;
+static const uint32_t FALL = VKF_ALL_SCENE;
+static const uint32_t FPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
 
 int emu_sample(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *p, uint32_t pixel, uint32_t sample,
                float rgb[3], uint32_t *draws) {
@@ -51,7 +51,7 @@ int emu_sample(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
     int st = linearize(desc, LS, g_err);
     if (st != VK_OK) return st;
     DScene S = LS.host_view();
-    GlobalMem M{S.items, S.spheres, S.sphere_mat};
+    GlobalMem M{S.items, S.spheres, S.sphere_mat, S.boxes};
     RenderConsts C = make_consts(cam, p);
     V3 c; uint32_t dr;
     if (p->integrator == VK_INTEGRATOR_PDF) trace_one<FPDF>(S, M, C, pixel, sample, c, dr, nullptr);
@@ -69,7 +69,7 @@ int emu_render(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
     if (st != VK_OK) return st;
     if (p->integrator == VK_INTEGRATOR_PDF && LS.lights.empty()) { g_err = "PDF integrator needs a non-empty lights list (hittable.rs:431 would panic)"; return VK_ERR_UNSUPPORTED; }
     DScene S = LS.host_view();
-    GlobalMem M{S.items, S.spheres, S.sphere_mat};
+    GlobalMem M{S.items, S.spheres, S.sphere_mat, S.boxes};
     RenderConsts C = make_consts(cam, p);
     if (info_out) { info_out[0] = S.n_items; info_out[1] = LS.n_prims; info_out[2] = (uint32_t)LS.instances.size(); info_out[3] = LS.features; }
     if (n_threads < 1) n_threads = 1;

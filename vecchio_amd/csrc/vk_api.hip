@@ -58,7 +58,7 @@ struct KArgs {
     uint32_t n_local_tiles;  // tiles of this call's partition
     uint32_t tile_rank, tile_world;
     uint32_t n_chunks;
-    uint32_t lds_items, lds_spheres;   // counts staged into LDS (LDS variant)
+    uint32_t lds_items, lds_spheres, lds_boxes;   // record counts staged into LDS (LDS variant)
     unsigned long long *phase_stats;   // optional (diagnostic build of the kernel): 8 counters, see vk_debug_phase_stats
 };
 
@@ -66,7 +66,16 @@ struct KArgs {
 struct LdsMem {
     const uint4 *items;      // 2 x uint4 per item
     const float4 *spheres;
+    const uint4 *boxes;      // 2 x uint4 per DBox
     const uint32_t *sphere_mat;
+    __device__ __forceinline__ DBox box(uint32_t i) const {
+        uint4 a = boxes[2 * i], b = boxes[2 * i + 1];
+        DBox o;
+        o.p0[0] = __uint_as_float(a.x); o.p0[1] = __uint_as_float(a.y); o.p0[2] = __uint_as_float(a.z);
+        o.p1x = __uint_as_float(a.w); o.p1y = __uint_as_float(b.x); o.p1z = __uint_as_float(b.y);
+        o.mat = b.z; o._p = 0;
+        return o;
+    }
     __device__ __forceinline__ DItem item(uint32_t i) const {
         uint4 a = items[2 * i], b = items[2 * i + 1];
         DItem n;
@@ -104,9 +113,10 @@ template <uint32_t F, bool LDS_SCENE>
 __device__ __forceinline__ typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type make_mem(const DScene &S, uint32_t lds_items) {
     typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type M;
     if constexpr (LDS_SCENE) {
-        M.items = smem; M.spheres = reinterpret_cast<const float4 *>(smem + 2u * lds_items); M.sphere_mat = S.sphere_mat;
+        M.items = smem; M.spheres = reinterpret_cast<const float4 *>(smem + 2u * lds_items);
+        M.boxes = smem + 2u * lds_items + S.n_spheres; M.sphere_mat = S.sphere_mat;
     } else {
-        M.items = S.items; M.spheres = S.spheres; M.sphere_mat = S.sphere_mat;
+        M.items = S.items; M.spheres = S.spheres; M.sphere_mat = S.sphere_mat; M.boxes = S.boxes;
     }
     return M;
 }
@@ -162,6 +172,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : 768)), MINW)
     using Mem = typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type;
     // diagnostic counters (STATS build only): phase executions and the lanes that had work in them
     unsigned long long st_box_steps = 0, st_box_lanes = 0, st_prim_execs = 0, st_prim_lanes = 0, st_shade_execs = 0, st_shade_lanes = 0, st_sched = 0;
+    unsigned long long st_t_box = 0, st_t_light = 0, st_t_heavy = 0, st_t_shade = 0, st_heavy_execs = 0, st_t0 = 0, st_t_total = 0;
+    if (STATS) st_t_total = clock64();
 
     // ---- LDS layout: [items][spheres][per-wave pixel accumulators][per-wave cold lane state]
     uint32_t lds_items = 0;
@@ -170,7 +182,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : 768)), MINW)
         KArgsC P = kargs_fresh();
         lds_items = LDS_SCENE ? KARG(P, lds_items) : 0u;
         uint32_t lds_spheres = LDS_SCENE ? KARG(P, lds_spheres) : 0u;
-        float *dyn = reinterpret_cast<float *>(smem + (2u * lds_items + lds_spheres));
+        uint32_t lds_boxes = LDS_SCENE ? KARG(P, lds_boxes) : 0u;
+        float *dyn = reinterpret_cast<float *>(smem + (2u * lds_items + lds_spheres + 2u * lds_boxes));
         acc_lds = dyn + wave * (64 * 3);
         cold = dyn + (blockDim.x >> 6) * (64 * 3) + wave * (64 * ncold<F>());
         if (LDS_SCENE) {
@@ -178,6 +191,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : 768)), MINW)
             for (uint32_t k = threadIdx.x; k < 2u * lds_items; k += blockDim.x) smem[k] = gi[k];
             const uint4 *gs = reinterpret_cast<const uint4 *>(KARG(P, S.spheres));
             for (uint32_t k = threadIdx.x; k < lds_spheres; k += blockDim.x) smem[2u * lds_items + k] = gs[k];
+            const uint4 *gb = reinterpret_cast<const uint4 *>(KARG(P, S.boxes));
+            for (uint32_t k = threadIdx.x; k < 2u * lds_boxes; k += blockDim.x) smem[2u * lds_items + lds_spheres + k] = gb[k];
             __syncthreads();
         }
     }
@@ -220,7 +235,15 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : 768)), MINW)
             bool is_prim = active && has_prim_work(L);
             bool is_box = active && !is_prim && traversing(L);
             bool is_shade = active && !is_prim && !is_box;
-            uint32_t n_box = (uint32_t)__popcll(__ballot(is_box)), n_prim = (uint32_t)__popcll(__ballot(is_prim));
+            // primitives come in two weights (sphere/rect ~50 instructions; Boxy, list, medium, instance
+            // entry several times that): scheduled separately so cheap tests never pay for heavy ones
+            const bool HAS_HEAVY = (F & (VKF_LIST | VKF_MEDIUM | VKF_INSTANCE | VKF_BOX)) != 0;
+            bool is_heavy = HAS_HEAVY && is_prim && prim_is_heavy(L.pend);
+            uint32_t n_box = (uint32_t)__popcll(__ballot(is_box));
+            uint32_t n_heavy = HAS_HEAVY ? (uint32_t)__popcll(__ballot(is_heavy)) : 0u;
+            uint32_t n_light = (uint32_t)__popcll(__ballot(is_prim && !is_heavy));
+            if (n_heavy > n_light) { is_prim = is_heavy; } else { is_prim = is_prim && !is_heavy; }
+            uint32_t n_prim = n_heavy > n_light ? n_heavy : n_light;
             uint32_t n_sn = (uint32_t)__popcll(__ballot(is_shade || need));
             if ((n_box | n_prim | n_sn) == 0) break;
             if (STATS) st_sched++;
@@ -229,8 +252,9 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : 768)), MINW)
                 KArgsC P = kargs_fresh();
                 DScene S = KARG(P, S);
                 Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
+                if (STATS) st_t0 = clock64();
                 cold_load_world_ray<F>(cold, lane, L);
-                const uint32_t live = n_box + n_prim + n_sn;         // lanes only change state here, none appear or vanish
+                const uint32_t live = n_box + n_heavy + n_light + n_sn;   // lanes only change state here, none appear or vanish
                 for (;;) {
                     if (STATS) { st_box_steps += 2; st_box_lanes += __popcll(__ballot(is_box)); }
                     box_step<F, Mem>(L, S, M, is_box);
@@ -243,12 +267,13 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : 768)), MINW)
                     uint32_t ns = live - nb - np;
                     if (nb == 0 || nb < np || nb < ns) break;          // another state now has more lanes parked than are stepping
                 }
+                if (STATS) st_t_box += clock64() - st_t0;
             } else if (n_prim >= n_sn) {
                 // ---- PRIM: intersect / enter the pending object
                 KArgsC P = kargs_fresh();
                 DScene S = KARG(P, S);
                 Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
-                if (STATS) { st_prim_execs++; st_prim_lanes += n_prim; }
+                if (STATS) { st_prim_execs++; st_prim_lanes += n_prim; st_t0 = clock64(); if (n_heavy > n_light) st_heavy_execs++; }
                 if (is_prim) {
                     if (F & VKF_MEDIUM) {    // ConstantMedium::hit draws inside traversal (hittable.rs:473)
                         L.rng.key = (uint64_t)__float_as_uint(cold[7 * 64 + lane]) | ((uint64_t)__float_as_uint(cold[8 * 64 + lane]) << 32);
@@ -257,13 +282,14 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : 768)), MINW)
                     prim_step<F, Mem>(L, S, M);
                     if (F & VKF_MEDIUM) cold[9 * 64 + lane] = __uint_as_float(L.rng.ctr);
                 }
+                if (STATS) { if (n_heavy > n_light) st_t_heavy += clock64() - st_t0; else st_t_light += clock64() - st_t0; }
             } else {
                 // ---- SHADE + REFILL
                 KArgsC P = kargs_fresh();
                 RenderConsts C = KARG(P, C);
                 DScene S = KARG(P, S);
                 Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
-                if (STATS) { st_shade_execs++; st_shade_lanes += n_sn; }
+                if (STATS) { st_shade_execs++; st_shade_lanes += n_sn; st_t0 = clock64(); }
                 uint32_t q = 0;
                 bool touched = is_shade;      // lanes whose cold state is in registers during this phase
                 if (is_shade) {
@@ -302,6 +328,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : 768)), MINW)
                     next_item += (uint32_t)__popcll(need_mask);
                 }
                 if (active && touched) cold_store<F>(cold, lane, L, q);
+                if (STATS) st_t_shade += clock64() - st_t0;
             }
         }
         // ---- write the unit's pixel sums
@@ -328,7 +355,9 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : 768)), MINW)
         unsigned long long *ps = KARG(P, phase_stats);
         if (ps && lane == 0) {
             atomicAdd(&ps[0], st_box_steps); atomicAdd(&ps[1], st_box_lanes); atomicAdd(&ps[2], st_prim_execs); atomicAdd(&ps[3], st_prim_lanes);
-            atomicAdd(&ps[4], st_shade_execs); atomicAdd(&ps[5], st_shade_lanes); atomicAdd(&ps[6], st_sched);
+            atomicAdd(&ps[4], st_shade_execs); atomicAdd(&ps[5], st_shade_lanes); atomicAdd(&ps[6], st_sched); atomicAdd(&ps[7], st_heavy_execs);
+            atomicAdd(&ps[8], st_t_box); atomicAdd(&ps[9], st_t_light); atomicAdd(&ps[10], st_t_heavy); atomicAdd(&ps[11], st_t_shade);
+            atomicAdd(&ps[12], (unsigned long long)(clock64() - st_t_total));
         }
     }
 }
@@ -421,11 +450,11 @@ int upload(vk_scene *s, const std::vector<T> &v, const T *&dptr) {
 }
 
 uint32_t pick_variant(uint32_t features) {
-    const uint32_t F_CORNELL = VKF_RECT | VKF_LIST | VKF_INSTANCE;
-    if (const char *e = getenv("VK_FORCE_FULL_VARIANT")) { if (e[0] == '1') return 0x7Fu; }   // diagnostics: cost of the general kernel
+    const uint32_t F_CORNELL = VKF_RECT | VKF_LIST | VKF_INSTANCE | VKF_BOX;
+    if (const char *e = getenv("VK_FORCE_FULL_VARIANT")) { if (e[0] == '1') return VKF_ALL_SCENE; }   // diagnostics: cost of the general kernel
     if (features == 0) return 0u;
     if ((features & ~F_CORNELL) == 0) return F_CORNELL;
-    return 0x7Fu;
+    return VKF_ALL_SCENE;
 }
 
 size_t per_wave_lds_bytes(uint32_t F) {   // pixel accumulators + cold lane state of one wave
@@ -546,7 +575,7 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
     bool lds = s->lds_bytes != 0;
     const uint32_t waves_per_wg = s->wg_threads / 64;
     size_t shmem = (size_t)waves_per_wg * per_wave_lds_bytes(pick_variant(s->host.features));
-    if (lds) { A.lds_items = s->dev.n_items; A.lds_spheres = s->dev.n_spheres; shmem += s->lds_bytes; }
+    if (lds) { A.lds_items = s->dev.n_items; A.lds_spheres = s->dev.n_spheres; A.lds_boxes = s->dev.n_boxes; shmem += s->lds_bytes; }
     // persistent grid: enough workgroups to fill the chip, never more than there are units
     uint32_t n_units = A.n_local_tiles * A.n_chunks;
     uint32_t grid = (uint32_t)s->num_cus * s->wgs_per_cu;
@@ -558,10 +587,10 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
     HIP_TRY(hipEventRecord(s->ev0, st));
     uint32_t F = pick_variant(s->host.features) | (p->integrator == VK_INTEGRATOR_PDF ? (uint32_t)VKF_INTEG_PDF : 0u);
     if (s->want_phase_stats) {
-        const uint32_t FULLPDF = 0x7Fu | VKF_INTEG_PDF;
+        const uint32_t FULLPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
         if ((F != 0u && F != FULLPDF) || !lds) return fail(VK_ERR_UNSUPPORTED, "phase statistics are only built for the LDS-resident sphere-only and full/PDF variants");
-        if (!s->phase_stats) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->phase_stats), 8 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(s->phase_stats, 0, 8 * sizeof(unsigned long long), st));
+        if (!s->phase_stats) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->phase_stats), 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(s->phase_stats, 0, 16 * sizeof(unsigned long long), st));
         A.phase_stats = s->phase_stats;
         if (F == 0u) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<0u, true, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -573,15 +602,15 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
         HIP_TRY(hipGetLastError());
         F = 0xFFFFFFFFu;   // launched
     }
-    const uint32_t F_CORNELL = VKF_RECT | VKF_LIST | VKF_INSTANCE;
+    const uint32_t F_CORNELL = VKF_RECT | VKF_LIST | VKF_INSTANCE | VKF_BOX;
     switch (F) {
         case 0xFFFFFFFFu: break;
         case 0u: rc = launch_variant<0u>(s, A, lds, dim3(grid), shmem, st); break;
         case VKF_INTEG_PDF: rc = launch_variant<VKF_INTEG_PDF>(s, A, lds, dim3(grid), shmem, st); break;
         case F_CORNELL: rc = launch_variant<F_CORNELL>(s, A, lds, dim3(grid), shmem, st); break;
         case F_CORNELL | VKF_INTEG_PDF: rc = launch_variant<(F_CORNELL | VKF_INTEG_PDF)>(s, A, lds, dim3(grid), shmem, st); break;
-        case 0x7Fu: rc = launch_variant<0x7Fu>(s, A, lds, dim3(grid), shmem, st); break;
-        default: rc = launch_variant<(0x7Fu | VKF_INTEG_PDF)>(s, A, lds, dim3(grid), shmem, st); break;
+        case VKF_ALL_SCENE: rc = launch_variant<VKF_ALL_SCENE>(s, A, lds, dim3(grid), shmem, st); break;
+        default: rc = launch_variant<(VKF_ALL_SCENE | VKF_INTEG_PDF)>(s, A, lds, dim3(grid), shmem, st); break;
     }
     if (rc != VK_OK) return rc;
     uint32_t launches = 1;
@@ -648,19 +677,19 @@ int vk_scene_create(const vk_scene_desc *desc, int device, vk_scene **out) {
     DScene &D = s->dev;
     memset(&D, 0, sizeof(D));
 #define UP(vec, field) do { rc = upload(s, H.vec, D.field); if (rc != VK_OK) { vk_scene_destroy(s); return rc; } } while (0)
-    UP(items, items); UP(spheres, spheres); UP(sphere_mat, sphere_mat); UP(moving, moving); UP(rects, rects);
+    UP(items, items); UP(spheres, spheres); UP(sphere_mat, sphere_mat); UP(moving, moving); UP(rects, rects); UP(boxes, boxes);
     UP(lists, lists); UP(list_refs, list_refs); UP(media, media); UP(instances, instances);
     UP(materials, materials); UP(textures, textures); UP(images, images); UP(image_bytes, image_bytes);
     UP(perlins, perlins); UP(lights, lights);
 #undef UP
     D.n_items = (uint32_t)H.items.size(); D.n_world_items = H.world_items; D.n_spheres = (uint32_t)H.spheres.size();
-    D.n_lights = (uint32_t)H.lights.size(); D.features = H.features;
+    D.n_lights = (uint32_t)H.lights.size(); D.features = H.features; D.n_boxes = (uint32_t)H.boxes.size();
     void *c = nullptr;
     if (hipMalloc(&c, 256) != hipSuccess) { vk_scene_destroy(s); return fail(VK_ERR_OOM, "hipMalloc failed"); }
     s->counter = reinterpret_cast<uint32_t *>(c);
     if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { vk_scene_destroy(s); return fail(VK_ERR_HIP, "hipEventCreate failed"); }
     // LDS residency: items + spheres + accumulators must leave room for >= 2 workgroups per CU
-    size_t hot = H.items.size() * sizeof(DItem) + H.spheres.size() * sizeof(DSphere);
+    size_t hot = H.items.size() * sizeof(DItem) + H.spheres.size() * sizeof(DSphere) + H.boxes.size() * sizeof(DBox);
     plan_residency(s, hot);
     *out = s;
     return VK_OK;
@@ -783,7 +812,7 @@ int vk_to_color_device(vk_scene *scene, const void *d_rgb, uint32_t width, uint3
 // [0] box steps executed (wave level), [1] lanes that had box work summed over those steps,
 // [2] PRIM phase executions, [3] lanes with prim work in them, [4] SHADE+REFILL executions,
 // [5] lanes shading or refilling in them, [6] scheduler rounds, [7] unused
-int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, uint64_t out[8]) {
+int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, uint64_t out[16]) {
     if (!scene || !out) return fail(VK_ERR_BAD_ARG, "null argument");
     size_t bytes = (size_t)params->width * params->height * 3 * sizeof(float);
     HIP_TRY(hipSetDevice(scene->device));
@@ -798,7 +827,7 @@ int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_
     scene->want_phase_stats = false;
     if (rc != VK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(nullptr));
-    HIP_TRY(hipMemcpy(out, scene->phase_stats, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, scene->phase_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return VK_OK;
 }
 

@@ -23,7 +23,7 @@
 namespace vkd {
 
 enum : uint32_t {
-    DK_NONE = 0, DK_SPHERE = 1, DK_MOVING = 2, DK_RECT = 3, DK_LIST = 4, DK_MEDIUM = 5, DK_INSTANCE = 6,
+    DK_NONE = 0, DK_SPHERE = 1, DK_MOVING = 2, DK_RECT = 3, DK_LIST = 4, DK_MEDIUM = 5, DK_INSTANCE = 6, DK_BOX = 7,
     DK_PRIM_ITEM = 15
 };
 constexpr uint32_t DREF_FLIP = 0x08000000u;
@@ -43,6 +43,10 @@ struct alignas(16) DSphere { float cx, cy, cz, r; };                       // 16
 struct alignas(16) DMoving { float c0[3], t0, c1[3], t1, r; uint32_t mat, _p0, _p1; };  // 48 B
 struct alignas(16) DRect { float c0, c1, d0, d1, k; uint32_t axes; uint32_t mat, _p; };  // 32 B; axes = a0 | a1<<2 | a2<<4
 struct DList { uint32_t first, count; };
+// A Vec of exactly the six rects Boxy::new builds (hittable.rs:325-353), recognised by the
+// lineariser and stored as its two corners: 32 B instead of 6 x 32 B + 6 refs, LDS-cacheable.
+// Face f (= index in Boxy::sides): 0 XY@p1.z, 1 Flip XY@p0.z, 2 XZ@p1.y, 3 Flip XZ@p0.y, 4 YZ@p1.x, 5 Flip YZ@p0.x
+struct alignas(16) DBox { float p0[3]; float p1x; float p1y, p1z; uint32_t mat, _p; };
 struct alignas(16) DMedium { uint32_t boundary; float neg_inv_density; uint32_t mat, _p; };
 
 enum : uint32_t { OP_TRANSLATE = 0, OP_ROTATE_X = 1, OP_ROTATE_Y = 2, OP_ROTATE_Z = 3 };
@@ -79,6 +83,8 @@ enum : uint32_t {  // feature bits -> kernel variant selection
     VKF_MOVING = 1u, VKF_RECT = 2u, VKF_LIST = 4u, VKF_MEDIUM = 8u, VKF_INSTANCE = 16u,
     VKF_TEXTURES = 32u,   // any non-solid texture (checker/image/noise)
     VKF_SPEC_DIFFUSE = 64u,
+    VKF_BOX = 256u,       // canonical Boxy lists stored as DBox
+    VKF_ALL_SCENE = 0x17Fu,
     VKF_INTEG_PDF = 128u  // not a scene property: selects the HEAD integrator (main.rs:123-153) at compile time
 };
 
@@ -88,6 +94,7 @@ struct DScene {
     const DSphere *spheres; const uint32_t *sphere_mat; uint32_t n_spheres;
     const DMoving *moving;
     const DRect *rects;
+    const DBox *boxes; uint32_t n_boxes;
     const DList *lists; const uint32_t *list_refs;
     const DMedium *media;
     const DInstance *instances;

@@ -14,6 +14,7 @@ DScene LinearScene::host_view() const {
     s.items = items.data(); s.n_items = (uint32_t)items.size(); s.n_world_items = world_items;
     s.spheres = spheres.data(); s.sphere_mat = sphere_mat.data(); s.n_spheres = (uint32_t)spheres.size();
     s.moving = moving.data(); s.rects = rects.data();
+    s.boxes = boxes.data(); s.n_boxes = (uint32_t)boxes.size();
     s.lists = lists.data(); s.list_refs = list_refs.data();
     s.media = media.data(); s.instances = instances.data();
     s.materials = materials.data(); s.textures = textures.data();
@@ -31,7 +32,7 @@ struct Builder {
     LinearScene &L;
     std::string &err;
     int status = VK_OK;
-    std::map<uint32_t, uint32_t> list_memo, medium_memo;
+    std::map<uint32_t, uint32_t> list_memo, medium_memo, box_memo;
     struct Pending { uint32_t bvh_index; uint32_t flip; int32_t inst; };
     std::deque<Pending> pending;   // BVH children of instances, emitted after the current range
 
@@ -83,6 +84,40 @@ struct Builder {
         L.features |= VKF_LIST;
         out = (uint32_t)L.lists.size() - 1;
         list_memo[idx] = out;
+        return true;
+    }
+
+    // Is list `idx` exactly Boxy::new(p0, p1, mat) (hittable.rs:321-359)?  Then store it as a DBox.
+    bool as_box(uint32_t idx, uint32_t &out) {
+        auto it = box_memo.find(idx);
+        if (it != box_memo.end()) { out = it->second; return out != 0xFFFFFFFFu; }
+        box_memo[idx] = 0xFFFFFFFFu;
+        const vk_list &l = d->lists[idx];
+        if (l.count != 6 || (uint64_t)l.first + 6 > d->n_list_items) return false;
+        const vk_rect *q[6];
+        static const uint8_t ax[6][3] = {{0, 1, 2}, {0, 1, 2}, {0, 2, 1}, {0, 2, 1}, {1, 2, 0}, {1, 2, 0}};
+        for (int f = 0; f < 6; f++) {
+            vk_ref r = d->list_items[l.first + f];
+            if (VK_REF_KIND(r) != VK_KIND_RECT || VK_REF_INDEX(r) >= d->n_rects) return false;
+            if (((r & VK_REF_FLIP) != 0) != ((f & 1) != 0)) return false;
+            q[f] = &d->rects[VK_REF_INDEX(r)];
+            if (q[f]->axis0 != ax[f][0] || q[f]->axis1 != ax[f][1] || q[f]->axis2 != ax[f][2]) return false;
+            if (q[f]->material != q[0]->material) return false;
+        }
+        float p0x = q[0]->c0, p1x = q[0]->c1, p0y = q[0]->d0, p1y = q[0]->d1, p1z = q[0]->k, p0z = q[1]->k;
+        auto same = [](float a, float b) { return memcmp(&a, &b, 4) == 0; };
+        bool ok = same(q[1]->c0, p0x) && same(q[1]->c1, p1x) && same(q[1]->d0, p0y) && same(q[1]->d1, p1y) &&
+                  same(q[2]->c0, p0x) && same(q[2]->c1, p1x) && same(q[2]->d0, p0z) && same(q[2]->d1, p1z) && same(q[2]->k, p1y) &&
+                  same(q[3]->c0, p0x) && same(q[3]->c1, p1x) && same(q[3]->d0, p0z) && same(q[3]->d1, p1z) && same(q[3]->k, p0y) &&
+                  same(q[4]->c0, p0y) && same(q[4]->c1, p1y) && same(q[4]->d0, p0z) && same(q[4]->d1, p1z) && same(q[4]->k, p1x) &&
+                  same(q[5]->c0, p0y) && same(q[5]->c1, p1y) && same(q[5]->d0, p0z) && same(q[5]->d1, p1z) && same(q[5]->k, p0x);
+        if (!ok || q[0]->material >= d->n_materials) return false;
+        DBox b; memset(&b, 0, sizeof(b));
+        b.p0[0] = p0x; b.p0[1] = p0y; b.p0[2] = p0z; b.p1x = p1x; b.p1y = p1y; b.p1z = p1z; b.mat = q[0]->material;
+        L.boxes.push_back(b);
+        L.features |= VKF_BOX;
+        out = (uint32_t)L.boxes.size() - 1;
+        box_memo[idx] = out;
         return true;
     }
 
@@ -164,7 +199,11 @@ struct Builder {
         uint32_t k = VK_REF_KIND(r), i = VK_REF_INDEX(r);
         uint32_t f = ((r & VK_REF_FLIP) ? DREF_FLIP : 0u) ^ flip;
         if (is_simple(k)) { out = simple_dref(r, flip); return true; }
-        if (k == VK_KIND_LIST) { uint32_t li; if (!convert_list(i, li)) return false; out = VKD_MAKE(DK_LIST, li) | f; return true; }
+        if (k == VK_KIND_LIST) {
+            uint32_t bi;
+            if (as_box(i, bi)) { out = VKD_MAKE(DK_BOX, bi) | f; return true; }
+            uint32_t li; if (!convert_list(i, li)) return false; out = VKD_MAKE(DK_LIST, li) | f; return true;
+        }
         if (k == VK_KIND_MEDIUM) { uint32_t mi; if (!convert_medium(i, mi)) return false; out = VKD_MAKE(DK_MEDIUM, mi) | f; return true; }
         if (k == VK_KIND_TRANSLATE || k == VK_KIND_ROTATE) return convert_instance(r, flip, inst, out, nest);
         return fail(VK_ERR_UNSUPPORTED, "device path: a BVHNode may only appear as the world, as a BVH child or under Translate/Rotate");
@@ -177,7 +216,7 @@ struct Builder {
         }
     }
 
-    static bool draw_free(uint32_t dref) { uint32_t k = VKD_KIND(dref); return k == DK_SPHERE || k == DK_MOVING || k == DK_RECT || k == DK_LIST; }
+    static bool draw_free(uint32_t dref) { uint32_t k = VKD_KIND(dref); return k == DK_SPHERE || k == DK_MOVING || k == DK_RECT || k == DK_LIST || k == DK_BOX; }
 
     // pre-order emission of one BVH (accel.rs:58-83 order: box, left, right); iterative to
     // survive 1M-primitive trees and degenerate depth

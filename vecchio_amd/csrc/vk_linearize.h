@@ -18,6 +18,7 @@ struct LinearScene {
     std::vector<uint32_t> sphere_mat;
     std::vector<DMoving> moving;
     std::vector<DRect> rects;
+    std::vector<DBox> boxes;
     std::vector<DList> lists;
     std::vector<uint32_t> list_refs;
     std::vector<DMedium> media;

@@ -55,7 +55,8 @@ struct RenderConsts {   // per-launch constants (camera + params)
 // Hot records (items, spheres) come either from HBM/L2 (GlobalMem) or from the workgroup's
 // LDS copy of the scene (LdsMem, set up by the kernel).
 struct GlobalMem {
-    const DItem *items; const DSphere *spheres; const uint32_t *sphere_mat;
+    const DItem *items; const DSphere *spheres; const uint32_t *sphere_mat; const DBox *boxes;
+    VK_HD DBox box(uint32_t i) const { return boxes[i]; }
     VK_HD DItem item(uint32_t i) const { return items[i]; }
     VK_HD DSphere sphere(uint32_t i) const { return spheres[i]; }
     VK_HD uint32_t smat(uint32_t i) const { return sphere_mat[i]; }
@@ -186,6 +187,44 @@ VK_HD bool list_t(const DScene &S, const Mem &M, uint32_t list_ref, V3 o, V3 d, 
     t = closest;
     return found;
 }
+// Boxy::hit = sides.hit (hittable.rs:362-365,381-394) for the canonical six rects, unrolled with
+// compile-time axes.  Same tests in the same order as list_t over the six vk_rects: Rect::hit's
+// inclusive bounds, then the list's strict `rec.t < closest_dist`.
+template <int A0, int A1, int A2>
+VK_HD void box_face(float k, float c0, float c1, float d0, float d1, V3 o, V3 d, float tmin, float &closest, uint32_t f, uint32_t &face, bool &found) {
+    float t = (k - comp(o, A2)) / comp(d, A2);
+    if (t < tmin || t > closest) return;
+    float a = comp(o, A0) + t * comp(d, A0);
+    float b = comp(o, A1) + t * comp(d, A1);
+    if (a < c0 || a > c1 || b < d0 || b > d1) return;
+    if (t < closest) { closest = t; face = f; found = true; }
+}
+VK_HD bool box_t(const DBox &B, V3 o, V3 d, float tmin, float tmax, float &t, uint32_t &face) {
+    float closest = tmax;
+    bool found = false;
+    box_face<0, 1, 2>(B.p1z, B.p0[0], B.p1x, B.p0[1], B.p1y, o, d, tmin, closest, 0u, face, found);
+    box_face<0, 1, 2>(B.p0[2], B.p0[0], B.p1x, B.p0[1], B.p1y, o, d, tmin, closest, 1u, face, found);
+    box_face<0, 2, 1>(B.p1y, B.p0[0], B.p1x, B.p0[2], B.p1z, o, d, tmin, closest, 2u, face, found);
+    box_face<0, 2, 1>(B.p0[1], B.p0[0], B.p1x, B.p0[2], B.p1z, o, d, tmin, closest, 3u, face, found);
+    box_face<1, 2, 0>(B.p1x, B.p0[1], B.p1y, B.p0[2], B.p1z, o, d, tmin, closest, 4u, face, found);
+    box_face<1, 2, 0>(B.p0[0], B.p0[1], B.p1y, B.p0[2], B.p1z, o, d, tmin, closest, 5u, face, found);
+    t = closest;
+    return found;
+}
+// the vk_rect that face f of a DBox stands for
+VK_HD DRect box_face_rect(const DBox &B, uint32_t f) {
+    DRect q;
+    uint32_t pair = f >> 1;                       // 0: XY, 1: XZ, 2: YZ
+    bool hi = (f & 1u) == 0u;                     // even faces sit at p1, odd (FlipFace'd) ones at p0
+    float p0x = B.p0[0], p0y = B.p0[1], p0z = B.p0[2];
+    q.c0 = pair == 2 ? p0y : p0x; q.c1 = pair == 2 ? B.p1y : B.p1x;
+    q.d0 = pair == 0 ? p0y : p0z; q.d1 = pair == 0 ? B.p1y : B.p1z;
+    q.k = pair == 0 ? (hi ? B.p1z : p0z) : (pair == 1 ? (hi ? B.p1y : p0y) : (hi ? B.p1x : p0x));
+    q.axes = pair == 0 ? (0u | (1u << 2) | (2u << 4)) : (pair == 1 ? (0u | (2u << 2) | (1u << 4)) : (1u | (2u << 2) | (0u << 4)));
+    q.mat = B.mat; q._p = 0;
+    return q;
+}
+
 // boundary.hit() for ConstantMedium (boundary is a Sphere, MovingSphere, Rect or a Boxy list)
 template <class Mem>
 VK_HD bool boundary_t(const DScene &S, const Mem &M, uint32_t ref, V3 o, V3 d, float a, float time, float tmin, float tmax, float &t, uint32_t &item) {
@@ -311,6 +350,12 @@ VK_HD void process_ref(Lane &L, const DScene &S, const Mem &M, uint32_t ref) {
         if (rect_t(S.rects[idx], L.o, L.d, T_MIN, L.T, t)) accept<F, Mem>(L, t, ref, 0.0f);
         return;
     }
+    if ((F & VKF_BOX) && k == DK_BOX) {
+        uint32_t face = 0;
+        DBox B = M.box(idx);
+        if (box_t(B, L.o, L.d, T_MIN, L.T, t, face)) accept<F, Mem>(L, t, ref, vk::bits_f32(face));
+        return;
+    }
     if ((F & VKF_LIST) && k == DK_LIST) {
         uint32_t item;
         if (list_t(S, M, ref, L.o, L.d, L.a, L.time, T_MIN, L.T, t, item)) accept<F, Mem>(L, t, item ^ (ref & DREF_FLIP), 0.0f);
@@ -331,6 +376,8 @@ VK_HD void process_ref(Lane &L, const DScene &S, const Mem &M, uint32_t ref) {
 // finished before the next item is fetched, which is the reference's order.
 VK_HD bool traversing(const Lane &L) { return L.i < L.end || L.pend != 0 || L.cur_inst >= 0; }
 VK_HD bool has_prim_work(const Lane &L) { return L.pend != 0; }
+// Sphere / MovingSphere / Rect tests are ~50 instructions; Boxy, lists, media and instance entry cost several times that
+VK_HD bool prim_is_heavy(uint32_t ref) { uint32_t k = VKD_KIND(ref); return k >= DK_LIST; }
 
 // `on` = this lane has box work.  Written with selects instead of branches: on gfx950 the one
 // scalar unit per CU is what a divergent traversal loop saturates first (every divergent `if`
@@ -398,22 +445,26 @@ VK_HD void face(V3 d, V3 outward, V3 &n, bool &front) {  // hittable.rs:23-30
     n = front ? outward : -outward;
 }
 
+// Rect::hit's record (hittable.rs:240-255)
+VK_HD void rect_record(const DRect &q, V3 o, V3 d, float t, Rec &R) {
+    uint32_t a0 = q.axes & 3u, a1 = (q.axes >> 2) & 3u, a2 = (q.axes >> 4) & 3u;
+    float a = comp(o, a0) + t * comp(d, a0);
+    float b = comp(o, a1) + t * comp(d, a1);
+    R.u = (a - q.c0) / (q.c1 - q.c0);
+    R.v = (b - q.d0) / (q.d1 - q.d0);
+    R.p = o + d * t;
+    V3 outward = v3(a2 == 0 ? 1.0f : 0.0f, a2 == 1 ? 1.0f : 0.0f, a2 == 2 ? 1.0f : 0.0f);
+    face(d, outward, R.n, R.front);
+    R.mat = q.mat;
+}
+
 // record of a Sphere/MovingSphere/Rect hit at t in the ray's own space
 template <class Mem>
 VK_HD void simple_record(const DScene &S, const Mem &M, uint32_t ref, V3 o, V3 d, float time, float t, bool want_uv, Rec &R) {
     uint32_t k = VKD_KIND(ref), idx = VKD_INDEX(ref);
     R.u = 0.0f; R.v = 0.0f;
     if (k == DK_RECT) {
-        const DRect &q = S.rects[idx];
-        uint32_t a0 = q.axes & 3u, a1 = (q.axes >> 2) & 3u, a2 = (q.axes >> 4) & 3u;
-        float a = comp(o, a0) + t * comp(d, a0);
-        float b = comp(o, a1) + t * comp(d, a1);
-        R.u = (a - q.c0) / (q.c1 - q.c0);
-        R.v = (b - q.d0) / (q.d1 - q.d0);
-        R.p = o + d * t;
-        V3 outward = v3(a2 == 0 ? 1.0f : 0.0f, a2 == 1 ? 1.0f : 0.0f, a2 == 2 ? 1.0f : 0.0f);
-        face(d, outward, R.n, R.front);
-        R.mat = q.mat;
+        rect_record(S.rects[idx], o, d, t, R);
     } else {
         V3 c; float r;
         if (k == DK_SPHERE) { DSphere s = M.sphere(idx); c = v3(s.cx, s.cy, s.cz); r = s.r; R.mat = M.smat(idx); }
@@ -451,6 +502,12 @@ VK_HD void build_record(const Lane &L, const DScene &S, const Mem &M, Rec &R) {
                 R.u = B.u; R.v = B.v;
             }
         }
+        if (ref & DREF_FLIP) R.front = !R.front;
+    } else if ((F & VKF_BOX) && k == DK_BOX) {
+        uint32_t f = vk::f32_bits(L.best_aux);
+        DRect q = box_face_rect(M.box(VKD_INDEX(ref)), f);
+        rect_record(q, o, d, L.T, R);
+        if (f & 1u) R.front = !R.front;              // odd sides are FlipFace-wrapped (hittable.rs:327-352)
         if (ref & DREF_FLIP) R.front = !R.front;
     } else {
         bool want_uv = false;
