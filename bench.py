@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override spp (marks the result as non-headline)")
-    ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU sample")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU sample (0 = size it to ~15 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -64,11 +64,19 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VK_BENCH_REHEARSAL=1: run the N-rank code path on ONE GPU (all ranks share device 0, gloo
+    # instead of RCCL, tile slabs staged through host memory) - for checking the multi-process
+    # logic on a single-GPU box; its numbers are not a scaling measurement.
+    rehearsal = os.environ.get("VK_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
 
     scene_name, width, spp, depth, label = WORKLOADS[args.workload]
     if args.spp:
@@ -77,11 +85,11 @@ def main():
     cam = hs.next_camera()
     params = hs.params(width, spp, depth, seed=2, tile_rank=rank, tile_world=world)   # render seed 2
     height = params.height
-    ds = DeviceScene(hs.desc, device=local_rank)         # scene upload: outside the timed region
+    ds = DeviceScene(hs.desc, device=dev_index)          # scene upload: outside the timed region
     info = ds.info()
     fb = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
     full = torch.zeros_like(fb) if (world > 1 and rank == 0) else None
-    gather = FramebufferGather(width, height, rank, world, dev)
+    gather = FramebufferGather(width, height, rank, world, dev, stage_on_cpu=rehearsal)
     stream = torch.cuda.current_stream().cuda_stream
 
     lib = ds._lib
@@ -115,11 +123,17 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    if rehearsal and world > 1 and rank == 0:
+        p1 = hs.params(width, spp, depth, seed=2)
+        ref, _ = ds.render(cam, p1)
+        same = bool((full.cpu().numpy() == ref).all())
+        print(f"rehearsal: gathered {world}-rank image bit-identical to 1-rank render: {same}", file=sys.stderr)
+        assert same
     total_samples = width * height * spp                  # all ranks together, per step
     if rank == 0:
         value = total_samples * args.steps / elapsed / 1e6
@@ -128,12 +142,21 @@ def main():
         import oracle_ffi as O
         cores = os.cpu_count() or 1
         cpu = None
-        cpu_spp = max(1, args.cpu_spp if world == 1 and not args.no_cpu else 1)
         cw = width if args.workload != "C5" else 1024     # C5's 16.7M pixels: sample a quarter-res grid on the CPU
-        pc = hs.params(cw, cpu_spp, depth, seed=2)
+        want_cpu = world == 1 and not args.no_cpu
+        # probe pass (also gives the visit counters); the timed CPU sample is then sized to ~15 s
+        pc = hs.params(cw, 1, depth, seed=2)
         tc0 = time.perf_counter()
         _, cnt = O.render(hs.desc, cam, pc, threads=cores)
         tc = time.perf_counter() - tc0
+        cpu_spp = 1
+        if want_cpu:
+            rate = cnt.samples / tc
+            cpu_spp = args.cpu_spp if args.cpu_spp > 0 else int(min(64, max(2, 15.0 * rate / (cw * pc.height))))
+            pc = hs.params(cw, cpu_spp, depth, seed=2)
+            tc0 = time.perf_counter()
+            _, cnt = O.render(hs.desc, cam, pc, threads=cores)
+            tc = time.perf_counter() - tc0
         c = cnt.as_dict()
         bps = algorithmic_bytes_per_sample(c, spp)
         if world == 1 and not args.no_cpu:
@@ -152,7 +175,8 @@ def main():
         out = {
             "metric": "Msamples/sec (pixels x spp)", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
             "config": {"workload": label if not args.spp else label + f" [spp overridden to {spp}]", "scene_seed": 1, "render_seed": 2,
                        "integrator": "scatter" if hs.integrator else "pdf", "tiles": "8x8 round-robin over ranks",
                        "bvh_items": info.n_items, "scene_in_lds": bool(info.lds_bytes)},

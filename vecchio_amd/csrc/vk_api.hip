@@ -521,11 +521,14 @@ int check_render_args(vk_scene *scene, const vk_camera *cam, const vk_render_par
 // partition), so 1-GPU and N-GPU renders sum every pixel in the same order
 uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
     (void)s;
-    // 256 samples per pixel per unit: 16K lane-paths per wave-unit keeps the end-of-unit tail
-    // (lanes idling while the last long paths finish) near 2 %, and C2 still splits into
-    // 130K units (16K per GPU at 8 GPUs, ~4 per resident wave) for load balance.
-    const uint32_t CHUNK_SPP = 256;
-    uint32_t n = (p->samples_per_pixel + CHUNK_SPP - 1) / CHUNK_SPP;
+    // Samples per pixel per unit.  256 keeps the end-of-unit tail (lanes idling while the last
+    // long paths of a unit finish) near 2 %; small images get smaller chunks so that there are
+    // still ~64K units to balance tiles of very different cost (fog, glass) over ~6K waves.
+    // A function of the image and spp only, never of the tile partition (see above).
+    uint64_t tiles = (uint64_t)((p->width + TILE - 1) / TILE) * ((p->height + TILE - 1) / TILE);
+    uint64_t c = (uint64_t)p->samples_per_pixel * tiles / 65536u;
+    uint32_t chunk_spp = (uint32_t)(c > 256 ? 256 : (c < 32 ? 32 : c));
+    uint32_t n = (p->samples_per_pixel + chunk_spp - 1) / chunk_spp;
     if (n < 1) n = 1;
     return n;
 }

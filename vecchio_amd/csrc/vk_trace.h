@@ -293,8 +293,32 @@ template <uint32_t F, class Mem>
 VK_HD void medium_test(Lane &L, const DScene &S, const Mem &M, uint32_t ref) {
     const DMedium &m = S.media[VKD_INDEX(ref)];
     float t1, t2; uint32_t it;
-    if (!boundary_t(S, M, m.boundary, L.o, L.d, L.a, L.time, -INFINITY, INFINITY, t1, it)) return;
-    if (!boundary_t(S, M, m.boundary, L.o, L.d, L.a, L.time, t1 + 0.0001f, INFINITY, t2, it)) return;
+    uint32_t bk = VKD_KIND(m.boundary);
+    if (bk == DK_SPHERE || bk == DK_MOVING) {
+        // boundary.hit(-inf, inf) then boundary.hit(t1 + 0.0001, inf) on a sphere: both calls solve the
+        // same quadratic (hittable.rs:66-74), so the two roots are computed once; the second call
+        // re-tests the near root against its new tmin and then takes the far one.
+        float cx, cy, cz, r;
+        if (bk == DK_SPHERE) { DSphere s = M.sphere(VKD_INDEX(m.boundary)); cx = s.cx; cy = s.cy; cz = s.cz; r = s.r; }
+        else { const DMoving &mv = S.moving[VKD_INDEX(m.boundary)]; V3 c = moving_center(mv, L.time); cx = c.x; cy = c.y; cz = c.z; r = mv.r; }
+        V3 oc = L.o - v3(cx, cy, cz);
+        float half_b = dot(oc, L.d);
+        float c = length2(oc) - r * r;
+        float disc = half_b * half_b - L.a * c;
+        if (!(disc > 0.0f)) return;
+        float root = sqrtf(disc);
+        float near_t = (-half_b - root) / L.a, far_t = (-half_b + root) / L.a;
+        bool near_ok = -INFINITY < near_t && near_t < INFINITY;
+        bool far_ok = -INFINITY < far_t && far_t < INFINITY;
+        if (near_ok) t1 = near_t; else if (far_ok) t1 = far_t; else return;
+        float tmin2 = t1 + 0.0001f;
+        if (tmin2 < near_t && near_t < INFINITY) t2 = near_t;
+        else if (tmin2 < far_t && far_t < INFINITY) t2 = far_t;
+        else return;
+    } else {
+        if (!boundary_t(S, M, m.boundary, L.o, L.d, L.a, L.time, -INFINITY, INFINITY, t1, it)) return;
+        if (!boundary_t(S, M, m.boundary, L.o, L.d, L.a, L.time, t1 + 0.0001f, INFINITY, t2, it)) return;
+    }
     float e = t1, x = t2;
     if (e < T_MIN) e = T_MIN;
     if (x > L.T) x = L.T;

@@ -27,16 +27,19 @@ class FramebufferGather:
     """Pre-computes the per-rank index sets once; `gather(fb)` moves each rank's tile slab to
     rank 0 with a single torch.distributed.gather and scatters it into the full image."""
 
-    def __init__(self, width, height, rank, world, device):
+    def __init__(self, width, height, rank, world, device, stage_on_cpu=False):
+        """stage_on_cpu: exchange through host tensors (gloo rehearsals: gloo cannot gather GPU tensors)."""
         import torch
         self.torch = torch
+        self.stage_on_cpu = stage_on_cpu
         self.width, self.height, self.rank, self.world = width, height, rank, world
         idx = [tile_pixel_indices(width, height, r, world) for r in range(world)]
         self.slab_len = max(len(i) for i in idx)
         self.own = torch.from_numpy(idx[rank]).to(device)
         self.all_idx = [torch.from_numpy(i).to(device) for i in idx] if rank == 0 else None
-        self.slab = torch.zeros((self.slab_len, 3), dtype=torch.float32, device=device)
-        self.recv = [torch.zeros((self.slab_len, 3), dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
+        xdev = "cpu" if stage_on_cpu else device
+        self.slab = torch.zeros((self.slab_len, 3), dtype=torch.float32, device=xdev)
+        self.recv = [torch.zeros((self.slab_len, 3), dtype=torch.float32, device=xdev) for _ in range(world)] if rank == 0 else None
 
     def gather(self, fb, out=None):
         """fb: (height, width, 3) float32 tensor holding this rank's tiles.  Returns the full image on
@@ -44,7 +47,7 @@ class FramebufferGather:
         import torch.distributed as dist
         flat = fb.view(-1, 3)
         n = self.own.numel()
-        self.slab[:n] = flat.index_select(0, self.own)
+        self.slab[:n] = flat.index_select(0, self.own).to(self.slab.device)
         if self.world == 1:
             if out is None:
                 return fb
@@ -57,5 +60,5 @@ class FramebufferGather:
         ff = full.view(-1, 3)
         for r in range(self.world):
             m = self.all_idx[r].numel()
-            ff.index_copy_(0, self.all_idx[r], self.recv[r][:m])
+            ff.index_copy_(0, self.all_idx[r], self.recv[r][:m].to(ff.device))
         return full
