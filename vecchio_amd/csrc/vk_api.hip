@@ -79,8 +79,8 @@ struct LdsMem {
     __device__ __forceinline__ DItem item(uint32_t i) const {
         uint4 a = items[2 * i], b = items[2 * i + 1];
         DItem n;
-        n.bmin[0] = __uint_as_float(a.x); n.bmin[1] = __uint_as_float(a.y); n.bmin[2] = __uint_as_float(a.z);
-        n.bmax0 = __uint_as_float(a.w); n.bmax1 = __uint_as_float(b.x); n.bmax2 = __uint_as_float(b.y);
+        n.mnx = __uint_as_float(a.x); n.mxx = __uint_as_float(a.y); n.mny = __uint_as_float(a.z); n.mxy = __uint_as_float(a.w);
+        n.mnz = __uint_as_float(b.x); n.mxz = __uint_as_float(b.y);
         n.w0 = b.z; n.w1 = b.w;
         return n;
     }

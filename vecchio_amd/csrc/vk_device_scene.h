@@ -33,9 +33,8 @@ constexpr uint32_t DREF_INDEX = 0x07FFFFFFu;
 #define VKD_MAKE(kind, idx) (((uint32_t)(kind) << 28) | ((uint32_t)(idx) & 0x07FFFFFFu))
 
 struct alignas(16) DItem {      // 32 B: the canonical BVH node record (24 B box + two 4 B links)
-    float bmin[3];
-    float bmax0;                // bmax[0]
-    float bmax1, bmax2;
+    float mnx, mxx, mny, mxy;   // box bounds interleaved per axis (min,max pairs feed packed f32 math)
+    float mnz, mxz;
     uint32_t w0, w1;
 };
 

@@ -232,8 +232,8 @@ struct Builder {
             if (fr.stage == 0) {
                 if (!check_ref(n.left) || !check_ref(n.right)) return false;
                 DItem it; memset(&it, 0, sizeof(it));
-                it.bmin[0] = n.bb_min[0]; it.bmin[1] = n.bb_min[1]; it.bmin[2] = n.bb_min[2];
-                it.bmax0 = n.bb_max[0]; it.bmax1 = n.bb_max[1]; it.bmax2 = n.bb_max[2];
+                it.mnx = n.bb_min[0]; it.mny = n.bb_min[1]; it.mnz = n.bb_min[2];
+                it.mxx = n.bb_max[0]; it.mxy = n.bb_max[1]; it.mxz = n.bb_max[2];
                 uint32_t lk = VK_REF_KIND(n.left), rk = VK_REF_KIND(n.right);
                 uint32_t pos = (uint32_t)L.items.size();
                 if (lk != VK_KIND_BVH && rk != VK_KIND_BVH) {

@@ -241,17 +241,17 @@ VK_HD bool boundary_t(const DScene &S, const Mem &M, uint32_t ref, V3 o, V3 d, f
 VK_HD bool slab_exact(const DItem &n, V3 o, V3 d, float tmin, float tmax) {
     float lo = tmin, hi = tmax;
     {
-        float q0 = (n.bmin[0] - o.x) / d.x, q1 = (n.bmax0 - o.x) / d.x;
+        float q0 = (n.mnx - o.x) / d.x, q1 = (n.mxx - o.x) / d.x;
         lo = fmaxf(fminf(q0, q1), lo); hi = fminf(fmaxf(q0, q1), hi);
         if (hi <= lo) return false;
     }
     {
-        float q0 = (n.bmin[1] - o.y) / d.y, q1 = (n.bmax1 - o.y) / d.y;
+        float q0 = (n.mny - o.y) / d.y, q1 = (n.mxy - o.y) / d.y;
         lo = fmaxf(fminf(q0, q1), lo); hi = fminf(fmaxf(q0, q1), hi);
         if (hi <= lo) return false;
     }
     {
-        float q0 = (n.bmin[2] - o.z) / d.z, q1 = (n.bmax2 - o.z) / d.z;
+        float q0 = (n.mnz - o.z) / d.z, q1 = (n.mxz - o.z) / d.z;
         lo = fmaxf(fminf(q0, q1), lo); hi = fminf(fmaxf(q0, q1), hi);
         if (hi <= lo) return false;
     }
@@ -263,9 +263,9 @@ VK_HD bool slab_exact(const DItem &n, V3 o, V3 d, float tmin, float tmax) {
 // equivalent to one test max(lo..) < min(hi..) because lo only grows and hi only shrinks.
 VK_HD bool slab(const DItem &n, const Lane &L, float tmax) {
     if (!L.exact_only) {
-        float x0 = (n.bmin[0] - L.o.x) * L.inv.x, x1 = (n.bmax0 - L.o.x) * L.inv.x;
-        float y0 = (n.bmin[1] - L.o.y) * L.inv.y, y1 = (n.bmax1 - L.o.y) * L.inv.y;
-        float z0 = (n.bmin[2] - L.o.z) * L.inv.z, z1 = (n.bmax2 - L.o.z) * L.inv.z;
+        float x0 = (n.mnx - L.o.x) * L.inv.x, x1 = (n.mxx - L.o.x) * L.inv.x;
+        float y0 = (n.mny - L.o.y) * L.inv.y, y1 = (n.mxy - L.o.y) * L.inv.y;
+        float z0 = (n.mnz - L.o.z) * L.inv.z, z1 = (n.mxz - L.o.z) * L.inv.z;
         float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));
         float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
         const float EP = 1.000002f;  // >> 2*(3*2^-24)
@@ -419,9 +419,11 @@ VK_HD void box_step(Lane &L, const DScene &S, const Mem &M, bool on) {
     bool inner = (k0 == 0);
     bool prim_item = (k0 == DK_PRIM_ITEM);               // object child beside a BVH child: no box of its own
     // AxisBB::hit decided from reciprocal multiplies (see slab()); same boolean as the reference's
-    float x0 = (n.bmin[0] - L.o.x) * L.inv.x, x1 = (n.bmax0 - L.o.x) * L.inv.x;
-    float y0 = (n.bmin[1] - L.o.y) * L.inv.y, y1 = (n.bmax1 - L.o.y) * L.inv.y;
-    float z0 = (n.bmin[2] - L.o.z) * L.inv.z, z1 = (n.bmax2 - L.o.z) * L.inv.z;
+    // (scalar on purpose: v_pk_add_f32/v_pk_mul_f32 on (min,max) pairs was measured 5 % SLOWER here —
+    // the broadcast operands need register pairs, which costs occupancy)
+    float x0 = (n.mnx - L.o.x) * L.inv.x, x1 = (n.mxx - L.o.x) * L.inv.x;
+    float y0 = (n.mny - L.o.y) * L.inv.y, y1 = (n.mxy - L.o.y) * L.inv.y;
+    float z0 = (n.mnz - L.o.z) * L.inv.z, z1 = (n.mxz - L.o.z) * L.inv.z;
     float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));
     float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), L.T));
     const float EP = 1.000002f;
