@@ -124,8 +124,8 @@ __device__ __forceinline__ typename std::conditional<LDS_SCENE, LdsMem, GlobalMe
 // Cold per-lane path state (throughput, radiance, RNG, pixel/sample ids, world ray) lives in
 // LDS between SHADE phases, SoA by field (word f of lane l at cold[f*64 + l]: conflict-free),
 // so that the box/primitive loops keep only the traversal state in VGPRs.
-constexpr int NCOLD_BASE = 13;      // thr3 acc3 depth key2 ctr pixel sample q
-constexpr int NCOLD_INST = 19;      // + world-space ray (o3 d3) for scenes with instances
+constexpr int NCOLD_BASE = 11;      // thr3 acc3 depth key2 ctr (q | sample << 6)
+constexpr int NCOLD_INST = 17;      // + world-space ray (o3 d3) for scenes with instances
 template <uint32_t F> constexpr int ncold() { return (F & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE; }
 
 template <uint32_t F>
@@ -135,10 +135,10 @@ __device__ __forceinline__ void cold_store(float *c, uint32_t lane, const Lane &
     c[6 * 64 + lane] = __uint_as_float(L.depth);
     c[7 * 64 + lane] = __uint_as_float((uint32_t)L.rng.key); c[8 * 64 + lane] = __uint_as_float((uint32_t)(L.rng.key >> 32));
     c[9 * 64 + lane] = __uint_as_float(L.rng.ctr);
-    c[10 * 64 + lane] = __uint_as_float(L.pixel); c[11 * 64 + lane] = __uint_as_float(L.sample); c[12 * 64 + lane] = __uint_as_float(q);
+    c[10 * 64 + lane] = __uint_as_float(q | (L.sample << 6));   // the pixel is implied by the unit's tile and q
     if (F & VKF_INSTANCE) {
-        c[13 * 64 + lane] = L.wo.x; c[14 * 64 + lane] = L.wo.y; c[15 * 64 + lane] = L.wo.z;
-        c[16 * 64 + lane] = L.wd.x; c[17 * 64 + lane] = L.wd.y; c[18 * 64 + lane] = L.wd.z;
+        c[11 * 64 + lane] = L.wo.x; c[12 * 64 + lane] = L.wo.y; c[13 * 64 + lane] = L.wo.z;
+        c[14 * 64 + lane] = L.wd.x; c[15 * 64 + lane] = L.wd.y; c[16 * 64 + lane] = L.wd.z;
     }
 }
 template <uint32_t F>
@@ -148,10 +148,11 @@ __device__ __forceinline__ void cold_load(const float *c, uint32_t lane, Lane &L
     L.depth = __float_as_uint(c[6 * 64 + lane]);
     L.rng.key = (uint64_t)__float_as_uint(c[7 * 64 + lane]) | ((uint64_t)__float_as_uint(c[8 * 64 + lane]) << 32);
     L.rng.ctr = __float_as_uint(c[9 * 64 + lane]);
-    L.pixel = __float_as_uint(c[10 * 64 + lane]); L.sample = __float_as_uint(c[11 * 64 + lane]); q = __float_as_uint(c[12 * 64 + lane]);
+    uint32_t qs = __float_as_uint(c[10 * 64 + lane]);
+    q = qs & 63u; L.sample = qs >> 6; L.pixel = 0;
     if (F & VKF_INSTANCE) {
-        L.wo = v3(c[13 * 64 + lane], c[14 * 64 + lane], c[15 * 64 + lane]);
-        L.wd = v3(c[16 * 64 + lane], c[17 * 64 + lane], c[18 * 64 + lane]);
+        L.wo = v3(c[11 * 64 + lane], c[12 * 64 + lane], c[13 * 64 + lane]);
+        L.wd = v3(c[14 * 64 + lane], c[15 * 64 + lane], c[16 * 64 + lane]);
     } else {
         L.wo = L.o; L.wd = L.d;       // no instances: the current space IS world space
     }
@@ -159,13 +160,13 @@ __device__ __forceinline__ void cold_load(const float *c, uint32_t lane, Lane &L
 template <uint32_t F>
 __device__ __forceinline__ void cold_load_world_ray(const float *c, uint32_t lane, Lane &L) {
     if (F & VKF_INSTANCE) {
-        L.wo = v3(c[13 * 64 + lane], c[14 * 64 + lane], c[15 * 64 + lane]);
-        L.wd = v3(c[16 * 64 + lane], c[17 * 64 + lane], c[18 * 64 + lane]);
+        L.wo = v3(c[11 * 64 + lane], c[12 * 64 + lane], c[13 * 64 + lane]);
+        L.wd = v3(c[14 * 64 + lane], c[15 * 64 + lane], c[16 * 64 + lane]);
     }
 }
 
 template <uint32_t F, bool LDS_SCENE, int MINW, bool STATS>
-__global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : 768)), MINW) void render_kernel(KArgs A_byval) {
+__global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ? 768 : 1024))), MINW) void render_kernel(KArgs A_byval) {
     (void)A_byval;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : 768)), MINW)
                     cold_load<F>(cold, lane, L, q);
                     if (!shade<F, Mem>(L, S, M, C)) {
                         float4 *dbg = KARG(P, debug);
-                        if (dbg) dbg[(size_t)L.pixel * C.spp + L.sample] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(L.rng.ctr));
+                        if (dbg) dbg[((size_t)(ty + (q >> 3)) * C.width + (tx + (q & 7u))) * C.spp + L.sample] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(L.rng.ctr));
                         if (isfinite(L.acc.x) && isfinite(L.acc.y) && isfinite(L.acc.z)) {   // main.rs:192-194
                             atomicAdd(&acc_lds[q * 3 + 0], L.acc.x);
                             atomicAdd(&acc_lds[q * 3 + 1], L.acc.y);
@@ -429,6 +430,7 @@ struct vk_scene {
     int num_cus = 256;
     uint32_t lds_bytes = 0;    // hot-record bytes staged per workgroup (0 = not LDS resident)
     uint32_t wg_threads = 512; // workgroup size chosen by plan_residency()
+    uint32_t sphere_waves = 6; // waves per SIMD of the sphere-only variant (8 was measured 3 % slower: it spills)
     uint32_t wgs_per_cu = 2;
     bool last_timed = false;
     unsigned long long *phase_stats = nullptr;   // device, 8 counters (diagnostic kernel build)
@@ -469,8 +471,9 @@ size_t per_wave_lds_bytes(uint32_t F) {   // pixel accumulators + cold lane stat
 void plan_residency(vk_scene *s, size_t hot) {
     const size_t pw = per_wave_lds_bytes(pick_variant(s->host.features));
     uint32_t best_waves = 0, best_wg = 0, best_n = 0;
-    uint32_t cap = (pick_variant(s->host.features) == 0u) ? 24 : 16;   // waves per CU the variant's register budget admits
-    const uint32_t max_wg_waves = cap == 24 ? 12 : 16;                       // = the variant's __launch_bounds__ thread limit / 64
+    const bool spheres_only = pick_variant(s->host.features) == 0u;
+    uint32_t cap = spheres_only ? 4 * s->sphere_waves : 16;                  // waves per CU the variant's register budget admits
+    const uint32_t max_wg_waves = (spheres_only && s->sphere_waves == 6) ? 12 : 16;   // = the variant's __launch_bounds__ thread limit / 64
     if (const char *e = getenv("VK_MAX_WAVES_PER_CU")) { int v = atoi(e); if (v >= 4 && (uint32_t)v < cap) cap = (uint32_t)v; }   // diagnostics: lower the occupancy
     for (uint32_t n_wg = 1; n_wg <= 4; n_wg++) {
         size_t budget = LDS_PER_CU / n_wg;
@@ -486,10 +489,10 @@ void plan_residency(vk_scene *s, size_t hot) {
     }
 }
 
-template <uint32_t F>
+template <uint32_t F, int MINW_SPHERES = 6>
 int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st) {
     // register budget: the sphere-only kernels fit 80 VGPRs (6 waves per SIMD, 24 per CU), the others are held to 128 (4 per SIMD)
-    constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? 6 : 4;
+    constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? MINW_SPHERES : 4;
     if (lds) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<F, true, MINW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL((render_kernel<F, true, MINW, false>), grid, dim3(s->wg_threads), shmem, st, A);
