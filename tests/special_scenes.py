@@ -45,6 +45,10 @@ def nested_transforms():
     inner = d.big_box(d.sphere((0, 0, 0), 0.7, glass), d.translate(d.sphere((0, 0, 0), 0.5, metal), (0, 1.4, 0)))
     refs.append(d.translate(d.rotate(inner, 1, 40.0), (7, 1.0, 6)))
     refs.append(Desc.flip(d.translate(d.sphere((0, 0, 0), 0.6, d.lambertian(0.9, 0.5, 0.1)), (2, 0.6, 8))))
+    # a Vec that is NOT the Boxy pattern (generic list path: first-wins ties, mixed primitive kinds)
+    grey = d.lambertian(0.5, 0.5, 0.5)
+    refs.append(d.list_([d.sphere((8, 3, 2), 0.8, grey), d.xy_rect(7, 9, 2, 4, 2.0, metal), Desc.flip(d.xy_rect(7, 9, 2, 4, 2.0, grey)),
+                         d.moving_sphere((8, 5, 2), (8.5, 5, 2), 0.0, 1.0, 0.5, grey)]))
     world = _bvh_chain(d, refs)
     desc = d.finish(world, lights)
     cam = camera((5, 5, -12), (5, 5, 0), vfov=40.0)

@@ -75,3 +75,27 @@ def test_pdf_integrator_needs_lights(emu):
     s = d.sphere((0, 0, 0), 1.0, d.lambertian(0.5, 0.5, 0.5))
     st, msg = emu_status(emu, d.finish(s, []), cam, params(8, 8, 1, integrator=ffi.VK_INTEGRATOR_PDF))
     assert st == ffi.VK_ERR_UNSUPPORTED and "lights" in msg   # Vec::random would unwrap None (hittable.rs:431)
+
+
+def test_boxy_lists_become_compact_boxes(emu):
+    """The lineariser stores an exact Boxy::new pattern as a 32-byte DBox (feature bit 0x100) and anything
+    else as a generic list (0x4); both must render like the oracle (covered by the parity tests)."""
+    cam = camera((5, 5, -12), (1, 1, 1))
+    p = params(8, 8, 1)
+    d = Desc()
+    m = d.lambertian(0.5, 0.5, 0.5)
+    box = d.boxy((0, 0, 0), (2, 3, 4), m)
+    lm = d.light(5, 5, 5)
+    ls = d.xz_rect(0, 1, 0, 1, 9, lm)
+    desc = d.finish(d.big_box(box, Desc.flip(ls)), [ls])
+    _, _, _, info = emu.render_samples(desc, cam, p)
+    assert info[3] & 0x100 and not (info[3] & 0x4)
+    d = Desc()
+    m = d.lambertian(0.5, 0.5, 0.5)
+    box = d.boxy((0, 0, 0), (2, 3, 4), m)
+    d.rects[2].k = 2.5                                  # no longer the canonical pattern: stays a list
+    lm = d.light(5, 5, 5)
+    ls = d.xz_rect(0, 1, 0, 1, 9, lm)
+    desc = d.finish(d.big_box(box, Desc.flip(ls)), [ls])
+    _, _, _, info = emu.render_samples(desc, cam, p)
+    assert info[3] & 0x4 and not (info[3] & 0x100)

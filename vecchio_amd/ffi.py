@@ -138,7 +138,8 @@ def load_host_lib():
         return _host
     path = os.path.join(LIB_DIR, "libvecchio_host.so")
     if not os.path.exists(path):
-        raise RuntimeError(f"{path} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        from . import build
+        build.build_host()          # a fresh checkout: compile (g++), never substitute anything
     lib = C.CDLL(path)
     lib.vkh_scene_build.restype = C.c_void_p
     lib.vkh_scene_build.argtypes = [C.c_char_p, C.c_uint64]
@@ -174,8 +175,12 @@ def load_device_lib():
         return _dev
     path = device_lib_path()
     if not os.path.exists(path):
-        raise RuntimeError(f"{path} missing: the HIP extension is not built (no CPU fallback exists); "
-                           "run `python -c 'import __graft_entry__ as g; g.build()'`")
+        from . import build
+        try:
+            build.build_device()    # a fresh checkout: compile with hipcc; there is no CPU fallback to use instead
+        except Exception as e:
+            raise RuntimeError(f"{path} missing and hipcc could not build it ({e}); the HIP extension is required "
+                               "(no CPU fallback exists)") from e
     lib = C.CDLL(path)
     lib.vk_abi_version.restype = C.c_int
     lib.vk_device_count.restype = C.c_int
