@@ -46,6 +46,7 @@ int fail(int code, const std::string &m) { g_err = m; return code; }
 constexpr int MAX_WG_THREADS = 1024;   // 16 waves = 4 per SIMD: the register budget (<= 128 VGPRs) every variant is held to
 constexpr size_t LDS_PER_CU = 160 * 1024;
 constexpr int TILE = 8;   // 8x8 pixels = one wave
+constexpr int BOX_UNROLL = 4;   // box steps between two exit tests of the BOX loop
 
 struct KArgs {
     DScene S;
@@ -256,13 +257,17 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 if (STATS) st_t0 = clock64();
                 cold_load_world_ray<F>(cold, lane, L);
                 const uint32_t live = n_box + n_heavy + n_light + n_sn;   // lanes only change state here, none appear or vanish
+                // steps between two exit tests (compile time: a run-time trip count costs 4-13 %): 4, but 2 for
+                // the Rect/Boxy/instance variant, whose scenes are toy trees (Cornell: 7 items) where most lanes
+                // leave the BOX state within a step or two
+                constexpr int UNROLL = ((F & VKF_ALL_SCENE) == (VKF_RECT | VKF_LIST | VKF_INSTANCE | VKF_BOX)) ? 2 : BOX_UNROLL;
                 for (;;) {
-                    if (STATS) { st_box_steps += 2; st_box_lanes += __popcll(__ballot(is_box)); }
-                    box_step<F, Mem>(L, S, M, is_box);
-                    is_box = active && !has_prim_work(L) && traversing(L);
-                    if (STATS) st_box_lanes += __popcll(__ballot(is_box));
-                    box_step<F, Mem>(L, S, M, is_box);
-                    is_box = active && !has_prim_work(L) && traversing(L);
+#pragma unroll
+                    for (int u = 0; u < UNROLL; u++) {
+                        if (STATS) { st_box_steps += 1; st_box_lanes += __popcll(__ballot(is_box)); }
+                        box_step<F, Mem>(L, S, M, is_box);
+                        is_box = active && !has_prim_work(L) && traversing(L);
+                    }
                     uint32_t nb = (uint32_t)__popcll(__ballot(is_box));
                     uint32_t np = (uint32_t)__popcll(__ballot(active && has_prim_work(L)));
                     uint32_t ns = live - nb - np;

@@ -9,8 +9,9 @@
 //               INNER  {bbox, w0 = skip index (kind nibble 0), w1 = 0}
 //                      box hit -> next item (= left subtree); box miss -> items[w0]
 //               LEAF   {bbox, w0 = dref A, w1 = dref B or 0}   (both children are objects)
-//               PRIM   {unused bbox, w0 = 0xF0000000, w1 = dref} (an object child next to a
-//                      BVH child, e.g. world leaves of final_scene, scene.rs:760-769)
+//               an object child next to a BVH child (e.g. the world leaves of final_scene,
+//               scene.rs:760-769) has no box of its own in the reference: it becomes a LEAF
+//               {box = (-3e38, 3e38)^3 (always hit), w0 = dref, w1 = 0}
 //   spheres[] float4 {cx,cy,cz,r} + sphere_mat[]      (SoA-by-type primitive buffers)
 //   moving[], rects[], lists[]+list_refs[], media[], instances[] (transform chains)
 //   materials[], textures[], images, perlin tables, lights[]

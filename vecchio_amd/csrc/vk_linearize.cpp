@@ -216,6 +216,14 @@ struct Builder {
         }
     }
 
+    // an object that is a direct BVH child beside a BVH sibling has no box test of its own in the
+    // reference: a leaf whose box every ray hits (decided on the fast path, no special case in the kernel)
+    static DItem always_hit_leaf() {
+        DItem it; memset(&it, 0, sizeof(it));
+        it.mnx = it.mny = it.mnz = -3.0e38f; it.mxx = it.mxy = it.mxz = 3.0e38f;
+        return it;
+    }
+
     static bool draw_free(uint32_t dref) { uint32_t k = VKD_KIND(dref); return k == DK_SPHERE || k == DK_MOVING || k == DK_RECT || k == DK_LIST || k == DK_BOX; }
 
     // pre-order emission of one BVH (accel.rs:58-83 order: box, left, right); iterative to
@@ -262,12 +270,10 @@ struct Builder {
                     st.push_back(nf);   // (fr is invalid after this)
                 } else {
                     uint32_t pos = (uint32_t)L.items.size();
-                    DItem it; memset(&it, 0, sizeof(it));
-                    it.w0 = VKD_MAKE(DK_PRIM_ITEM, 0);
-                    L.items.push_back(it);
+                    L.items.push_back(always_hit_leaf());
                     uint32_t a;
                     if (!convert_object(child, fr.flip, inst, a)) return false;
-                    L.items[pos].w1 = a;
+                    L.items[pos].w0 = a;
                     set_home(a, pos + 1, 0);
                     L.n_prims += 1;
                 }
@@ -373,12 +379,10 @@ struct Builder {
         if (VK_REF_KIND(d->world) == VK_KIND_BVH) {
             if (!emit_bvh(VK_REF_INDEX(d->world), (d->world & VK_REF_FLIP) ? DREF_FLIP : 0u, -1)) return false;
         } else {
-            DItem it; memset(&it, 0, sizeof(it));
-            it.w0 = VKD_MAKE(DK_PRIM_ITEM, 0);
-            L.items.push_back(it);
+            L.items.push_back(always_hit_leaf());
             uint32_t a;
             if (!convert_object(d->world, 0, -1, a)) return false;
-            L.items[0].w1 = a;
+            L.items[0].w0 = a;
             set_home(a, 1, 0);
             L.n_prims = 1;
         }

@@ -66,7 +66,7 @@ struct GlobalMem {
 struct Lane {
     // current-space ray (object space while inside an instance)
     V3 o, d; float time;
-    V3 inv; float a; uint32_t exact_only;
+    V3 inv; float a; float xnan;   // xnan: 0, or NaN when the reciprocal-multiply box test must not be trusted
     V3 wo, wd;                 // world-space ray of this segment
     // traversal cursor
     uint32_t i, end, pend, pend2; int32_t cur_inst;
@@ -85,7 +85,7 @@ VK_HD void set_space(Lane &L, V3 o, V3 d) {
     float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
     // reciprocal-multiply slab test is only trusted when 1/d is a full-precision normal number
     bool ok = ax > 1e-30f && ax < 1e30f && ay > 1e-30f && ay < 1e30f && az > 1e-30f && az < 1e30f;
-    L.exact_only = ok ? 0u : 1u;
+    L.xnan = ok ? 0.0f : vk::bits_f32(0x7FC00000u);
 }
 
 // ------------------------------------------------------------------ instance transforms (hittable.rs:507-524,579-624,676-713,765-802)
@@ -257,24 +257,6 @@ VK_HD bool slab_exact(const DItem &n, V3 o, V3 d, float tmin, float tmax) {
     }
     return true;
 }
-// Same boolean as slab_exact, decided from reciprocal multiplies when the margin is clear:
-// both forms compute fl(b-o) identically; q~ = fl(fl(b-o)*fl(1/d)) differs from the
-// reference's fl(fl(b-o)/d) by < 3*2^-24 relative, and the three per-axis early-outs are
-// equivalent to one test max(lo..) < min(hi..) because lo only grows and hi only shrinks.
-VK_HD bool slab(const DItem &n, const Lane &L, float tmax) {
-    if (!L.exact_only) {
-        float x0 = (n.mnx - L.o.x) * L.inv.x, x1 = (n.mxx - L.o.x) * L.inv.x;
-        float y0 = (n.mny - L.o.y) * L.inv.y, y1 = (n.mxy - L.o.y) * L.inv.y;
-        float z0 = (n.mnz - L.o.z) * L.inv.z, z1 = (n.mxz - L.o.z) * L.inv.z;
-        float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));
-        float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
-        const float EP = 1.000002f;  // >> 2*(3*2^-24)
-        if (hi > lo * EP) return true;      // lo >= T_MIN > 0
-        if (hi * EP < lo) return false;     // also covers hi <= 0
-    }
-    return slab_exact(n, L.o, L.d, T_MIN, tmax);  // NaN/inf or within rounding distance: reference arithmetic
-}
-
 // ------------------------------------------------------------------ traversal
 VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time) {
     L.wo = o; L.wd = d; L.time = time;
@@ -405,8 +387,10 @@ VK_HD bool prim_is_heavy(uint32_t ref) { uint32_t k = VKD_KIND(ref); return k >=
 
 // `on` = this lane has box work.  Written with selects instead of branches: on gfx950 the one
 // scalar unit per CU is what a divergent traversal loop saturates first (every divergent `if`
-// costs s_and_saveexec / s_cbranch / s_or), so the whole wave runs the step with full EXEC and
-// lanes that are not `on` (or are past their range) redo item 0 and discard the result.
+// costs s_and_saveexec / s_cbranch / s_or, every boolean combination an s_and/s_or), so the
+// whole wave runs the step with full EXEC, lanes that are not `on` (or are past their range)
+// redo item 0 and discard the result, and the only branch is the rare exact fallback, decided
+// by ONE float compare.
 template <uint32_t F, class Mem>
 VK_HD void box_step(Lane &L, const DScene &S, const Mem &M, bool on) {
     bool at_end = L.i >= L.end;
@@ -415,31 +399,30 @@ VK_HD void box_step(Lane &L, const DScene &S, const Mem &M, bool on) {
     }
     bool go = on && !at_end;
     DItem n = M.item(go ? L.i : 0u);
-    uint32_t k0 = n.w0 >> 28;
-    bool inner = (k0 == 0);
-    bool prim_item = (k0 == DK_PRIM_ITEM);               // object child beside a BVH child: no box of its own
-    // AxisBB::hit decided from reciprocal multiplies (see slab()); same boolean as the reference's
-    // (scalar on purpose: v_pk_add_f32/v_pk_mul_f32 on (min,max) pairs was measured 5 % SLOWER here —
+    // AxisBB::hit decided from reciprocal multiplies; same boolean as the reference's (see slab_exact):
+    // both forms compute fl(b-o) identically and q~ = fl(fl(b-o)*fl(1/d)) differs from the reference's
+    // fl(fl(b-o)/d) by < 3*2^-24 relative, so a margin of 2e-6 on either side is decisive; the three
+    // per-axis early-outs equal one test max(lo..) < min(hi..) because lo only grows and hi only shrinks.
+    // (scalar on purpose: v_pk_add_f32/v_pk_mul_f32 on (min,max) pairs was measured 5 % SLOWER —
     // the broadcast operands need register pairs, which costs occupancy)
     float x0 = (n.mnx - L.o.x) * L.inv.x, x1 = (n.mxx - L.o.x) * L.inv.x;
     float y0 = (n.mny - L.o.y) * L.inv.y, y1 = (n.mxy - L.o.y) * L.inv.y;
     float z0 = (n.mnz - L.o.z) * L.inv.z, z1 = (n.mxz - L.o.z) * L.inv.z;
-    float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));
-    float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), L.T));
+    float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));   // >= T_MIN > 0, never NaN
+    float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), L.T));    // <= T, never NaN
     const float EP = 1.000002f;
-    bool hit_safe = hi > lo * EP;
-    bool miss_safe = hi * EP < lo;
-    bool h = hit_safe;
-    if (go && !prim_item && (L.exact_only != 0u || !(hit_safe || miss_safe)))
-        h = slab_exact(n, L.o, L.d, T_MIN, L.T);         // within rounding distance / NaN / inf: the reference's divisions
-    h = h || prim_item;
-    uint32_t next_i = inner ? (h ? L.i + 1u : n.w0) : L.i + 1u;   // inner: hit -> left subtree, miss -> skip link
-    bool leaf_hit = h && !inner;
-    uint32_t p1 = leaf_hit ? (prim_item ? n.w1 : n.w0) : 0u;     // leaf: left object first ...
-    uint32_t p2 = (leaf_hit && !prim_item) ? n.w1 : 0u;          // ... then the right one
+    float miss_margin = lo - hi * EP;     // > 0: certainly a miss (also when hi <= 0)
+    float hit_margin = hi - lo * EP;      // > 0: certainly a hit; the two cannot both be positive
+    bool h = hit_margin > 0.0f;
+    // xnan is NaN for rays whose 1/d is not a full-precision normal number: forces the fallback
+    if (!(fmaxf(miss_margin, hit_margin) + L.xnan > 0.0f))
+        h = slab_exact(n, L.o, L.d, T_MIN, L.T);         // within rounding distance: the reference's divisions
+    bool inner = (n.w0 >> 28) == 0u;
+    bool leaf_hit = h && !inner;                          // leaf: left object first, then the right one
+    uint32_t next_i = (inner && !h) ? n.w0 : L.i + 1u;    // inner: hit -> left subtree, miss -> skip link
     L.i = go ? next_i : L.i;
-    L.pend = go ? p1 : L.pend;
-    L.pend2 = go ? p2 : L.pend2;
+    L.pend = go ? (leaf_hit ? n.w0 : 0u) : L.pend;
+    L.pend2 = go ? (leaf_hit ? n.w1 : 0u) : L.pend2;
 }
 
 template <uint32_t F, class Mem>
