@@ -65,7 +65,9 @@ struct KArgs {
 
 // LDS-resident hot records
 struct LdsMem {
-    const uint4 *items;      // 2 x uint4 per item
+    const uint4 *items;      // first halves of all items (x/y bounds) ...
+    const uint4 *items_hi;   // ... then the second halves (z bounds, w0, w1): 16-byte stride per array gives a
+                             // ds_read_b128 16 bank slots instead of the 8 a 32-byte stride leaves it
     const float4 *spheres;
     const uint4 *boxes;      // 2 x uint4 per DBox
     const uint32_t *sphere_mat;
@@ -78,7 +80,7 @@ struct LdsMem {
         return o;
     }
     __device__ __forceinline__ DItem item(uint32_t i) const {
-        uint4 a = items[2 * i], b = items[2 * i + 1];
+        uint4 a = items[i], b = items_hi[i];
         DItem n;
         n.mnx = __uint_as_float(a.x); n.mxx = __uint_as_float(a.y); n.mny = __uint_as_float(a.z); n.mxy = __uint_as_float(a.w);
         n.mnz = __uint_as_float(b.x); n.mxz = __uint_as_float(b.y);
@@ -114,7 +116,7 @@ template <uint32_t F, bool LDS_SCENE>
 __device__ __forceinline__ typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type make_mem(const DScene &S, uint32_t lds_items) {
     typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type M;
     if constexpr (LDS_SCENE) {
-        M.items = smem; M.spheres = reinterpret_cast<const float4 *>(smem + 2u * lds_items);
+        M.items = smem; M.items_hi = smem + lds_items; M.spheres = reinterpret_cast<const float4 *>(smem + 2u * lds_items);
         M.boxes = smem + 2u * lds_items + S.n_spheres; M.sphere_mat = S.sphere_mat;
     } else {
         M.items = S.items; M.spheres = S.spheres; M.sphere_mat = S.sphere_mat; M.boxes = S.boxes;
@@ -166,6 +168,9 @@ __device__ __forceinline__ void cold_load_world_ray(const float *c, uint32_t lan
     }
 }
 
+// number of lanes of the wave for which p holds (v_cmp -> s_bcnt1, no VGPR round trip)
+__device__ __forceinline__ uint32_t lanes_with(bool p) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
+
 template <uint32_t F, bool LDS_SCENE, int MINW, bool STATS>
 __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ? 768 : 1024))), MINW) void render_kernel(KArgs A_byval) {
     (void)A_byval;
@@ -190,7 +195,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
         cold = dyn + (blockDim.x >> 6) * (64 * 3) + wave * (64 * ncold<F>());
         if (LDS_SCENE) {
             const uint4 *gi = reinterpret_cast<const uint4 *>(KARG(P, S.items));
-            for (uint32_t k = threadIdx.x; k < 2u * lds_items; k += blockDim.x) smem[k] = gi[k];
+            for (uint32_t k = threadIdx.x; k < 2u * lds_items; k += blockDim.x) smem[(k >> 1) + ((k & 1u) ? lds_items : 0u)] = gi[k];
             const uint4 *gs = reinterpret_cast<const uint4 *>(KARG(P, S.spheres));
             for (uint32_t k = threadIdx.x; k < lds_spheres; k += blockDim.x) smem[2u * lds_items + k] = gs[k];
             const uint4 *gb = reinterpret_cast<const uint4 *>(KARG(P, S.boxes));
@@ -241,12 +246,12 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             // entry several times that): scheduled separately so cheap tests never pay for heavy ones
             const bool HAS_HEAVY = (F & (VKF_LIST | VKF_MEDIUM | VKF_INSTANCE | VKF_BOX)) != 0;
             bool is_heavy = HAS_HEAVY && is_prim && prim_is_heavy(L.pend);
-            uint32_t n_box = (uint32_t)__popcll(__ballot(is_box));
-            uint32_t n_heavy = HAS_HEAVY ? (uint32_t)__popcll(__ballot(is_heavy)) : 0u;
-            uint32_t n_light = (uint32_t)__popcll(__ballot(is_prim && !is_heavy));
+            uint32_t n_box = lanes_with(is_box);
+            uint32_t n_heavy = HAS_HEAVY ? lanes_with(is_heavy) : 0u;
+            uint32_t n_light = lanes_with(is_prim && !is_heavy);
             if (n_heavy > n_light) { is_prim = is_heavy; } else { is_prim = is_prim && !is_heavy; }
             uint32_t n_prim = n_heavy > n_light ? n_heavy : n_light;
-            uint32_t n_sn = (uint32_t)__popcll(__ballot(is_shade || need));
+            uint32_t n_sn = lanes_with(is_shade || need);
             if ((n_box | n_prim | n_sn) == 0) break;
             if (STATS) st_sched++;
             if (n_box >= n_prim && n_box >= n_sn) {
@@ -264,12 +269,12 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 for (;;) {
 #pragma unroll
                     for (int u = 0; u < UNROLL; u++) {
-                        if (STATS) { st_box_steps += 1; st_box_lanes += __popcll(__ballot(is_box)); }
+                        if (STATS) { st_box_steps += 1; st_box_lanes += lanes_with(is_box); }
                         box_step<F, Mem>(L, S, M, is_box);
                         is_box = active && !has_prim_work(L) && traversing(L);
                     }
-                    uint32_t nb = (uint32_t)__popcll(__ballot(is_box));
-                    uint32_t np = (uint32_t)__popcll(__ballot(active && has_prim_work(L)));
+                    uint32_t nb = lanes_with(is_box);
+                    uint32_t np = lanes_with(active && has_prim_work(L));
                     uint32_t ns = live - nb - np;
                     if (nb == 0 || nb < np || nb < ns) break;          // another state now has more lanes parked than are stepping
                 }
@@ -312,7 +317,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                         need = true;
                     }
                 }
-                unsigned long long need_mask = __ballot(need);
+                unsigned long long need_mask = __builtin_amdgcn_ballot_w64(need);
                 if (need_mask) {
                     uint32_t rank = __popcll(need_mask & ((1ull << lane) - 1ull));
                     if (need) {
