@@ -164,11 +164,23 @@ def main():
                    "sample": f"{cw}x{pc.height} px x {cpu_spp} spp = {c['samples']} samples of the same scene/seed/depth, "
                              f"{tc:.1f} s, oracle (recursive CPU restatement) on {cores} threads"}
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else None
+        # measured HBM traffic per launch: PMC counters cannot be collected from inside this process, so the
+        # figure comes from the committed rocprofv3 passes of this same command (profiles/, tests/prof_r01.sh):
+        # WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950: FETCH_SIZE counts half the bytes of wide reads -> upper bound)
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "r01", f"{args.workload.lower()}_pmc_summary.json")
+        if world == 1 and not args.spp and os.path.exists(prof):
+            try:
+                d = json.load(open(prof))["derived"]
+                traffic = float(d["hbm_write_bytes_per_dispatch"] + d["hbm_read_bytes_per_dispatch"]["with_gfx950_x2_correction_upper_bound"])
+            except Exception:
+                traffic = None
         roof = None
         if k_ms:
             achieved = bps * local_samples / (k_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "traffic_note": "HBM bytes per launch from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command (profiles/r01/), not re-measured in this run",
                     "algorithmic_bytes_per_sample": round(bps, 1), "kernel_ms": round(k_ms, 3),
                     "note": "algorithmic bytes (SURVEY 8d record sizes x oracle visit counts); the scene is LDS/L2 resident, "
                             "so measured HBM traffic is far below this (see profiles/)"}

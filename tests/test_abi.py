@@ -72,7 +72,7 @@ def test_product_does_not_reference_oracle():
         for f in files:
             if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".rs")):
                 txt = open(os.path.join(base, f), errors="ignore").read()
-                if re.search(r'#include\s*"[^"\n]*(oracle|emu)|import\s+(oracle|emu)|liboracle|libemu|dlopen', txt):
+                if re.search(r'#include\s*"[^"\n]*(oracle|emu)|import\s+(oracle|emu)|liboracle|libemu|dlopen\([^)\n]*(oracle|emu)', txt):
                     if f != "build.py":       # build.py only COMPILES the checker (allowed: build() builds it)
                         bad.append(os.path.join(base, f))
     assert not bad, bad

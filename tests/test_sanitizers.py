@@ -1,0 +1,18 @@
+"""Host AddressSanitizer + UBSan over the oracle and the C++ host mirror (scene builders, BVHNode::new,
+flatten).  CPU only: GPU ASan / XNACK are not available on this pool."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_oracle_and_host_under_asan_ubsan(tmp_path):
+    exe = tmp_path / "asan_check"
+    srcs = [os.path.join(ROOT, "oracle", "asan_check.cpp"), os.path.join(ROOT, "oracle", "oracle.cpp")] + \
+           [os.path.join(ROOT, "vecchio_amd", "host", f) for f in ("host.cpp", "scene.cpp", "host_api.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-o", str(exe)] + srcs + ["-lpthread"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("samples") == 6
