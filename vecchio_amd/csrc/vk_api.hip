@@ -495,7 +495,7 @@ void plan_residency(vk_scene *s, size_t hot) {
     if (best_waves >= 6) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = best_wg * 64; s->wgs_per_cu = best_n;
     } else {
-        s->lds_bytes = 0; s->wg_threads = 512; s->wgs_per_cu = cap / 8;
+        s->lds_bytes = 0; s->wg_threads = 512; s->wgs_per_cu = cap / 8;   // 24 (sphere-only) or 16 waves per CU
     }
 }
 
@@ -503,6 +503,9 @@ template <uint32_t F, int MINW_SPHERES = 6>
 int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st) {
     // register budget: the sphere-only kernels fit 80 VGPRs (6 waves per SIMD, 24 per CU), the others are held to 128 (4 per SIMD)
     constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? MINW_SPHERES : 4;
+    // (global-memory traversal — C5, 33 MB of items — was also tried at 8 waves per SIMD / 64 VGPRs: 8 % slower.
+    // It is bound by the L2-miss path: every box step gathers a 32-byte item but moves a 128-byte line,
+    // ~3.5 TB/s of lines from the Infinity Cache at 21 Msamples/s; more waves in flight do not help.)
     if (lds) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<F, true, MINW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL((render_kernel<F, true, MINW, false>), grid, dim3(s->wg_threads), shmem, st, A);
@@ -534,13 +537,17 @@ int check_render_args(vk_scene *scene, const vk_camera *cam, const vk_render_par
 // partition), so 1-GPU and N-GPU renders sum every pixel in the same order
 uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
     (void)s;
-    // Samples per pixel per unit.  256 keeps the end-of-unit tail (lanes idling while the last
-    // long paths of a unit finish) near 2 %; small images get smaller chunks so that there are
-    // still ~64K units to balance tiles of very different cost (fog, glass) over ~6K waves.
+    // Samples per pixel per unit: large enough that the end-of-unit tail (lanes idling while the last long
+    // paths of a unit finish) stays small, small enough that tiles of very different cost (fog, glass,
+    // grazing rays over 1M spheres) are spread over many waves; small images get smaller chunks so that
+    // there are still ~64K units for ~6K waves.
     // A function of the image and spp only, never of the tile partition (see above).
     uint64_t tiles = (uint64_t)((p->width + TILE - 1) / TILE) * ((p->height + TILE - 1) / TILE);
     uint64_t c = (uint64_t)p->samples_per_pixel * tiles / 65536u;
-    uint32_t chunk_spp = (uint32_t)(c > 256 ? 256 : (c < 32 ? 32 : c));
+    uint32_t cap = 64;    // measured on C2: 64..128 samples per pixel per unit is the optimum (256: -3 %, 32: -5 %)
+    if (const char *e = getenv("VK_CHUNK_CAP")) { int v = atoi(e); if (v >= 1) cap = (uint32_t)v; }   // diagnostics
+    uint32_t lo = cap < 32 ? cap : 32;
+    uint32_t chunk_spp = (uint32_t)(c > cap ? cap : (c < lo ? lo : c));
     uint32_t n = (p->samples_per_pixel + chunk_spp - 1) / chunk_spp;
     if (n < 1) n = 1;
     return n;
