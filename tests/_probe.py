@@ -1,9 +1,17 @@
-import sys, os, time
+import sys, os, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from vecchio_amd import HostScene, DeviceScene
-hs = HostScene("stress_spheres:500", 1); cam = hs.next_camera()
-ds = DeviceScene(hs.desc)
-for w, spp in ((1024, 128),):
-    p = hs.params(w, spp, 50)
-    img, st = ds.render(cam, p)
-    print(f"waves={os.environ.get('VK_GLOBAL_WAVES')} {w}x{p.height}x{spp}: {st.samples/st.kernel_ms/1e3:.2f} Msamples/s ({st.kernel_ms:.0f} ms)", flush=True)
+from vecchio_amd import HostScene, DeviceScene, ffi
+lib = ffi.load_device_lib()
+lib.vk_debug_phase_stats.restype = C.c_int
+lib.vk_debug_phase_stats.argtypes = [C.c_void_p, C.POINTER(ffi.Camera), C.POINTER(ffi.RenderParams), C.POINTER(C.c_uint64 * 16)]
+for name, w, spp in (("final_scene", 800, 256), ("random_spheres_iow", 1920, 128)):
+    hs = HostScene(name, 1); cam = hs.next_camera(); ds = DeviceScene(hs.desc); p = hs.params(w, spp, 50)
+    ds.render(cam, p); img, st = ds.render(cam, p)
+    out = (C.c_uint64 * 16)()
+    rc = lib.vk_debug_phase_stats(ds._h, C.byref(cam), C.byref(p), C.byref(out))
+    v = list(out); ns = p.width * p.height * p.samples_per_pixel
+    print(f"{name}: {st.samples/st.kernel_ms/1e3:.1f} Msamples/s rc={rc}")
+    if rc == 0:
+        tot = max(1, v[12])
+        print(f"   per sample: box wave-steps {v[0]/ns:.3f} (fill {v[1]/max(1,v[0])/64:.3f}), prim phases {v[2]/ns:.3f} (heavy {v[7]/ns:.3f}, fill {v[3]/max(1,v[2])/64:.3f}), shade phases {v[4]/ns:.3f} (fill {v[5]/max(1,v[4])/64:.3f}) rounds {v[6]/ns:.3f}")
+        print(f"   wave clocks: box {v[8]/tot:.3f} light {v[9]/tot:.3f} heavy {v[10]/tot:.3f} shade {v[11]/tot:.3f} | clocks per: box step {v[8]/max(1,v[0]):.0f}, light prim {v[9]/max(1,v[2]-v[7]):.0f}, heavy prim {v[10]/max(1,v[7]):.0f}, shade phase {v[11]/max(1,v[4]):.0f}", flush=True)

@@ -521,7 +521,7 @@ int check_render_args(vk_scene *scene, const vk_camera *cam, const vk_render_par
     if (!scene || !cam || !p) return fail(VK_ERR_BAD_ARG, "null argument");
     if (p->width < 2 || p->height < 2) return fail(VK_ERR_BAD_ARG, "width and height must be >= 2 (u,v divide by width-1/height-1, main.rs:187-188)");
     if ((uint64_t)p->width * p->height > (1ull << 31) / 3) return fail(VK_ERR_BAD_ARG, "image too large");
-    if (p->samples_per_pixel == 0) return fail(VK_ERR_BAD_ARG, "samples_per_pixel must be > 0");
+    if (p->samples_per_pixel == 0 || p->samples_per_pixel > (1u << 26)) return fail(VK_ERR_BAD_ARG, "samples_per_pixel must be in 1..2^26");
     if (!(cam->time0 < cam->time1)) return fail(VK_ERR_BAD_ARG, "camera time0 >= time1 (gen_range panics, main.rs:118)");
     if (p->integrator > VK_INTEGRATOR_SCATTER || p->background > VK_BACKGROUND_SKY) return fail(VK_ERR_BAD_ARG, "bad integrator/background");
     uint32_t world = p->tile_world ? p->tile_world : 1;

@@ -396,6 +396,10 @@ struct Builder {
             if (!check_ref(r)) return false;
             uint32_t k = VK_REF_KIND(r);
             uint32_t out = 0;   // kinds without pdf_value/random impls behave as the trait defaults
+            if (k == VK_KIND_RECT && !(r & VK_REF_FLIP)) {
+                const vk_rect &q = d->rects[VK_REF_INDEX(r)];
+                if (!(q.c0 < q.c1) || !(q.d0 < q.d1)) return fail(VK_ERR_BAD_ARG, "light Rect with an empty extent (gen_range(c0,c1) panics, hittable.rs:287-288)");
+            }
             if (k == VK_KIND_SPHERE || k == VK_KIND_RECT) out = simple_dref(r, 0);
             else if (k == VK_KIND_LIST) { uint32_t li; if (!convert_list(VK_REF_INDEX(r), li)) return false; out = VKD_MAKE(DK_LIST, li) | ((r & VK_REF_FLIP) ? DREF_FLIP : 0u); }
             L.lights.push_back(out);

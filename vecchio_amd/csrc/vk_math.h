@@ -85,13 +85,16 @@ VK_HD float gen_f32(Rng &r) { return (float)(next_u32(r) >> 8) * (1.0f / 1677721
 // rand 0.7.3 UniformFloat<f32>::sample_single
 VK_HD float gen_range(Rng &r, float lo, float hi) {
     float scale = hi - lo;
-    for (;;) {
+    // The reference asserts lo < hi (panics otherwise) and redraws while res >= hi, which for lo < hi
+    // happens with probability ~2^-24 per draw.  The loop is bounded so that a degenerate range
+    // (lo >= hi, NaN) that slipped past validation can never hang a GPU wave.
+    for (int guard = 0; guard < 256; guard++) {
         float v12 = bits_f32((next_u32(r) >> 9) | 0x3F800000u);
         float v01 = v12 - 1.0f;
         float res = v01 * scale + lo;
         if (res < hi) return res;
-        if (!(scale < INFINITY && scale > -INFINITY)) return lo;  // reference would spin/panic
     }
+    return lo;
 }
 
 // rand 0.7.3 UniformInt<u32>::sample_single(0, n) as used by SliceRandom::choose/gen_index
