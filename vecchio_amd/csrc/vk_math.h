@@ -86,15 +86,17 @@ VK_HD float gen_f32(Rng &r) { return (float)(next_u32(r) >> 8) * (1.0f / 1677721
 VK_HD float gen_range(Rng &r, float lo, float hi) {
     float scale = hi - lo;
     // The reference asserts lo < hi (panics otherwise) and redraws while res >= hi, which for lo < hi
-    // happens with probability ~2^-24 per draw.  The loop is bounded so that a degenerate range
-    // (lo >= hi, NaN) that slipped past validation can never hang a GPU wave.
-    for (int guard = 0; guard < 256; guard++) {
+    // happens with probability ~2^-24 per draw.  A degenerate range (lo >= hi, NaN, hi-lo overflowing)
+    // that slipped past validation is answered up front so that it can never hang a GPU wave; the
+    // test folds away at the call sites with constant bounds and costs no loop-carried register
+    // (a draw counter in the loop pushed the sphere-only kernel over its 80-VGPR budget).
+    if (!(scale > 0.0f) || scale > 3.0e38f) return lo;
+    for (;;) {
         float v12 = bits_f32((next_u32(r) >> 9) | 0x3F800000u);
         float v01 = v12 - 1.0f;
         float res = v01 * scale + lo;
         if (res < hi) return res;
     }
-    return lo;
 }
 
 // rand 0.7.3 UniformInt<u32>::sample_single(0, n) as used by SliceRandom::choose/gen_index
