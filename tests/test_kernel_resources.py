@@ -1,0 +1,64 @@
+"""Register / scratch / occupancy budget of the megakernel variants, read from the compiler's
+kernel-resource-usage remarks that build_device() keeps next to the library.
+
+The render kernel is latency bound: its throughput follows waves/SIMD, and a variant that starts
+spilling loses a third of its rate (a loop-carried draw counter in gen_range once cost C2
+3.4 -> 2.2 Gsamples/s with every parity test still green).  This pins the budget on the CPU."""
+import os
+import re
+
+from vecchio_amd import build
+
+F_CORNELL = 0x2 | 0x4 | 0x10 | 0x100          # RECT | LIST | INSTANCE | BOX  (vk_api.hip pick_variant)
+F_PDF = 0x80
+
+
+def variants():
+    txt = open(build.kernel_resources_path()).read()
+    out = {}
+    for blk in txt.split("Name: ")[1:]:
+        name = blk.split("\n")[0].strip()
+        m = re.search(r"render_kernelILj(\d+)ELb([01])ELi(\d+)ELb([01])E", name)
+        if not m:
+            continue
+        get = lambda k: int(re.search(re.escape(k) + r": (\d+)", blk).group(1))
+        out[(int(m.group(1)), m.group(2) == "1", int(m.group(3)), m.group(4) == "1")] = dict(
+            vgprs=get("VGPRs"), agprs=get("AGPRs"), scratch=get("ScratchSize [bytes/lane]"),
+            occupancy=get("Occupancy [waves/SIMD]"), dynamic_stack="Dynamic Stack: True" in blk)
+    return out
+
+
+def test_resource_file_lists_every_variant(built):
+    assert os.path.exists(build.kernel_resources_path())
+    v = variants()
+    feats = {k[0] for k in v}
+    assert {0, F_PDF, F_CORNELL | F_PDF, 0x17F, 0x17F | F_PDF} <= feats, sorted(feats)
+    for f in feats:
+        assert (f, True, 6 if f in (0, F_PDF) else 4, False) in v       # LDS-resident scene
+        assert (f, False, 6 if f in (0, F_PDF) else 4, False) in v      # global-memory scene
+
+
+def test_sphere_only_variant_keeps_six_waves_per_simd(built):
+    for key, r in variants().items():
+        f, lds, minw, stats = key
+        if f not in (0, F_PDF):
+            continue
+        assert minw == 6 and r["occupancy"] >= 6, (key, r)
+        assert r["vgprs"] <= 80 and r["agprs"] == 0, (key, r)
+        # the C2/C4 kernel proper: at most the 16 B (4 dwords) it has always had
+        assert r["scratch"] <= (16 if f == 0 else 48), (key, r)
+        assert not r["dynamic_stack"], (key, r)
+
+
+def test_cornell_variant_does_not_spill(built):
+    for key, r in variants().items():
+        if key[0] & ~F_PDF != F_CORNELL:
+            continue
+        assert r["occupancy"] >= 4 and r["scratch"] == 0 and r["vgprs"] <= 128, (key, r)
+
+
+def test_full_variant_budget(built):
+    for key, r in variants().items():
+        if key[0] & ~F_PDF not in (0x17F, 0x17F & ~F_PDF):
+            continue
+        assert r["occupancy"] >= 4 and r["scratch"] <= 144 and not r["dynamic_stack"], (key, r)

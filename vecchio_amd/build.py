@@ -4,6 +4,7 @@
 contracts a*b+c) and host/device parity of every control-flow value depends on it.
 """
 import os
+import re
 import subprocess
 import sys
 
@@ -58,10 +59,27 @@ def build_device(force=False):
     srcs = [os.path.join(CSRC, "vk_api.hip"), os.path.join(CSRC, "vk_linearize.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("vk_trace.h", "vk_math.h", "vk_device_scene.h", "vk_linearize.h")] + \
         [os.path.join(ROOT, "include", "vecchio_amd.h")]
-    if force or _newer(out, deps):
+    if force or _newer(out, deps) or not os.path.exists(kernel_resources_path()):
         os.makedirs(LIB, exist_ok=True)
-        _run([HIPCC] + HIPFLAGS + ["-shared", "-o", out] + srcs)
+        cmd = [HIPCC] + HIPFLAGS + ["-Rpass-analysis=kernel-resource-usage", "-shared", "-o", out] + srcs
+        print("+", " ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        remarks = [l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" in l]
+        other = [l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l]
+        if other:
+            print("\n".join(other), file=sys.stderr)
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        # registers / scratch / occupancy of every kernel, kept next to the library: the megakernel's
+        # throughput collapses when a variant starts spilling, so tests/test_kernel_resources.py pins them
+        with open(kernel_resources_path(), "w") as f:
+            f.write("\n".join(re.sub(r"^.*remark: [^ ]* ", "", l).replace(" [-Rpass-analysis=kernel-resource-usage]", "")
+                              for l in remarks) + "\n")
     return out
+
+
+def kernel_resources_path():
+    return os.path.join(LIB, "kernel_resources.txt")
 
 
 def build_oracle(force=False):
