@@ -255,7 +255,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             if ((n_box | n_prim | n_sn) == 0) break;
             if (STATS) st_sched++;
             if (n_box >= n_prim && n_box >= n_sn) {
-                // ---- BOX: predicated steps (full EXEC), two per exit test, while box lanes are the plurality
+                // ---- BOX: UNROLL steps under a shrinking EXEC mask per exit test, while box lanes are the plurality
                 KArgsC P = kargs_fresh();
                 DScene S = KARG(P, S);
                 Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
@@ -267,12 +267,13 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 // leave the BOX state within a step or two
                 constexpr int UNROLL = ((F & VKF_ALL_SCENE) == (VKF_RECT | VKF_LIST | VKF_INSTANCE | VKF_BOX)) ? 2 : BOX_UNROLL;
                 for (;;) {
-#pragma unroll
-                    for (int u = 0; u < UNROLL; u++) {
-                        if (STATS) { st_box_steps += 1; st_box_lanes += lanes_with(is_box); }
-                        box_step<F, Mem>(L, S, M, is_box);
-                        is_box = active && !has_prim_work(L) && traversing(L);
+                    if (F & VKF_INSTANCE) {     // end of an instance's item range: back to the parent space (rare)
+                        if (is_box && L.i >= L.end && L.cur_inst >= 0) leave_instance<F, Mem>(L, S);
                     }
+                    bool go = active && L.pend == 0u && L.i < range_end<F>(L, S);
+                    if (STATS) { st_box_steps += UNROLL; st_box_lanes += lanes_with(go); }
+                    box_steps<F, Mem, UNROLL>(L, S, M, go);
+                    is_box = active && !has_prim_work(L) && traversing(L);
                     uint32_t nb = lanes_with(is_box);
                     uint32_t np = lanes_with(active && has_prim_work(L));
                     uint32_t ns = live - nb - np;

@@ -385,24 +385,18 @@ VK_HD bool has_prim_work(const Lane &L) { return L.pend != 0; }
 // Sphere / MovingSphere / Rect tests are ~50 instructions; Boxy, lists, media and instance entry cost several times that
 VK_HD bool prim_is_heavy(uint32_t ref) { uint32_t k = VKD_KIND(ref); return k >= DK_LIST; }
 
-// `on` = this lane has box work.  Written with selects instead of branches: on gfx950 the one
-// scalar unit per CU is what a divergent traversal loop saturates first (every divergent `if`
-// costs s_and_saveexec / s_cbranch / s_or, every boolean combination an s_and/s_or), so the
-// whole wave runs the step with full EXEC, lanes that are not `on` (or are past their range)
-// redo item 0 and discard the result, and the only branch is the rare exact fallback, decided
-// by ONE float compare.
+// One box step of a lane that HAS box work and is inside its range (pend == 0, i < end).
+// The wave runs it under the EXEC mask of exactly those lanes (box_steps below): a lane that queues
+// objects or reaches the end of its range drops out of the mask and costs nothing more, and the
+// bookkeeping is a handful of VALU selects (a fully predicated version that kept all 64 lanes in
+// EXEC and re-did item 0 on idle lanes spent 14 of its 45 VALU instructions on selects).
 template <uint32_t F, class Mem>
-VK_HD void box_step(Lane &L, const DScene &S, const Mem &M, bool on) {
-    bool at_end = L.i >= L.end;
-    if (F & VKF_INSTANCE) {
-        if (on && at_end) { if (L.cur_inst >= 0) leave_instance<F, Mem>(L, S); return; }   // rare
-    }
-    bool go = on && !at_end;
-    DItem n = M.item(go ? L.i : 0u);
+VK_HD void box_step_core(Lane &L, const Mem &M) {
+    DItem n = M.item(L.i);
     // AxisBB::hit decided from reciprocal multiplies; same boolean as the reference's (see slab_exact):
     // both forms compute fl(b-o) identically and q~ = fl(fl(b-o)*fl(1/d)) differs from the reference's
-    // fl(fl(b-o)/d) by < 3*2^-24 relative, so a margin of 2e-6 on either side is decisive; the three
-    // per-axis early-outs equal one test max(lo..) < min(hi..) because lo only grows and hi only shrinks.
+    // fl(fl(b-o)/d) by < 3*2^-24 relative; the three per-axis early-outs equal one test
+    // max(lo..) < min(hi..) because lo only grows and hi only shrinks.
     // (scalar on purpose: v_pk_add_f32/v_pk_mul_f32 on (min,max) pairs was measured 5 % SLOWER —
     // the broadcast operands need register pairs, which costs occupancy)
     float x0 = (n.mnx - L.o.x) * L.inv.x, x1 = (n.mxx - L.o.x) * L.inv.x;
@@ -410,19 +404,41 @@ VK_HD void box_step(Lane &L, const DScene &S, const Mem &M, bool on) {
     float z0 = (n.mnz - L.o.z) * L.inv.z, z1 = (n.mxz - L.o.z) * L.inv.z;
     float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));   // >= T_MIN > 0, never NaN
     float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), L.T));    // <= T, never NaN
-    const float EP = 1.000002f;
-    float miss_margin = lo - hi * EP;     // > 0: certainly a miss (also when hi <= 0)
-    float hit_margin = hi - lo * EP;      // > 0: certainly a hit; the two cannot both be positive
-    bool h = hit_margin > 0.0f;
-    // xnan is NaN for rays whose 1/d is not a full-precision normal number: forces the fallback
-    if (!(fmaxf(miss_margin, hit_margin) + L.xnan > 0.0f))
+    // lo >= T_MIN > 0, so with e = 3*2^-24 the sign of the exact (hi - lo) equals the sign of this one whenever
+    // |hi - lo| > 2e*hi/(1-e) ~ 3.6e-7*hi (also for hi <= 0: a certain miss).  The test below asks for 2e-6*hi,
+    // and is false (-> exact fallback) when xnan is NaN, i.e. for rays whose 1/d is not a full-precision normal
+    // number.  `>=` so that hi = +inf (always-hit leaves while T is still infinite) stays on the fast path.
+    float dlt = hi - lo;
+    bool h = dlt > 0.0f;
+    if (!(fabsf(dlt) >= __builtin_fmaf(hi, 2.0e-6f, L.xnan)))
         h = slab_exact(n, L.o, L.d, T_MIN, L.T);         // within rounding distance: the reference's divisions
     bool inner = (n.w0 >> 28) == 0u;
-    bool leaf_hit = h && !inner;                          // leaf: left object first, then the right one
-    uint32_t next_i = (inner && !h) ? n.w0 : L.i + 1u;    // inner: hit -> left subtree, miss -> skip link
-    L.i = go ? next_i : L.i;
-    L.pend = go ? (leaf_hit ? n.w0 : 0u) : L.pend;
-    L.pend2 = go ? (leaf_hit ? n.w1 : 0u) : L.pend2;
+    L.i = (inner && !h) ? n.w0 : L.i + 1u;               // inner: hit -> left subtree, miss -> skip link
+    L.pend = (h && !inner) ? n.w0 : 0u;                  // leaf: left object first, then the right one
+    L.pend2 = n.w1;                                      // only read after pend, i.e. after a leaf hit
+}
+
+// range end of the lane's current item range: wave-uniform when the scene has no instances
+template <uint32_t F>
+VK_HD uint32_t range_end(const Lane &L, const DScene &S) { return (F & VKF_INSTANCE) ? L.end : S.n_world_items; }
+
+// N box steps, each run by the lanes that still have box work: nested ifs, i.e. one shrinking EXEC mask
+template <uint32_t F, class Mem, int N>
+VK_HD void box_steps(Lane &L, const DScene &S, const Mem &M, bool go) {
+    if (go) {
+        box_step_core<F, Mem>(L, M);
+        if (N > 1) box_steps<F, Mem, (N > 1 ? N - 1 : 1)>(L, S, M, L.pend == 0u && L.i < range_end<F>(L, S));
+    }
+}
+
+// sequential form of one step (CPU emulator); `on` = this lane has box work
+template <uint32_t F, class Mem>
+VK_HD void box_step(Lane &L, const DScene &S, const Mem &M, bool on) {
+    bool at_end = L.i >= L.end;
+    if (F & VKF_INSTANCE) {
+        if (on && at_end) { if (L.cur_inst >= 0) leave_instance<F, Mem>(L, S); return; }   // rare
+    }
+    if (on && !at_end) box_step_core<F, Mem>(L, M);
 }
 
 template <uint32_t F, class Mem>
