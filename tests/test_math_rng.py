@@ -78,3 +78,30 @@ def test_gen_index_mapping(oracle):
         assert v.min() >= 0 and v.max() <= n - 1
         counts = np.bincount(v.astype(np.int64), minlength=n) / len(v)
         assert np.abs(counts - 1.0 / n).max() < 0.01
+
+
+def _chi2(counts):
+    e = counts.sum() / counts.size
+    return float(((counts - e) ** 2 / e).sum()), counts.size - 1
+
+
+def test_sample_stream_statistics(oracle):
+    """The per-sample generator (32-bit Weyl sequence + two-multiply finaliser keyed by the sample's
+    64-bit key) is the build's own substitute for thread_rng(): uniform in 1, 2 and 3 dimensions
+    within one stream, and across the streams of neighbouring (pixel, sample) pairs."""
+    n = 1 << 21
+    u = oracle.draws(11, 5, 9, 0, n).astype(np.float64)
+    assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 0.004 and abs(np.corrcoef(u[:-2], u[2:])[0, 1]) < 0.004
+    for counts in (np.histogram(u, bins=4096, range=(0, 1))[0],
+                   np.histogram2d(u[:-1], u[1:], bins=96, range=((0, 1), (0, 1)))[0],
+                   np.histogramdd(np.stack([u[0::3][:n // 3], u[1::3][:n // 3], u[2::3][:n // 3]], 1), bins=20, range=((0, 1),) * 3)[0]):
+        c, dof = _chi2(counts)
+        assert abs(c - dof) < 5.0 * np.sqrt(2.0 * dof), (c, dof)      # 5 sigma
+    # first 8 draws of 40 000 neighbouring streams (the dimensions of camera jitter / lens / time)
+    first = np.stack([oracle.draws(2, p, s, 0, 8) for p in range(625) for s in range(64)]).astype(np.float64)
+    for a, b in ((0, 1), (0, 7), (2, 3)):
+        c, dof = _chi2(np.histogram2d(first[:, a], first[:, b], bins=24, range=((0, 1), (0, 1)))[0])
+        assert abs(c - dof) < 5.0 * np.sqrt(2.0 * dof), (a, b, c, dof)
+    c, dof = _chi2(np.histogram2d(first[:-1, 0], first[1:, 0], bins=24, range=((0, 1), (0, 1)))[0])
+    assert abs(c - dof) < 5.0 * np.sqrt(2.0 * dof), (c, dof)
+    assert abs(np.corrcoef(first[:-1, 0], first[1:, 0])[0, 1]) < 0.02

@@ -46,7 +46,10 @@ int fail(int code, const std::string &m) { g_err = m; return code; }
 constexpr int MAX_WG_THREADS = 1024;   // 16 waves = 4 per SIMD: the register budget (<= 128 VGPRs) every variant is held to
 constexpr size_t LDS_PER_CU = 160 * 1024;
 constexpr int TILE = 8;   // 8x8 pixels = one wave
-constexpr int BOX_UNROLL = 4;   // box steps between two exit tests of the BOX loop
+#ifndef VK_BOX_UNROLL
+#define VK_BOX_UNROLL 4
+#endif
+constexpr int BOX_UNROLL = VK_BOX_UNROLL;   // box steps between two exit tests of the BOX loop
 
 struct KArgs {
     DScene S;

@@ -64,26 +64,41 @@ VK_HD Rng rng_for_sample(uint64_t seed, uint32_t pixel, uint32_t sample) {
     return r;
 }
 
-// a stream for host-side scene construction (scene builders, BVH axis choice)
-VK_HD Rng rng_for_stream(uint64_t seed, uint64_t stream) {
-    Rng r;
+// Per-sample stream, drawn from on the device once per random decision: a 32-bit Weyl sequence
+// through a two-multiply finaliser (the "lowbias32" constants), keyed by both halves of the
+// sample's 64-bit key.  A draw is 3 v_mul_lo_u32 + 8 simple ops; SplitMix64 per draw (two
+// 64-bit multiplies = ~16 quarter-rate integer multiplies on gfx950) made the generator the
+// largest single cost of the shading phase.  Statistical checks: tests/test_math_rng.py.
+VK_HD uint32_t next_u32(Rng &r) {
+    r.ctr += 1u;
+    uint32_t x = (uint32_t)r.key + r.ctr * 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x21F0AAADu;
+    x ^= x >> 15; x ^= (uint32_t)(r.key >> 32); x *= 0x735A2D97u;
+    x ^= x >> 15;
+    return x;
+}
+
+// The stream for host-side scene construction (scene builders, BVH axis choice, Perlin tables):
+// SplitMix64 in counter mode.  A separate type so that scenes do not depend on the per-sample generator.
+struct BuildRng { uint64_t key; uint32_t ctr; };
+VK_HD BuildRng rng_for_stream(uint64_t seed, uint64_t stream) {
+    BuildRng r;
     uint64_t h = mix64(seed + 0x9E3779B97F4A7C15ull);
     r.key = mix64(h ^ mix64(stream + 0xD1B54A32D192ED03ull));
     r.ctr = 0;
     return r;
 }
-
-VK_HD uint32_t next_u32(Rng &r) {
+VK_HD uint32_t next_u32(BuildRng &r) {
     r.ctr += 1u;
     uint64_t z = r.key + (uint64_t)r.ctr * 0x9E3779B97F4A7C15ull;
     return (uint32_t)(mix64(z) >> 32);
 }
 
 // rand 0.7.3 Standard for f32: 24 random bits scaled by 2^-24 -> [0,1)
-VK_HD float gen_f32(Rng &r) { return (float)(next_u32(r) >> 8) * (1.0f / 16777216.0f); }
+template <class R> VK_HD float gen_f32(R &r) { return (float)(next_u32(r) >> 8) * (1.0f / 16777216.0f); }
 
 // rand 0.7.3 UniformFloat<f32>::sample_single
-VK_HD float gen_range(Rng &r, float lo, float hi) {
+template <class R> VK_HD float gen_range(R &r, float lo, float hi) {
     float scale = hi - lo;
     // The reference asserts lo < hi (panics otherwise) and redraws while res >= hi, which for lo < hi
     // happens with probability ~2^-24 per draw.  A degenerate range (lo >= hi, NaN, hi-lo overflowing)
@@ -100,7 +115,7 @@ VK_HD float gen_range(Rng &r, float lo, float hi) {
 }
 
 // rand 0.7.3 UniformInt<u32>::sample_single(0, n) as used by SliceRandom::choose/gen_index
-VK_HD uint32_t gen_index(Rng &r, uint32_t n) {
+template <class R> VK_HD uint32_t gen_index(R &r, uint32_t n) {
     uint32_t range = n;
     uint32_t zone = (range << __builtin_clz(range)) - 1u;
     for (;;) {

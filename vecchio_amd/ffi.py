@@ -165,7 +165,8 @@ DEVICE_SYMBOLS = [
 
 
 def device_lib_path():
-    return os.path.join(LIB_DIR, "libvecchio_amd.so")
+    # VK_DEVICE_LIB: an alternate build of the same library (kernel experiments); never a different backend
+    return os.environ.get("VK_DEVICE_LIB") or os.path.join(LIB_DIR, "libvecchio_amd.so")
 
 
 def load_device_lib():

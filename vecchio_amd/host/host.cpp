@@ -8,8 +8,8 @@
 
 namespace vecchio {
 
-static thread_local vk::Rng g_build_rng = vk::rng_for_stream(1, 0);
-vk::Rng &thread_rng() { return g_build_rng; }
+static thread_local vk::BuildRng g_build_rng = vk::rng_for_stream(1, 0);
+vk::BuildRng &thread_rng() { return g_build_rng; }
 void seed_thread_rng(uint64_t seed) { g_build_rng = vk::rng_for_stream(seed, 0); }
 
 // ------------------------------------------------------------------ FlatBuilder

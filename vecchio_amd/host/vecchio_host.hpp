@@ -30,7 +30,7 @@ namespace vecchio {
 // ------------------------------------------------------------------ seeded thread_rng()
 // scene.rs / accel.rs / material.rs draw from rand::thread_rng() while building; the
 // stand-in is one seeded stream per scene build.
-vk::Rng &thread_rng();
+vk::BuildRng &thread_rng();
 void seed_thread_rng(uint64_t seed);
 inline float gen_f32() { return vk::gen_f32(thread_rng()); }
 inline float gen_range(float lo, float hi) { return vk::gen_range(thread_rng(), lo, hi); }
