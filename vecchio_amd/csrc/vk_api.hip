@@ -280,7 +280,16 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     uint32_t nb = lanes_with(is_box);
                     uint32_t np = lanes_with(active && has_prim_work(L));
                     uint32_t ns = live - nb - np;
-                    if (nb == 0 || nb < np || nb < ns) break;          // another state now has more lanes parked than are stepping
+                    if (nb == 0 || nb < np || nb < ns) {               // another state now has more lanes parked than are stepping
+                        // sphere-only variants: when that state is PRIM, test the pending spheres right here and
+                        // keep stepping (saves the scheduler round trip that otherwise follows every ~10 box steps)
+                        if (!HAS_HEAVY && !(F & VKF_MEDIUM) && np != 0 && np >= ns) {
+                            if (active && has_prim_work(L)) prim_step<F, Mem>(L, S, M);
+                            is_box = active && !has_prim_work(L) && traversing(L);
+                            continue;
+                        }
+                        break;
+                    }
                 }
                 if (STATS) st_t_box += clock64() - st_t0;
             } else if (n_prim >= n_sn) {
