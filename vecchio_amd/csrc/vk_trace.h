@@ -778,7 +778,9 @@ VK_HD V3 object_random(const DScene &S, const Mem &M, Rng &g, uint32_t ref, V3 o
 }
 
 // ------------------------------------------------------------------ camera + sample start (main.rs:111-120,187-189)
-VK_HD void start_sample(Lane &L, const DScene &S, const RenderConsts &C, uint32_t x, uint32_t y, uint32_t sample) {
+// The new ray is returned, not installed: the kernel installs the rays of refilled lanes and of lanes whose
+// path continues with ONE begin_segment (its three exact reciprocals are ~60 instructions per call site).
+VK_HD void start_sample_core(Lane &L, const RenderConsts &C, uint32_t x, uint32_t y, uint32_t sample, V3 &o, V3 &d, float &time) {
     uint32_t pixel = y * C.width + x;                         // main.rs:182-183
     L.pixel = pixel; L.sample = sample;
     L.rng = vk::rng_for_sample(C.seed, pixel, sample);
@@ -787,35 +789,53 @@ VK_HD void start_sample(Lane &L, const DScene &S, const RenderConsts &C, uint32_
     V3 rd = random_in_unit_disk(L.rng) * C.cam.lens_radius;
     V3 offset = ld3(C.cam.u) * rd.x + ld3(C.cam.v) * rd.y;
     V3 org = ld3(C.cam.origin);
-    V3 o = org + offset;
-    V3 d = ld3(C.cam.lower_left_corner) + ld3(C.cam.horizontal) * u + ld3(C.cam.vertical) * v - org - offset;
-    float time = vk::gen_range(L.rng, C.cam.time0, C.cam.time1);
+    o = org + offset;
+    d = ld3(C.cam.lower_left_corner) + ld3(C.cam.horizontal) * u + ld3(C.cam.vertical) * v - org - offset;
+    time = vk::gen_range(L.rng, C.cam.time0, C.cam.time1);
     L.thr = v3s(1.0f); L.acc = v3s(0.0f); L.depth = 1;
+}
+VK_HD void start_sample(Lane &L, const DScene &S, const RenderConsts &C, uint32_t x, uint32_t y, uint32_t sample) {
+    V3 o, d; float time;
+    start_sample_core(L, C, x, y, sample, o, d, time);
     begin_segment(L, S, o, d, time);
 }
 
-VK_HD V3 background_of(const RenderConsts &C, V3 d) {
+VK_HD V3 background_of(const RenderConsts &C, V3 ud) {       // ud = unit(ray direction), only read for the sky
     if (C.background == VK_BACKGROUND_SKY) {
-        V3 ud = unit(d);
         float t = 0.5f * (ud.y + 1.0f);
         return v3s(1.0f) * (1.0f - t) + v3(0.5f, 0.7f, 1.0f) * t;
     }
     return v3(C.bg[0], C.bg[1], C.bg[2]);
 }
 
-// Called when traversal of the current segment has finished.  Returns true when a new
-// segment was set up (keep traversing), false when the path ended (L.acc is its radiance).
+// Called when traversal of the current segment has finished.  Returns true when the path continues with
+// the ray (no, nd, ntime) (the caller installs it with begin_segment), false when the path ended (L.acc is
+// its radiance).
 template <uint32_t F, class Mem>
-VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) {
-    if (L.best_prim == 0) {                                   // miss: main.rs:150-152
-        L.acc = L.acc + L.thr * background_of(C, L.wd);
+VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C, V3 &no, V3 &ndir, float &ntime) {
+    const bool miss = L.best_prim == 0;
+    Rec R;
+    const DMaterial *m = S.materials;
+    uint32_t k0 = VK_MAT_LAMBERTIAN;
+    if (!miss) {
+        build_record<F, Mem>(L, S, M, R);
+        m = &S.materials[R.mat];
+        k0 = m->kind;
+    }
+    V3 rd = L.wd;                                             // `r` of ray_color is the world-space ray
+    // unit_vector(r.direction) is what the sky, Metal and Dielectric start from (main.rs IOW sky; material.rs:119,
+    // 155,182): one copy of its three divisions + square root for the whole wave instead of one per branch
+    V3 ud = rd;
+    {
+        if (F & VKF_SPEC_DIFFUSE) k0 = (k0 == VK_MAT_SPEC_DIFFUSE) ? (uint32_t)VK_MAT_METAL : k0;   // its children may need it
+        bool need_ud = miss ? (C.background == VK_BACKGROUND_SKY) : (k0 == VK_MAT_METAL || k0 == VK_MAT_DIELECTRIC);
+        if (need_ud) ud = unit(rd);
+    }
+    if (miss) {                                               // miss: main.rs:150-152
+        L.acc = L.acc + L.thr * background_of(C, ud);
         return false;
     }
-    Rec R;
-    build_record<F, Mem>(L, S, M, R);
-    V3 rd = L.wd;                                             // `r` of ray_color is the world-space ray
-    const DMaterial *m = &S.materials[R.mat];
-    V3 ndir; float ntime = L.time;
+    ntime = L.time;
     if (!(F & VKF_INTEG_PDF)) {
         // emitted + attenuation * ray_color(scattered): Material::emitted + Material::scatter
         V3 emitted = v3s(0.0f);
@@ -826,14 +846,13 @@ VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) 
             ndir = R.n + lambertian_random(L.rng);
             atten = material_color<F>(S, *m, R);
         } else if (kind == VK_MAT_METAL) {                    // material.rs:118-132
-            V3 reflected = reflect(unit(rd), R.n);
+            V3 reflected = reflect(ud, R.n);
             ndir = reflected + random_in_unit_sphere(L.rng) * m->param;
             atten = material_color<F>(S, *m, R);
             scattered = dot(ndir, R.n) > 0.0f;
         } else if (kind == VK_MAT_DIELECTRIC) {               // material.rs:150-175
             atten = v3s(1.0f);
             float eta = R.front ? 1.0f / m->param : m->param;
-            V3 ud = unit(rd);
             float cos_theta = fminf(dot(-ud, R.n), 1.0f);
             float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
             if (eta * sin_theta > 1.0f) ndir = reflect(ud, R.n);
@@ -870,13 +889,12 @@ VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) 
         }
         uint32_t kind = m->kind;
         if (kind == VK_MAT_METAL) {                           // material.rs:134-141 (Ray::new: time 0, never absorbs)
-            V3 reflected = reflect(unit(rd), R.n);
+            V3 reflected = reflect(ud, R.n);
             ndir = reflected + random_in_unit_sphere(L.rng) * m->param;
             ntime = 0.0f;
             L.thr = L.thr * material_color<F>(S, *m, R);         // specular: emitted is NOT added (main.rs:134-137)
         } else if (kind == VK_MAT_DIELECTRIC) {               // material.rs:177-206
             float eta = R.front ? 1.0f / m->param : m->param;
-            V3 ud = unit(rd);
             float cos_theta = fminf(dot(-ud, R.n), 1.0f);
             float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
             if (eta * sin_theta > 1.0f) ndir = reflect(ud, R.n);
@@ -922,7 +940,14 @@ VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) 
         L.acc = L.acc + L.thr * v3s(0.0f);                    // keeps the reference's 0*inf / 0/0 -> NaN drops
         return false;
     }
-    begin_segment(L, S, R.p, ndir, ntime);
+    no = R.p;
+    return true;
+}
+template <uint32_t F, class Mem>
+VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) {
+    V3 o, d; float time;
+    if (!shade_core<F, Mem>(L, S, M, C, o, d, time)) return false;
+    begin_segment(L, S, o, d, time);
     return true;
 }
 
