@@ -182,7 +182,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
     using Mem = typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type;
     // diagnostic counters (STATS build only): phase executions and the lanes that had work in them
     unsigned long long st_box_steps = 0, st_box_lanes = 0, st_prim_execs = 0, st_prim_lanes = 0, st_shade_execs = 0, st_shade_lanes = 0, st_sched = 0;
-    unsigned long long st_t_box = 0, st_t_light = 0, st_t_heavy = 0, st_t_shade = 0, st_heavy_execs = 0, st_t0 = 0, st_t_total = 0;
+    unsigned long long st_t_box = 0, st_t_light = 0, st_t_heavy = 0, st_t_shade = 0, st_heavy_execs = 0, st_t0 = 0, st_t_total = 0, st_t_mat = 0, st_t_refill = 0, st_t_install = 0, st_t1 = 0;
     if (STATS) st_t_total = clock64();
 
     // ---- LDS layout: [items][spheres][per-wave pixel accumulators][per-wave cold lane state]
@@ -329,6 +329,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 constexpr bool ONE_INSTALL = (F & VKF_ALL_SCENE) != VKF_ALL_SCENE;
                 if (is_shade) {
                     cold_load<F>(cold, lane, L, q);
+                    if (STATS) st_t1 = clock64();
                     bool cont;
                     if (ONE_INSTALL) {
                         V3 no, nd; float nt;
@@ -337,6 +338,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     } else {
                         cont = shade<F, Mem>(L, S, M, C);
                     }
+                    if (STATS) st_t_mat += clock64() - st_t1;
                     if (!cont) {
                         float4 *dbg = KARG(P, debug);
                         if (dbg) dbg[((size_t)(ty + (q >> 3)) * C.width + (tx + (q & 7u))) * C.spp + L.sample] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(L.rng.ctr));
@@ -349,6 +351,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                         need = true;
                     }
                 }
+                if (STATS) st_t1 = clock64();
                 unsigned long long need_mask = __builtin_amdgcn_ballot_w64(need);
                 if (need_mask) {
                     uint32_t rank = __popcll(need_mask & ((1ull << lane) - 1ull));
@@ -377,9 +380,10 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     }
                     next_item += (uint32_t)__popcll(need_mask);
                 }
+                if (STATS) { st_t_refill += clock64() - st_t1; st_t1 = clock64(); }
                 if (ONE_INSTALL && fresh) begin_segment(L, S, L.wo, L.wd, L.time);   // one copy of the exact reciprocals for both kinds of new ray
                 if (active && touched) cold_store<F>(cold, lane, L, q);
-                if (STATS) st_t_shade += clock64() - st_t0;
+                if (STATS) { st_t_shade += clock64() - st_t0; st_t_install += clock64() - st_t1; }
             }
         }
         // ---- write the unit's pixel sums
@@ -409,6 +413,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             atomicAdd(&ps[4], st_shade_execs); atomicAdd(&ps[5], st_shade_lanes); atomicAdd(&ps[6], st_sched); atomicAdd(&ps[7], st_heavy_execs);
             atomicAdd(&ps[8], st_t_box); atomicAdd(&ps[9], st_t_light); atomicAdd(&ps[10], st_t_heavy); atomicAdd(&ps[11], st_t_shade);
             atomicAdd(&ps[12], (unsigned long long)(clock64() - st_t_total));
+            atomicAdd(&ps[13], st_t_mat); atomicAdd(&ps[14], st_t_refill); atomicAdd(&ps[15], st_t_install);
         }
     }
 }
@@ -513,11 +518,13 @@ size_t per_wave_lds_bytes(uint32_t F) {   // pixel accumulators + cold lane stat
     return (size_t)64 * (3 + ((F & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE)) * sizeof(float);
 }
 
-// LDS residency plan.  `hot` = bytes of items + spheres.  The traversal is a chain of dependent
-// 32-byte gathers: from LDS a step costs ~100 cycles of latency, from L2 ~500+, so residency is
-// worth a lot of occupancy.  Choose the workgroup size (waves share one LDS copy of the scene)
-// and workgroups per CU that give the most waves per CU (cap 16 = the 128-VGPR budget) with
-// the scene resident; fall back to the global-memory variant when fewer than 6 waves would fit.
+// LDS residency plan.  `hot` = bytes of items + spheres + boxes.  Measured on MI355X with the VALU-bound
+// kernel: at EQUAL occupancy a scene staged in LDS beats the same scene read through L1/L2 by only 7 % (C2:
+// 4.06 vs 3.77 Gsamples/s at 24 waves/CU; C4: no difference), while occupancy is worth much more (C3: the
+// 118 KB scene in LDS leaves 11 waves/CU = 371 Msamples/s; from L2 at 16 waves/CU = 503).  So the scene is
+// staged in LDS only when that costs no waves: choose the workgroup size (waves share one LDS copy) and
+// workgroups per CU that reach the variant's full occupancy (24 waves/CU at 80 VGPRs, 16 at 128) with the
+// scene resident, else traverse from global memory at full occupancy.
 void plan_residency(vk_scene *s, size_t hot) {
     const size_t pw = per_wave_lds_bytes(pick_variant(s->host.features));
     uint32_t best_waves = 0, best_wg = 0, best_n = 0;
@@ -532,7 +539,9 @@ void plan_residency(vk_scene *s, size_t hot) {
         if (w < 1) break;
         if (w * n_wg > best_waves) { best_waves = w * n_wg; best_wg = w; best_n = n_wg; }
     }
-    if (best_waves >= 6) {
+    bool no_lds = false;
+    if (const char *e = getenv("VK_NO_LDS_SCENE")) no_lds = e[0] == '1';   // diagnostics: traverse from L2 at full occupancy
+    if (best_waves >= cap && !no_lds) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = best_wg * 64; s->wgs_per_cu = best_n;
     } else {
         s->lds_bytes = 0; s->wg_threads = 512; s->wgs_per_cu = cap / 8;   // 24 (sphere-only) or 16 waves per CU
