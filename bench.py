@@ -47,6 +47,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--bvh", default="reference", choices=["reference", "sah"],
+                    help="host-side BVH builder: the reference's BVHNode::new (default; what a drop-in host hands over) "
+                         "or the host mirror's SAH builder over the same objects (SURVEY 8f-2)")
     ap.add_argument("--spp", type=int, default=0, help="override spp (marks the result as non-headline)")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU sample (0 = size it to ~15 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -81,6 +84,9 @@ def main():
     scene_name, width, spp, depth, label = WORKLOADS[args.workload]
     if args.spp:
         spp = args.spp
+    if args.bvh == "sah":
+        scene_name += "+sah"
+        label += " [SAH BVH over the same objects]"
     hs = HostScene(scene_name, 1)                        # scene seed 1
     cam = hs.next_camera()
     params = hs.params(width, spp, depth, seed=2, tile_rank=rank, tile_world=world)   # render seed 2
@@ -191,7 +197,7 @@ def main():
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
             "config": {"workload": label if not args.spp else label + f" [spp overridden to {spp}]", "scene_seed": 1, "render_seed": 2,
                        "integrator": "scatter" if hs.integrator else "pdf", "tiles": "8x8 round-robin over ranks",
-                       "bvh_items": info.n_items, "scene_in_lds": bool(info.lds_bytes)},
+                       "bvh_builder": args.bvh, "bvh_items": info.n_items, "scene_in_lds": bool(info.lds_bytes)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -24,7 +24,8 @@ def variants():
         get = lambda k: int(re.search(re.escape(k) + r": (\d+)", blk).group(1))
         out[(int(m.group(1)), m.group(2) == "1", int(m.group(3)), m.group(4) == "1")] = dict(
             vgprs=get("VGPRs"), agprs=get("AGPRs"), scratch=get("ScratchSize [bytes/lane]"),
-            occupancy=get("Occupancy [waves/SIMD]"), dynamic_stack="Dynamic Stack: True" in blk)
+            occupancy=get("Occupancy [waves/SIMD]"), dynamic_stack="Dynamic Stack: True" in blk,
+            scratch_ops=int(re.search(r"ScratchOps: (-?\d+)", blk).group(1)))
     return out
 
 
@@ -48,6 +49,8 @@ def test_sphere_only_variant_keeps_six_waves_per_simd(built):
         # a few dwords spilled around the shading phase are tolerated (none may sit in the box / primitive loops:
         # check the ISA when this number moves); C2 lost a third of its rate at 80 B with spills in the loops
         assert r["scratch"] <= (80 if (stats or f != 0) else 32), (key, r)      # STATS = diagnostic build with extra counters
+        # number of scratch load/store instructions in the code (10 / 7 / 35 / 30 when written)
+        assert 0 <= r["scratch_ops"] <= (40 if (stats or f != 0) else 14), (key, r)
         assert not r["dynamic_stack"], (key, r)
 
 
@@ -55,7 +58,7 @@ def test_cornell_variant_does_not_spill(built):
     for key, r in variants().items():
         if key[0] & ~F_PDF != F_CORNELL:
             continue
-        assert r["occupancy"] >= 4 and r["scratch"] == 0 and r["vgprs"] <= 128, (key, r)
+        assert r["occupancy"] >= 4 and r["scratch"] == 0 and r["scratch_ops"] == 0 and r["vgprs"] <= 128, (key, r)
 
 
 def test_full_variant_budget(built):
@@ -63,3 +66,9 @@ def test_full_variant_budget(built):
         if key[0] & ~F_PDF not in (0x17F, 0x17F & ~F_PDF):
             continue
         assert r["occupancy"] >= 4 and r["scratch"] <= 176 and not r["dynamic_stack"], (key, r)
+        # The same scratch SIZE can be spilled in twice as many places: two extra live scalars in the work-fetch code
+        # once took this variant from 91 to 213 scratch instructions and C3 from 505 to 290 Msamples/s.
+        # (91..155 when written; the variants C3 runs are the 511 ones)
+        assert 0 <= r["scratch_ops"] <= 165, (key, r)
+        if key == (0x1FF, False, 4, False):
+            assert r["scratch_ops"] <= 100, (key, r)

@@ -61,20 +61,39 @@ def build_device(force=False):
         [os.path.join(ROOT, "include", "vecchio_amd.h")]
     if force or _newer(out, deps) or not os.path.exists(kernel_resources_path()):
         os.makedirs(LIB, exist_ok=True)
-        cmd = [HIPCC] + HIPFLAGS + ["-Rpass-analysis=kernel-resource-usage", "-shared", "-o", out] + srcs
-        print("+", " ".join(cmd), file=sys.stderr)
-        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
-        remarks = [l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" in l]
-        other = [l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l]
-        if other:
-            print("\n".join(other), file=sys.stderr)
-        if r.returncode != 0:
-            raise subprocess.CalledProcessError(r.returncode, cmd)
+        # -save-temps in a scratch directory: the gfx950 assembly is read back for the per-kernel spill counts
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            cmd = [HIPCC] + HIPFLAGS + ["-Rpass-analysis=kernel-resource-usage", "-save-temps", "-shared", "-o", out] + srcs
+            print("+", " ".join(cmd), file=sys.stderr)
+            r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True, cwd=tmp)
+            remarks = [l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" in l]
+            other = [l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l]
+            if other:
+                print("\n".join(other), file=sys.stderr)
+            if r.returncode != 0:
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            spills = {}
+            for f in os.listdir(tmp):
+                if f.endswith("gfx950.s"):
+                    spills.update(_scratch_ops(open(os.path.join(tmp, f)).read()))
         # registers / scratch / occupancy of every kernel, kept next to the library: the megakernel's
-        # throughput collapses when a variant starts spilling, so tests/test_kernel_resources.py pins them
+        # throughput collapses when a variant starts spilling, so tests/test_kernel_resources.py pins them.
+        # ScratchOps = number of scratch_load/scratch_store instructions in the kernel's code: the remark's
+        # ScratchSize does not move when the allocator spills the same slots in twice as many places.
+        text = "\n".join(re.sub(r"^.*remark: [^ ]* ", "", l).replace(" [-Rpass-analysis=kernel-resource-usage]", "") for l in remarks) + "\n"
+        blocks = text.split("Function Name: ")
+        text = blocks[0] + "".join("Name: " + b.rstrip("\n") + f"\n   ScratchOps: {spills.get(b.split()[0], -1)}\n" for b in blocks[1:])
         with open(kernel_resources_path(), "w") as f:
-            f.write("\n".join(re.sub(r"^.*remark: [^ ]* ", "", l).replace(" [-Rpass-analysis=kernel-resource-usage]", "")
-                              for l in remarks) + "\n")
+            f.write(text)
+    return out
+
+
+def _scratch_ops(asm):
+    """kernel symbol -> number of scratch_* instructions between its label and .Lfunc_end"""
+    out = {}
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end", asm, flags=re.S | re.M):
+        out[m.group(1)] = sum(1 for l in m.group(2).split("\n") if l.lstrip().startswith("scratch_"))
     return out
 
 

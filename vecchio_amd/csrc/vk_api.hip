@@ -207,6 +207,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
         }
     }
 
+    // (per-XCD work queues — contiguous image bands per XCD, stealing when empty — were tried for L2 locality on
+    // C5: no gain there, -1.7 % on C2, and the two extra live scalars doubled the everything-variant's spills)
     for (;;) {
         KArgsC U = kargs_fresh();
         uint32_t unit = 0;
@@ -484,6 +486,7 @@ struct vk_scene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cus = 256;
     uint32_t lds_bytes = 0;    // hot-record bytes staged per workgroup (0 = not LDS resident)
+    size_t hot_bytes = 0;      // items + spheres + boxes: what traversal gathers from
     uint32_t wg_threads = 512; // workgroup size chosen by plan_residency()
     uint32_t sphere_waves = 6; // waves per SIMD of the sphere-only variant (8 was measured 3 % slower: it spills)
     uint32_t wgs_per_cu = 2;
@@ -585,7 +588,6 @@ int check_render_args(vk_scene *scene, const vk_camera *cam, const vk_render_par
 // number of sample chunks per tile: a function of the image and spp ONLY (never of the tile
 // partition), so 1-GPU and N-GPU renders sum every pixel in the same order
 uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
-    (void)s;
     // Samples per pixel per unit: large enough that the end-of-unit tail (lanes idling while the last long
     // paths of a unit finish) stays small, small enough that tiles of very different cost (fog, glass,
     // grazing rays over 1M spheres) are spread over many waves; small images get smaller chunks so that
@@ -594,10 +596,17 @@ uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
     uint64_t tiles = (uint64_t)((p->width + TILE - 1) / TILE) * ((p->height + TILE - 1) / TILE);
     uint64_t c = (uint64_t)p->samples_per_pixel * tiles / 65536u;
     uint32_t cap = 64;    // measured on C2: 64..128 samples per pixel per unit is the optimum (256: -3 %, 32: -5 %)
+    // Scenes that exceed an XCD's L2 are bound by the L2 hit rate of the item gathers, i.e. by
+    // how much of the BVH the concurrently running waves touch.  Small chunks put many waves on the same tile at the
+    // same time (consecutive units = the chunks of one tile): C5 at 64 spp, 16 -> 38 Msamples/s going from 64 to 8.
+    if (s->hot_bytes > (4u << 20)) cap = 8;      // bigger than one XCD's L2
     if (const char *e = getenv("VK_CHUNK_CAP")) { int v = atoi(e); if (v >= 1) cap = (uint32_t)v; }   // diagnostics
     uint32_t lo = cap < 32 ? cap : 32;
     uint32_t chunk_spp = (uint32_t)(c > cap ? cap : (c < lo ? lo : c));
     uint32_t n = (p->samples_per_pixel + chunk_spp - 1) / chunk_spp;
+    // the chunk partials cost n x framebuffer bytes: keep them under 8 GiB
+    const uint64_t fb = (uint64_t)p->width * p->height * 12u;
+    while (n > 1 && (uint64_t)n * fb > (8ull << 30)) n = (n + 1) / 2;
     if (n < 1) n = 1;
     return n;
 }
@@ -762,6 +771,7 @@ int vk_scene_create(const vk_scene_desc *desc, int device, vk_scene **out) {
     if (hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { vk_scene_destroy(s); return fail(VK_ERR_HIP, "hipEventCreate failed"); }
     // LDS residency: items + spheres + accumulators must leave room for >= 2 workgroups per CU
     size_t hot = H.items.size() * sizeof(DItem) + H.spheres.size() * sizeof(DSphere) + H.boxes.size() * sizeof(DBox);
+    s->hot_bytes = hot;
     plan_residency(s, hot);
     *out = s;
     return VK_OK;

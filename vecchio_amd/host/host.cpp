@@ -292,6 +292,122 @@ std::shared_ptr<BVHNode> BVHNode::build(std::vector<HittableP> &objects, size_t 
     }
     return node;
 }
+static thread_local BvhBuilder g_builder = BvhBuilder::REFERENCE;
+void set_bvh_builder(BvhBuilder b) { g_builder = b; }
+BvhBuilder bvh_builder() { return g_builder; }
+
+std::shared_ptr<BVHNode> BVHNode::build(std::vector<HittableP> &objects) {
+    if (g_builder == BvhBuilder::SAH) {
+        std::vector<HittableP> scratch(objects);
+        (void)build(scratch, 0, scratch.size());          // consumes the reference's axis draws; tree discarded
+        return build_sah(objects);
+    }
+    return build(objects, 0, objects.size());
+}
+
+// ---- binned SAH builder (not in the reference: SURVEY §8f-2).  Same node shape as BVHNode::new produces
+// (two children; one object -> both children are that object; two objects -> a leaf), so the flat format,
+// the oracle and the kernel need nothing new.  Traversal order is fixed (left, then right with the left
+// hit's t as tmax, accel.rs:64-70), so the child with the larger surface area goes LEFT: large objects
+// (a ground sphere) are hit first and their t culls the boxes behind them.
+namespace {
+struct SahPrim { AxisBB bb; Vec3 c; HittableP obj; };
+inline float half_area(const AxisBB &b) {
+    float dx = b.max.x - b.min.x, dy = b.max.y - b.min.y, dz = b.max.z - b.min.z;
+    return dx * dy + dy * dz + dz * dx;
+}
+inline float axis_of(const Vec3 &v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+std::shared_ptr<BVHNode> sah_rec(std::vector<SahPrim> &P, size_t begin, size_t end, int depth) {
+    size_t len = end - begin;
+    auto node = std::make_shared<BVHNode>();
+    if (len == 1) {
+        node->left = P[begin].obj; node->right = P[begin].obj;
+        node->bb = AxisBB::surrounding_box(P[begin].bb, P[begin].bb);
+        return node;
+    }
+    if (len == 2) {
+        size_t a = begin, b = begin + 1;
+        if (half_area(P[b].bb) > half_area(P[a].bb)) std::swap(a, b);
+        node->left = P[a].obj; node->right = P[b].obj;
+        node->bb = AxisBB::surrounding_box(P[a].bb, P[b].bb);
+        return node;
+    }
+    // centroid bounds
+    Vec3 cmin = P[begin].c, cmax = P[begin].c;
+    for (size_t i = begin + 1; i < end; i++) {
+        cmin = Vec3(fminf(cmin.x, P[i].c.x), fminf(cmin.y, P[i].c.y), fminf(cmin.z, P[i].c.z));
+        cmax = Vec3(fmaxf(cmax.x, P[i].c.x), fmaxf(cmax.y, P[i].c.y), fmaxf(cmax.z, P[i].c.z));
+    }
+    const int NB = 32;
+    int best_axis = -1, best_split = 0; double best_cost = 1e300;
+    if (depth < 96) {
+        for (int ax = 0; ax < 3; ax++) {
+            float lo = axis_of(cmin, ax), hi = axis_of(cmax, ax);
+            if (!(hi > lo)) continue;
+            float scale = (float)NB / (hi - lo);
+            AxisBB bb[NB]; size_t cnt[NB]; bool used[NB];
+            for (int b = 0; b < NB; b++) { cnt[b] = 0; used[b] = false; }
+            for (size_t i = begin; i < end; i++) {
+                int b = (int)((axis_of(P[i].c, ax) - lo) * scale);
+                b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                bb[b] = used[b] ? AxisBB::surrounding_box(bb[b], P[i].bb) : P[i].bb;
+                used[b] = true; cnt[b]++;
+            }
+            // sweep: cost(split after bin s) = A(left)*n(left) + A(right)*n(right)
+            double la[NB]; size_t ln[NB];
+            AxisBB acc{}; bool have = false; size_t n = 0;
+            for (int b = 0; b < NB; b++) {
+                if (used[b]) { acc = have ? AxisBB::surrounding_box(acc, bb[b]) : bb[b]; have = true; n += cnt[b]; }
+                la[b] = have ? (double)half_area(acc) : 0.0; ln[b] = n;
+            }
+            have = false; n = 0;
+            for (int b = NB - 1; b >= 1; b--) {
+                if (used[b]) { acc = have ? AxisBB::surrounding_box(acc, bb[b]) : bb[b]; have = true; n += cnt[b]; }
+                if (n == 0 || ln[b - 1] == 0) continue;
+                double cost = la[b - 1] * (double)ln[b - 1] + (double)half_area(acc) * (double)n;
+                if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = b; }
+            }
+        }
+    }
+    size_t mid;
+    if (best_axis >= 0) {
+        float lo = axis_of(cmin, best_axis), hi = axis_of(cmax, best_axis);
+        float scale = (float)NB / (hi - lo);
+        int ax = best_axis, sp = best_split;
+        auto it = std::stable_partition(P.begin() + begin, P.begin() + end, [&](const SahPrim &q) {
+            int b = (int)((axis_of(q.c, ax) - lo) * scale);
+            b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+            return b < sp;
+        });
+        mid = (size_t)(it - P.begin());
+    } else {
+        mid = begin + len / 2;      // coincident centroids (or a runaway depth): split the slice in the middle
+    }
+    if (mid == begin || mid == end) mid = begin + len / 2;
+    auto l = sah_rec(P, begin, mid, depth + 1);
+    auto r = sah_rec(P, mid, end, depth + 1);
+    if (half_area(r->bb) > half_area(l->bb)) std::swap(l, r);
+    node->left = l; node->right = r;
+    node->bb = AxisBB::surrounding_box(l->bb, r->bb);
+    return node;
+}
+}  // namespace
+
+std::shared_ptr<BVHNode> BVHNode::build_sah(std::vector<HittableP> &objects) {
+    if (objects.empty()) throw std::runtime_error("BVHNode::new on an empty slice (index out of bounds in the reference)");
+    std::vector<SahPrim> P;
+    P.reserve(objects.size());
+    for (auto &h : objects) {
+        auto bb = h->bounding_box(0.0f, 0.0f);             // the boxes the reference builder uses (accel.rs:93)
+        if (!bb) throw std::runtime_error("bounding_box() is None (unwrap panics, accel.rs:93)");
+        if (bb->min.x != bb->min.x || bb->max.x != bb->max.x) throw std::runtime_error("NaN in bounding box");
+        Vec3 c((bb->min.x + bb->max.x) * 0.5f, (bb->min.y + bb->max.y) * 0.5f, (bb->min.z + bb->max.z) * 0.5f);
+        P.push_back(SahPrim{*bb, c, h});
+    }
+    return sah_rec(P, 0, P.size(), 0);
+}
+
 vk_ref BVHNode::flatten(FlatBuilder &b) const {
     vk_bvh_node n;
     n.bb_min[0] = bb.min.x; n.bb_min[1] = bb.min.y; n.bb_min[2] = bb.min.z;

@@ -28,6 +28,9 @@ vkh_scene *vkh_scene_build(const char *name, uint64_t seed) {
     try {
         seed_thread_rng(seed);
         std::string n(name);
+        // "<scene>+sah": every BVHNode::new of the scene runs the SAH builder instead (same objects, same geometry)
+        set_bvh_builder(BvhBuilder::REFERENCE);
+        if (n.size() > 4 && n.compare(n.size() - 4, 4, "+sah") == 0) { n.resize(n.size() - 4); set_bvh_builder(BvhBuilder::SAH); }
         auto s = new vkh_scene;
         if (n == "balls_demo") s->cfg = balls_demo();
         else if (n == "random_spheres_demo") s->cfg = random_spheres_demo();

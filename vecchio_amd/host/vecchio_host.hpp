@@ -290,10 +290,19 @@ class BVHNode : public Hittable {  // accel.rs:52-56,85-136
     HittableP left, right; AxisBB bb;
     // BVHNode::new (accel.rs:98-136): random axis, stable sort by bb.min[axis], split len/2
     static std::shared_ptr<BVHNode> build(std::vector<HittableP> &objects, size_t begin, size_t end);
-    static std::shared_ptr<BVHNode> build(std::vector<HittableP> &objects) { return build(objects, 0, objects.size()); }
+    static std::shared_ptr<BVHNode> build(std::vector<HittableP> &objects);
+    // binned surface-area-heuristic builder over the same leaf objects (opt-in, see set_bvh_builder)
+    static std::shared_ptr<BVHNode> build_sah(std::vector<HittableP> &objects);
     std::optional<AxisBB> bounding_box(float, float) const override { return bb; }
     vk_ref flatten(FlatBuilder &b) const override;
 };
+
+// Which builder BVHNode::build(objects) runs.  REFERENCE = accel.rs:98-136 (the default, and what every parity
+// fixture uses).  SAH builds a better tree over the same objects; it first runs the reference builder and
+// discards its tree so that the scene's random stream, hence its geometry, is identical in both modes.
+enum class BvhBuilder { REFERENCE, SAH };
+void set_bvh_builder(BvhBuilder b);
+BvhBuilder bvh_builder();
 
 // ------------------------------------------------------------------ main.rs:56-109 Camera::new
 vk_camera camera_new(Vec3 lookfrom, Vec3 lookat, Vec3 vup, float vfov, float aspect_ratio, float aperture,
