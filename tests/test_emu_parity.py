@@ -7,7 +7,7 @@ import pytest
 
 import special_scenes
 
-BUILDER_SCENES = ["random_spheres_iow", "cornell_box", "final_scene", "random_spheres_demo", "perlin_demo", "balls_demo",
+BUILDER_SCENES = ["random_spheres_iow", "cornell_box", "final_scene", "random_spheres_demo", "perlin_demo", "balls_demo", "bowser_demo",
                   "random_spheres_iow+sah", "final_scene+sah", "cornell_box+sah"]     # +sah: SURVEY 8f-2 builder, same objects
 
 

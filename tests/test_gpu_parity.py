@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4   # north_star: per-pixel f32 RGB delta vs the seeded CPU reference
 
-BUILDER_SCENES = ["random_spheres_iow", "cornell_box", "final_scene", "random_spheres_demo", "perlin_demo", "balls_demo",
+BUILDER_SCENES = ["random_spheres_iow", "cornell_box", "final_scene", "random_spheres_demo", "perlin_demo", "balls_demo", "bowser_demo",
                   "random_spheres_iow+sah", "final_scene+sah"]
 
 

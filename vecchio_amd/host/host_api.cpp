@@ -36,6 +36,7 @@ vkh_scene *vkh_scene_build(const char *name, uint64_t seed) {
         else if (n == "random_spheres_demo") s->cfg = random_spheres_demo();
         else if (n == "random_spheres_iow") s->cfg = random_spheres_iow(11);
         else if (n == "perlin_demo") s->cfg = perlin_demo();
+        else if (n == "bowser_demo") s->cfg = bowser_demo();
         else if (n == "cornell_box") s->cfg = cornell_box();
         else if (n == "final_scene") s->cfg = final_scene();
         else if (n.rfind("stress_spheres:", 0) == 0) {

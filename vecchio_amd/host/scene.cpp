@@ -134,6 +134,75 @@ SceneConfig perlin_demo() {
     return cfg;
 }
 
+// scene.rs:340-549: struct Bowser — 5 image-textured rects, a grey bottom, 26 Boxys, in a BVHNode.
+// (The reference wraps the BVH in a Hittable that forwards hit/bounding_box: a no-op here.)
+// assets/bowser_*.png and assets/twitter.png cannot ship: seeded synthetic images of the same role.
+static HittableP bowser_new(float x, float y, float z) {
+    std::vector<HittableP> world;
+    auto img = [](uint64_t seed) { return std::make_shared<Lambertian>(ImageTexture::synthetic_earth(256, 256, seed)); };
+    const float y0 = y - 1.875f, zf = z + 4.5f;
+    world.push_back(Rect::XYRect(x - 2.0f, x + 2.0f, y0 + 1.0f, y0 + 4.0f, zf - 3.0f, img(21)));     // face
+    world.push_back(Rect::XZRect(x - 2.0f, x + 2.0f, zf - 6.0f, zf - 3.0f, y0 + 4.0f, img(22)));     // top
+    world.push_back(Rect::XYRect(x - 2.0f, x + 2.0f, y0 + 1.0f, y0 + 4.0f, zf - 6.0f, img(23)));     // back
+    auto side = img(24);
+    world.push_back(Rect::YZRect(y0 + 1.0f, y0 + 4.0f, zf - 6.0f, zf - 3.0f, x - 2.0f, side));       // sides share one texture
+    world.push_back(Rect::YZRect(y0 + 1.0f, y0 + 4.0f, zf - 6.0f, zf - 3.0f, x + 2.0f, side));
+    auto grey = lambert(Vec3(0.278f, 0.387f, 0.438f));
+    world.push_back(Rect::XZRect(x - 2.0f, x + 2.0f, zf - 6.0f, zf - 3.0f, y0 + 1.0f, grey));        // bottom
+    auto box = [&](float ax, float ay, float az, float bx, float by, float bz, MaterialP m) {
+        world.push_back(std::make_shared<Boxy>(Vec3(x + ax, y0 + ay, zf + az), Vec3(x + bx, y0 + by, zf + bz), m));
+    };
+    // feet
+    box(-1.5f, 0.5f, -4.75f, -0.5f, 1.0f, -4.25f, grey);
+    box(0.5f, 0.5f, -4.75f, 1.5f, 1.0f, -4.25f, grey);
+    box(-1.5f, 0.25f, -4.75f, -0.5f, 0.5f, -3.5f, grey);
+    box(0.5f, 0.25f, -4.75f, 1.5f, 0.5f, -3.5f, grey);
+    // arms
+    auto brown = lambert(Vec3(0.4f, 0.2f, 0.1f));
+    box(-2.25f, 1.75f, -4.65f, -2.00f, 2.75f, -4.35f, brown);
+    box(-2.50f, 1.75f, -4.65f, -2.25f, 2.50f, -4.35f, brown);
+    box(-2.75f, 1.75f, -4.65f, -2.50f, 2.25f, -4.35f, brown);
+    box(2.00f, 1.75f, -4.65f, 2.25f, 2.75f, -4.35f, brown);
+    box(2.25f, 1.75f, -4.65f, 2.50f, 2.50f, -4.35f, brown);
+    box(2.50f, 1.75f, -4.65f, 2.75f, 2.25f, -4.35f, brown);
+    // face rim
+    auto lightgrey = lambert(Vec3(0.601f, 0.687f, 0.723f));
+    box(-2.0f, 3.875f, -3.00f, 2.0f, 4.00f, -2.875f, lightgrey);
+    box(-2.0f, 1.0f, -3.00f, 2.0f, 1.125f, -2.875f, lightgrey);
+    box(-2.0f, 1.125f, -3.00f, -1.875f, 3.875f, -2.875f, lightgrey);
+    box(1.875f, 1.125f, -3.00f, 2.0f, 3.875f, -2.875f, lightgrey);
+    // ports on the back
+    box(-1.875f, 1.625f, -6.125f, -0.875f, 1.75f, -6.0f, lightgrey);
+    box(-1.875f, 1.125f, -6.125f, -0.875f, 1.25f, -6.0f, lightgrey);
+    box(-1.875f, 1.25f, -6.125f, -1.750f, 1.625f, -6.0f, lightgrey);
+    box(-1.0f, 1.25f, -6.125f, -0.875f, 1.625f, -6.0f, lightgrey);
+    box(0.875f, 1.625f, -6.125f, 1.875f, 1.75f, -6.0f, lightgrey);
+    box(0.875f, 1.125f, -6.125f, 1.875f, 1.25f, -6.0f, lightgrey);
+    box(1.750f, 1.25f, -6.125f, 1.875f, 1.625f, -6.0f, lightgrey);
+    box(0.875f, 1.25f, -6.125f, 1.0f, 1.625f, -6.0f, lightgrey);
+    return BVHNode::build(world);
+}
+
+// scene.rs:551-628
+SceneConfig bowser_demo() {
+    SceneConfig cfg;
+    auto &world = cfg.world;
+    auto checker = std::make_shared<Checker>(solid(Vec3(0.1f, 0.1f, 0.1f)), solid(Vec3(0.9f, 0.9f, 0.9f)));
+    world.push_back(std::make_shared<Sphere>(Vec3(0.0f, -1000.0f, 0.0f), 1000.0f, std::make_shared<Lambertian>(checker)));
+    // Translate(RotateX(RotateY(RotateZ(Bowser, 0), 0), 0), (0, 1.625, -4.5)): three zero-angle rotations, kept
+    world.push_back(std::make_shared<Translate>(RotateX(RotateY(RotateZ(bowser_new(0.0f, 0.0f, 0.0f), 0.0f), 0.0f), 0.0f),
+                                                Vec3(0.0f, 1.625f, -4.5f)));
+    auto light_shape = Rect::XYRect(-2.0f, 2.0f, 1.0f, 4.0f, 3.0f,
+                                    std::make_shared<DiffuseLight>(ImageTexture::synthetic_earth(128, 128, 25)));   // image-textured emitter
+    world.push_back(std::make_shared<FlipFace>(light_shape));
+    cfg.lights.push_back(light_shape);
+    float aspect_ratio = 16.0f / 9.0f;
+    cfg.cam_iter = RotatingCamera(Vec3(0.0f, 2.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), 20.0f, aspect_ratio, 0.0f, 10.0f, 0.0f, 1.0f,
+                                  2.5f, -35.0f, 20.0f, 0.5f, 360.0f - 35.0f);
+    cfg.aspect_ratio = aspect_ratio;
+    return cfg;
+}
+
 // scene.rs:630-730
 SceneConfig cornell_box() {
     SceneConfig cfg;

@@ -327,6 +327,7 @@ std::function<bool(vk_camera &)> RotatingCamera(Vec3 lookat, Vec3 vup, float vfo
 SceneConfig balls_demo();            // scene.rs:93-165
 SceneConfig random_spheres_demo();   // scene.rs:167-284 (HEAD: checker ground, earth, sky light, PDF integrator)
 SceneConfig perlin_demo();           // scene.rs:286-338
+SceneConfig bowser_demo();           // scene.rs:340-628 (PNG assets replaced by seeded synthetic images)
 SceneConfig cornell_box();           // scene.rs:630-730
 SceneConfig final_scene();           // scene.rs:732-874
 // InOneWeekend-tag variant of random_spheres_demo (sphere-only, sky background, aperture 0.1;
