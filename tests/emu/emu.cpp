@@ -107,4 +107,35 @@ int emu_render(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
     return VK_OK;
 }
 
+// AxisBB::hit property test: the kernel's box step (reciprocal multiplies + margin, exact fallback) against the
+// reference's division sequence alone, for n (box, ray, tmax) triples.  decisions[i] bit0 = kernel's answer,
+// bit1 = slab_exact's answer, bit2 = the kernel took the exact fallback.
+void emu_box_decisions(const float *boxes, const float *rays, size_t n, uint8_t *decisions) {
+    for (size_t k = 0; k < n; k++) {
+        DItem it;
+        it.mnx = boxes[k * 6 + 0]; it.mxx = boxes[k * 6 + 1]; it.mny = boxes[k * 6 + 2]; it.mxy = boxes[k * 6 + 3];
+        it.mnz = boxes[k * 6 + 4]; it.mxz = boxes[k * 6 + 5];
+        it.w0 = ((uint32_t)DK_SPHERE << 28) | 1u; it.w1 = 0;      // a leaf: pend != 0 afterwards <=> box hit
+        Lane L;
+        memset(&L, 0, sizeof(L));
+        V3 o = v3(rays[k * 7 + 0], rays[k * 7 + 1], rays[k * 7 + 2]), d = v3(rays[k * 7 + 3], rays[k * 7 + 4], rays[k * 7 + 5]);
+        set_space(L, o, d);
+        L.T = rays[k * 7 + 6];
+        L.i = 0; L.end = 1; L.pend = 0;
+        GlobalMem M{&it, nullptr, nullptr, nullptr};
+        box_step_core<VKF_ALL_SCENE, GlobalMem>(L, M);
+        bool fast = L.pend != 0;
+        bool exact = slab_exact(it, o, d, T_MIN, rays[k * 7 + 6]);
+        // was the fallback taken?  the margin test exactly as box_step_core writes it
+        float x0 = (it.mnx - o.x) * L.inv.x, x1 = (it.mxx - o.x) * L.inv.x;
+        float y0 = (it.mny - o.y) * L.inv.y, y1 = (it.mxy - o.y) * L.inv.y;
+        float z0 = (it.mnz - o.z) * L.inv.z, z1 = (it.mxz - o.z) * L.inv.z;
+        float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));
+        float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), rays[k * 7 + 6]));
+        float dlt = hi - lo;
+        bool fb = !(fabsf(dlt) >= __builtin_fmaf(hi, 2.0e-6f, L.xnan));
+        decisions[k] = (uint8_t)((fast ? 1 : 0) | (exact ? 2 : 0) | (fb ? 4 : 0));
+    }
+}
+
 }  // extern "C"

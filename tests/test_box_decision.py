@@ -1,0 +1,74 @@
+"""AxisBB::hit (accel.rs:16-35) as the kernel evaluates it — reciprocal multiplies, one margin compare, the
+reference's division sequence only inside the margin — must give the reference's boolean for EVERY box, ray and
+tmax, including grazing rays, rays starting on a face, axis-parallel rays, zero/denormal/huge direction
+components, infinite tmax and the always-hit leaf boxes.  Millions of cases through the kernel's own
+box_step_core (tests/emu) against slab_exact alone."""
+import ctypes as C
+
+import numpy as np
+
+
+def decide(emu, boxes, rays):
+    lib = emu.load()
+    lib.emu_box_decisions.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    boxes = np.ascontiguousarray(boxes, np.float32)
+    rays = np.ascontiguousarray(rays, np.float32)
+    out = np.zeros(len(boxes), np.uint8)
+    lib.emu_box_decisions(boxes.ctypes.data, rays.ctypes.data, len(boxes), out.ctypes.data)
+    return out
+
+
+def make_boxes(rng, n, scale):
+    c = rng.uniform(-scale, scale, (n, 3))
+    h = rng.uniform(0.0, scale * 0.2, (n, 3)) * rng.choice([1.0, 1e-3, 0.0], (n, 3), p=[0.8, 0.15, 0.05])   # thin and flat boxes too
+    b = np.empty((n, 6), np.float32)
+    b[:, 0::2] = c - h
+    b[:, 1::2] = c + h
+    return b
+
+
+def test_fast_path_equals_reference_divisions(emu):
+    rng = np.random.default_rng(7)
+    n = 1_500_000
+    total_fb = 0
+    for scale in (1.0, 500.0):
+        boxes = make_boxes(rng, n, scale)
+        o = rng.uniform(-scale, scale, (n, 3)).astype(np.float32)
+        # a third of the rays aim exactly at a point ON the box (corner, edge, face or interior point): grazing cases
+        t = rng.uniform(0, 1, (n, 3)).astype(np.float32) * rng.choice([0.0, 1.0, 0.5], (n, 3)).astype(np.float32)
+        target = boxes[:, 0::2] + t * (boxes[:, 1::2] - boxes[:, 0::2])
+        d = (target - o).astype(np.float32) * rng.uniform(0.1, 3.0, (n, 1)).astype(np.float32)
+        rnd = rng.normal(size=(n, 3)).astype(np.float32)
+        pick = rng.uniform(size=n) < 0.35
+        d[~pick] = rnd[~pick]
+        # axis-parallel / degenerate components
+        z = rng.uniform(size=(n, 3)) < 0.03
+        d[z] = rng.choice(np.array([0.0, -0.0, 1e-38, 1e-31, 1e31, -1e-40], np.float32), int(z.sum()))
+        # origins on a face
+        onface = rng.uniform(size=n) < 0.1
+        o[onface, 0] = boxes[onface, 0]
+        tmax = rng.choice(np.array([np.inf, 1e30, 5.0, 0.5, 0.001, 0.0011], np.float32), n).astype(np.float32)
+        near = rng.uniform(size=n) < 0.3            # tmax right at the box: |target - o| / |d| is where the ray reaches `target`
+        with np.errstate(all="ignore"):
+            tt = (np.linalg.norm(target - o, axis=1) / np.linalg.norm(d, axis=1)).astype(np.float32)
+        tmax[near & np.isfinite(tt)] = tt[near & np.isfinite(tt)]
+        rays = np.concatenate([o, d, tmax[:, None]], 1)
+        dec = decide(emu, boxes, rays)
+        bad = ((dec & 1) != ((dec >> 1) & 1))
+        assert not bad.any(), f"{int(bad.sum())} of {n} decisions differ, first: box {boxes[bad][0]} ray {rays[bad][0]}"
+        total_fb += int(((dec >> 2) & 1).sum())
+        assert ((dec & 1) == 1).mean() > 0.05 and ((dec & 1) == 0).mean() > 0.05      # both outcomes well covered
+    assert 0 < total_fb < 0.2 * 2 * n          # the fallback is exercised, and is the exception
+
+
+def test_always_hit_leaf_boxes(emu):
+    """objects that sit beside a BVH child are leaves with a +-3e38 box: hit for every ray the reference could form"""
+    rng = np.random.default_rng(8)
+    n = 200_000
+    boxes = np.tile(np.array([-3e38, 3e38, -3e38, 3e38, -3e38, 3e38], np.float32), (n, 1))
+    o = rng.uniform(-1e4, 1e4, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32) * rng.choice(np.array([1.0, 1e-6, 1e6], np.float32), (n, 1))
+    tmax = rng.choice(np.array([np.inf, 10.0, 0.002], np.float32), n)
+    dec = decide(emu, boxes, np.concatenate([o, d, tmax[:, None]], 1))
+    assert ((dec & 1) == ((dec >> 1) & 1)).all()
+    assert (dec & 1).all()
