@@ -592,7 +592,10 @@ uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
     // paths of a unit finish) stays small, small enough that tiles of very different cost (fog, glass,
     // grazing rays over 1M spheres) are spread over many waves; small images get smaller chunks so that
     // there are still ~64K units for ~6K waves.
-    // A function of the image and spp only, never of the tile partition (see above).
+    // A function of the image, spp and scene only, never of the tile partition (see above).
+    // (Tried for the multi-GPU tail — one rank of 8 renders C2's 1/8 in 77.7 ms against 65.3 ideal: cutting the last
+    // chunk of every tile into 8 small ones and ordering the units chunk by chunk so that the launch ends on short
+    // units.  Slower, 80.4 ms: short units pay the per-unit drain; the tail is heavy tiles, not the last unit.)
     uint64_t tiles = (uint64_t)((p->width + TILE - 1) / TILE) * ((p->height + TILE - 1) / TILE);
     uint64_t c = (uint64_t)p->samples_per_pixel * tiles / 65536u;
     uint32_t cap = 64;    // measured on C2: 64..128 samples per pixel per unit is the optimum (256: -3 %, 32: -5 %)
