@@ -1,17 +1,21 @@
 // vk_api.hip — the HIP megakernel and the C ABI of include/vecchio_amd.h (libvecchio_amd.so).
 //
 // Kernel structure (gfx950 / CDNA4, wave64):
-//   * persistent workgroups of 256 threads (4 waves); each WAVE repeatedly pulls one work
-//     unit = (8x8-pixel tile, sample chunk) from a global atomic counter;
-//   * one ray per lane.  A lane whose path ended pulls the next (pixel, sample) of the
-//     wave's unit through a ballot + prefix-popcount ("active-ray compaction": lanes never
-//     idle while the unit still has samples); the RNG is keyed (seed, pixel, sample), so the
-//     result does not depend on which lane, wave or GPU traces a sample;
-//   * traversal is the stack-free threaded walk of vk_trace.h; when the linear BVH + sphere
-//     buffer fit, every workgroup stages them into its LDS (160 KB/CU on MI355X) once and all
-//     node/primitive fetches are ds_read_b128 instead of L1/L2 gathers;
-//   * per-pixel sums live in LDS (one float3 per tile pixel per wave, ds_add_f32), written
-//     once per unit: the framebuffer costs 12 B per pixel per launch;
+//   * persistent workgroups (512-768 threads, sized by plan_residency); each WAVE repeatedly pulls one
+//     work unit = (8x8-pixel tile, sample chunk) from a global atomic counter;
+//   * one ray per lane.  A lane whose path ended pulls the next (pixel, sample) of the wave's unit
+//     through a ballot + prefix-popcount ("active-ray compaction": lanes never idle while the unit
+//     still has samples); the RNG is keyed (seed, pixel, sample), so the result does not depend on
+//     which lane, wave or GPU traces a sample;
+//   * a wave-level phase scheduler runs, each round, the code of the state most lanes are in: BOX
+//     (box_steps: nested steps under one shrinking EXEC mask), PRIM light / heavy, SHADE + REFILL;
+//     lane state that only shading needs (throughput, radiance, RNG, depth) is parked in LDS between
+//     SHADE phases so the traversal loops fit 80 VGPRs (6 waves/SIMD) or 128 (4 waves/SIMD);
+//   * traversal is the stack-free threaded walk of vk_trace.h; when the linear BVH + spheres + boxes
+//     fit next to that per-wave state WITHOUT costing occupancy, every workgroup stages them into its
+//     LDS (160 KB/CU) once and item fetches are ds_read_b128; otherwise they are L1/L2 gathers;
+//   * per-pixel sums live in LDS (one float3 per tile pixel per wave, ds_add_f32), written once per
+//     unit as a chunk partial; resolve_kernel adds the partials of a pixel in chunk order;
 //   * no MFMA: there is no dense contraction in a path tracer.
 //
 // There is NO CPU fallback in this library: every entry point either runs on a gfx950
@@ -63,7 +67,7 @@ struct KArgs {
     uint32_t tile_rank, tile_world;
     uint32_t n_chunks;
     uint32_t lds_items, lds_spheres, lds_boxes;   // record counts staged into LDS (LDS variant)
-    unsigned long long *phase_stats;   // optional (diagnostic build of the kernel): 8 counters, see vk_debug_phase_stats
+    unsigned long long *phase_stats;   // optional (diagnostic build of the kernel): 16 counters, see vk_debug_phase_stats
 };
 
 // LDS-resident hot records
@@ -491,7 +495,7 @@ struct vk_scene {
     uint32_t sphere_waves = 6; // waves per SIMD of the sphere-only variant (8 was measured 3 % slower: it spills)
     uint32_t wgs_per_cu = 2;
     bool last_timed = false;
-    unsigned long long *phase_stats = nullptr;   // device, 8 counters (diagnostic kernel build)
+    unsigned long long *phase_stats = nullptr;   // device, 16 counters (diagnostic kernel build)
     bool want_phase_stats = false;
 };
 

@@ -42,9 +42,9 @@ VK_HD uint64_t f64_bits(double f) { return __builtin_bit_cast(uint64_t, f); }
 VK_HD double bits_f64(uint64_t u) { return __builtin_bit_cast(double, u); }
 
 // ---------------------------------------------------------------------------------------
-// Counter-based generator.  One stream per (seed, pixel, sample); draw i of a stream is
-// mix64(key + (i+1)*GAMMA) >> 32 (SplitMix64 used as a counter-mode hash).  Regenerating
-// a sample on any lane, wave or GPU therefore reproduces the same stream.
+// Counter-based generator.  One stream per (seed, pixel, sample): the 64-bit key is a SplitMix64 hash
+// of the triple, draw i of the stream is a 32-bit hash of (key, i) (next_u32 below).  Regenerating a
+// sample on any lane, wave or GPU therefore reproduces the same stream.
 struct Rng {
     uint64_t key;
     uint32_t ctr;
