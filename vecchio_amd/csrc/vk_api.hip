@@ -603,10 +603,15 @@ uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
     uint64_t tiles = (uint64_t)((p->width + TILE - 1) / TILE) * ((p->height + TILE - 1) / TILE);
     uint64_t c = (uint64_t)p->samples_per_pixel * tiles / 65536u;
     uint32_t cap = 64;    // measured on C2: 64..128 samples per pixel per unit is the optimum (256: -3 %, 32: -5 %)
-    // Scenes that exceed an XCD's L2 are bound by the L2 hit rate of the item gathers, i.e. by
-    // how much of the BVH the concurrently running waves touch.  Small chunks put many waves on the same tile at the
-    // same time (consecutive units = the chunks of one tile): C5 at 64 spp, 16 -> 38 Msamples/s going from 64 to 8.
-    if (s->hot_bytes > (4u << 20)) cap = 8;      // bigger than one XCD's L2
+    // Scenes that exceed an XCD's L2 (C5): tile costs are skewed by orders of magnitude (rays grazing a million
+    // spheres at the horizon) and one wave's 64-spp unit of the dearest tile was the critical path of the whole
+    // launch (C5 at 64 spp: 67 s, 28 s with 8-spp units).  Short units pay the per-unit drain (lanes idle while
+    // the unit's last paths finish), so: at least 8 units per tile, 8..32 spp each (C5 at 256 spp: 8 -> 44, 16 -> 54,
+    // 32 -> 55, 64 -> 45 Msamples/s).
+    if (s->hot_bytes > (4u << 20)) {      // bigger than one XCD's L2
+        uint32_t v = p->samples_per_pixel / 8u;
+        cap = v < 8u ? 8u : (v > 32u ? 32u : v);
+    }
     if (const char *e = getenv("VK_CHUNK_CAP")) { int v = atoi(e); if (v >= 1) cap = (uint32_t)v; }   // diagnostics
     uint32_t lo = cap < 32 ? cap : 32;
     uint32_t chunk_spp = (uint32_t)(c > cap ? cap : (c < lo ? lo : c));
