@@ -18,8 +18,8 @@ def variants():
     out = {}
     for blk in txt.split("Name: ")[1:]:
         name = blk.split("\n")[0].strip()
-        m = re.search(r"render_kernelILj(\d+)ELb([01])ELi(\d+)ELb([01])E", name)
-        if not m:
+        m = re.search(r"render_kernelILj(\d+)ELb([01])ELi(\d+)ELb([01])ELb([01])E", name)
+        if not m or m.group(5) == "1":      # ...ELb1E = the probe (COST) build: runs a few samples per pixel, not pinned
             continue
         get = lambda k: int(re.search(re.escape(k) + r": (\d+)", blk).group(1))
         out[(int(m.group(1)), m.group(2) == "1", int(m.group(3)), m.group(4) == "1")] = dict(

@@ -62,6 +62,8 @@ struct KArgs {
     float *partial;          // [n_chunks][width*height*3] when n_chunks > 1
     float4 *debug;           // optional per-sample (rgb, draws) dump
     uint32_t *counter;       // work-unit counter
+    uint32_t *tile_cost;     // [tiles of the image] time spent on each tile (1.6 us ticks): written by the probe (COST) build only
+    const uint32_t *tile_order;   // [n_local_tiles] local tile slots, dearest first (from the probe launch), or null = raster order
     uint32_t tiles_x, tiles_y;
     uint32_t n_local_tiles;  // tiles of this call's partition
     uint32_t tile_rank, tile_world;
@@ -175,10 +177,20 @@ __device__ __forceinline__ void cold_load_world_ray(const float *c, uint32_t lan
     }
 }
 
+// LDS word of a wave that holds the time its previous unit ended.  Re-derived from freshly loaded kernel arguments at
+// its uses (kernel start, unit end) so that no pointer stays live across the traversal loops.
+template <uint32_t F, bool LDS_SCENE>
+__device__ __forceinline__ uint32_t *unit_t0_word(uint32_t wave) {
+    KArgsC P = kargs_fresh();
+    uint32_t scene16 = LDS_SCENE ? 2u * KARG(P, lds_items) + KARG(P, lds_spheres) + 2u * KARG(P, lds_boxes) : 0u;
+    float *dyn = reinterpret_cast<float *>(smem + scene16);
+    return reinterpret_cast<uint32_t *>(dyn + (blockDim.x >> 6) * (64 * 3 + 64 * ncold<F>())) + wave;
+}
+
 // number of lanes of the wave for which p holds (v_cmp -> s_bcnt1, no VGPR round trip)
 __device__ __forceinline__ uint32_t lanes_with(bool p) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
 
-template <uint32_t F, bool LDS_SCENE, int MINW, bool STATS>
+template <uint32_t F, bool LDS_SCENE, int MINW, bool STATS, bool COST = false>
 __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ? 768 : 1024))), MINW) void render_kernel(KArgs A_byval) {
     (void)A_byval;
     const uint32_t lane = threadIdx.x & 63u;
@@ -211,6 +223,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
         }
     }
 
+    if (COST) { if (lane == 0) *unit_t0_word<F, LDS_SCENE>(wave) = (uint32_t)(wall_clock64() >> 4); }
     // (per-XCD work queues — contiguous image bands per XCD, stealing when empty — were tried for L2 locality on
     // C5: no gain there, -1.7 % on C2, and the two extra live scalars doubled the everything-variant's spills)
     for (;;) {
@@ -221,7 +234,10 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
         const uint32_t n_chunks = KARG(U, n_chunks);
         if (unit >= KARG(U, n_local_tiles) * n_chunks) break;
         const uint32_t chunk = unit % n_chunks;
-        const uint32_t tile = KARG(U, tile_rank) + (unit / n_chunks) * KARG(U, tile_world);
+        // tiles are visited dearest-first when the probe launch left an order (see enqueue_render)
+        uint32_t tslot = unit / n_chunks;
+        { const uint32_t *ord = KARG(U, tile_order); if (ord) tslot = ord[tslot]; }
+        const uint32_t tile = KARG(U, tile_rank) + tslot * KARG(U, tile_world);
         const uint32_t tiles_x = KARG(U, tiles_x);
         const uint32_t tx = (tile % tiles_x) * TILE, ty = (tile / tiles_x) * TILE;
         const uint32_t spp = KARG(U, C.spp);
@@ -395,6 +411,15 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
         // ---- write the unit's pixel sums
         {
             KArgsC P = kargs_fresh();
+            if (COST) {   // probe launch: time since this wave's previous unit ended = this unit's cost (units run back to back)
+                uint32_t *tc = KARG(P, tile_cost);
+                if (tc && lane == 0) {
+                    uint32_t *w = unit_t0_word<F, LDS_SCENE>(wave);
+                    uint32_t now = (uint32_t)(wall_clock64() >> 4);
+                    atomicAdd(&tc[(ty / TILE) * KARG(P, tiles_x) + tx / TILE], now - *w);
+                    *w = now;
+                }
+            }
             uint32_t width = KARG(P, C.width), height = KARG(P, C.height);
             uint32_t px = tx + (lane & 7u), py = ty + (lane >> 3);
             if (px < width && py < height) {
@@ -422,6 +447,30 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             atomicAdd(&ps[13], st_t_mat); atomicAdd(&ps[14], st_t_refill); atomicAdd(&ps[15], st_t_install);
         }
     }
+}
+
+// ---- heavy-first tile order (bucket sort of the probe's per-tile times, dearest first).
+// 8 buckets per octave of cost; the order inside a bucket is arbitrary, which is fine: any order renders the same image.
+constexpr uint32_t ORDER_BUCKETS = 256;
+__device__ __forceinline__ uint32_t cost_bucket(uint32_t c) {
+    if (c < 8u) return c;
+    uint32_t msb = 31u - (uint32_t)__builtin_clz(c);
+    uint32_t b = (msb - 2u) * 8u + ((c >> (msb - 3u)) & 7u);
+    return b < ORDER_BUCKETS ? b : ORDER_BUCKETS - 1u;
+}
+__global__ void order_hist_kernel(const uint32_t *cost, uint32_t n_local, uint32_t tile_rank, uint32_t tile_world, uint32_t *hist) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_local) atomicAdd(&hist[cost_bucket(cost[tile_rank + i * tile_world])], 1u);
+}
+__global__ void order_scan_kernel(uint32_t *hist) {      // one thread: start offset of every bucket, dearest bucket first
+    uint32_t run = 0;
+    for (int b = (int)ORDER_BUCKETS - 1; b >= 0; b--) { uint32_t c = hist[b]; hist[b] = run; run += c; }
+}
+__global__ void order_scatter_kernel(uint32_t *cost, uint32_t n_local, uint32_t tile_rank, uint32_t tile_world, uint32_t *hist, uint32_t *order) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_local) return;
+    uint32_t t = tile_rank + i * tile_world;
+    order[atomicAdd(&hist[cost_bucket(cost[t])], 1u)] = i;
 }
 
 // sums the sample chunks of each pixel in chunk order (deterministic) and divides by spp
@@ -497,6 +546,9 @@ struct vk_scene {
     bool last_timed = false;
     unsigned long long *phase_stats = nullptr;   // device, 16 counters (diagnostic kernel build)
     bool want_phase_stats = false;
+    // heavy-first tile order: per-tile times of the probe launch and the order derived from them
+    uint32_t *tile_cost = nullptr, *tile_order = nullptr, *order_hist = nullptr;
+    size_t tile_cost_n = 0, tile_order_n = 0;
 };
 
 namespace {
@@ -522,7 +574,7 @@ uint32_t pick_variant(uint32_t features) {
 }
 
 size_t per_wave_lds_bytes(uint32_t F) {   // pixel accumulators + cold lane state of one wave
-    return (size_t)64 * (3 + ((F & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE)) * sizeof(float);
+    return (size_t)64 * (3 + ((F & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE)) * sizeof(float) + sizeof(uint32_t);   // + the unit's start time
 }
 
 // LDS residency plan.  `hot` = bytes of items + spheres + boxes.  Measured on MI355X with the VALU-bound
@@ -556,21 +608,36 @@ void plan_residency(vk_scene *s, size_t hot) {
 }
 
 template <uint32_t F, int MINW_SPHERES = 6>
-int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st) {
+int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st, bool cost) {
     // register budget: the sphere-only kernels fit 80 VGPRs (6 waves per SIMD, 24 per CU), the others are held to 128 (4 per SIMD)
     constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? MINW_SPHERES : 4;
     // (global-memory traversal — C5, 33 MB of items — was also tried at 8 waves per SIMD / 64 VGPRs: 8 % slower.
     // It is bound by the L2-miss path: every box step gathers a 32-byte item but moves a 128-byte line,
     // ~3.5 TB/s of lines from the Infinity Cache at 21 Msamples/s; more waves in flight do not help.)
-    if (lds) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<F, true, MINW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL((render_kernel<F, true, MINW, false>), grid, dim3(s->wg_threads), shmem, st, A);
-    } else {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<F, false, MINW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL((render_kernel<F, false, MINW, false>), grid, dim3(s->wg_threads), shmem, st, A);
-    }
+    auto go = [&](auto kernel) -> int {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(kernel, grid, dim3(s->wg_threads), shmem, st, A);
+        return VK_OK;
+    };
+    int rc;
+    if (cost) rc = lds ? go(&render_kernel<F, true, MINW, false, true>) : go(&render_kernel<F, false, MINW, false, true>);
+    else rc = lds ? go(&render_kernel<F, true, MINW, false, false>) : go(&render_kernel<F, false, MINW, false, false>);
+    if (rc != VK_OK) return rc;
     HIP_TRY(hipGetLastError());
     return VK_OK;
+}
+
+// cost = the probe build of the variant (per-tile times into A.tile_cost)
+int launch_by_features(vk_scene *s, uint32_t F, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st, bool cost) {
+    const uint32_t F_CORNELL = VKF_RECT | VKF_LIST | VKF_INSTANCE | VKF_BOX;
+    switch (F) {
+        case 0u: return launch_variant<0u>(s, A, lds, grid, shmem, st, cost);
+        case VKF_INTEG_PDF: return launch_variant<VKF_INTEG_PDF>(s, A, lds, grid, shmem, st, cost);
+        case F_CORNELL: return launch_variant<F_CORNELL>(s, A, lds, grid, shmem, st, cost);
+        case F_CORNELL | VKF_INTEG_PDF: return launch_variant<(F_CORNELL | VKF_INTEG_PDF)>(s, A, lds, grid, shmem, st, cost);
+        case VKF_ALL_SCENE: return launch_variant<VKF_ALL_SCENE>(s, A, lds, grid, shmem, st, cost);
+        default: return launch_variant<(VKF_ALL_SCENE | VKF_INTEG_PDF)>(s, A, lds, grid, shmem, st, cost);
+    }
 }
 
 int check_render_args(vk_scene *scene, const vk_camera *cam, const vk_render_params *p) {
@@ -642,6 +709,28 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
     A.n_local_tiles = tiles > p->tile_rank ? (tiles - p->tile_rank + world - 1) / world : 0;
     A.n_chunks = choose_chunks(s, p);
     A.counter = s->counter;
+    // Heavy-first tile order.  A launch ends when its slowest unit does, and tile costs are skewed (C2's glass tiles cost 8x
+    // the mean, units that start mid-launch finish last).  So a probe launch of a few samples per pixel times every tile
+    // (the COST build of the same kernel variant), three tiny kernels bucket-sort the tiles dearest first, and the real
+    // launch takes its units in that order (longest processing time first).  The order never changes a pixel.
+    // One rank's 1/8 share of C2: 78.1 -> 66.9 ms (ideal 65.0); whole frame 522 -> 519 ms including the probe.
+    bool use_order = A.n_local_tiles >= 64 && p->samples_per_pixel >= 64;
+    if (const char *e = getenv("VK_TILE_ORDER")) use_order = use_order && e[0] != '0';      // diagnostics
+    if (use_order) {
+        if (tiles > s->tile_cost_n) {
+            if (s->tile_cost) HIP_TRY(hipFree(s->tile_cost));
+            s->tile_cost = nullptr; s->tile_cost_n = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->tile_cost), (size_t)tiles * sizeof(uint32_t)));
+            s->tile_cost_n = tiles;
+        }
+        if (A.n_local_tiles > s->tile_order_n) {
+            if (s->tile_order) HIP_TRY(hipFree(s->tile_order));
+            s->tile_order = nullptr; s->tile_order_n = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->tile_order), (size_t)A.n_local_tiles * sizeof(uint32_t)));
+            s->tile_order_n = A.n_local_tiles;
+        }
+        if (!s->order_hist) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->order_hist), ORDER_BUCKETS * sizeof(uint32_t)));
+    }
     size_t n_pixels = (size_t)p->width * p->height;
     if (A.n_chunks > 1) {
         size_t need = (size_t)A.n_chunks * n_pixels * 3 * sizeof(float);
@@ -676,9 +765,28 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
     if (grid > need_wgs) grid = need_wgs;
     if (grid < 1) grid = 1;
 
-    HIP_TRY(hipMemsetAsync(s->counter, 0, sizeof(uint32_t), st));
     HIP_TRY(hipEventRecord(s->ev0, st));
     uint32_t F = pick_variant(s->host.features) | (p->integrator == VK_INTEGRATOR_PDF ? (uint32_t)VKF_INTEG_PDF : 0u);
+    if (use_order && !s->want_phase_stats) {
+        KArgs B = A;                                   // the probe: the same view at 1..4 samples per pixel, one unit per tile
+        B.C.spp = p->samples_per_pixel / 256u; B.C.spp = B.C.spp < 1u ? 1u : (B.C.spp > 4u ? 4u : B.C.spp);
+        B.n_chunks = 1; B.partial = nullptr; B.debug = nullptr; B.tile_order = nullptr;
+        B.tile_cost = s->tile_cost;                    // its pixels land in d_out and are overwritten by the real launch
+        HIP_TRY(hipMemsetAsync(s->tile_cost, 0, (size_t)tiles * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(s->counter, 0, sizeof(uint32_t), st));
+        uint32_t pgrid = (uint32_t)s->num_cus * s->wgs_per_cu, pneed = (A.n_local_tiles + waves_per_wg - 1) / waves_per_wg;
+        if (pgrid > pneed) pgrid = pneed;
+        rc = launch_by_features(s, F, B, lds, dim3(pgrid), shmem, st, true);
+        if (rc != VK_OK) return rc;
+        uint32_t nb = (A.n_local_tiles + 255u) / 256u;
+        HIP_TRY(hipMemsetAsync(s->order_hist, 0, ORDER_BUCKETS * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(order_hist_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t *)s->tile_cost, A.n_local_tiles, A.tile_rank, A.tile_world, s->order_hist);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1), 0, st, s->order_hist);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, st, s->tile_cost, A.n_local_tiles, A.tile_rank, A.tile_world, s->order_hist, s->tile_order);
+        HIP_TRY(hipGetLastError());
+        A.tile_order = s->tile_order;
+    }
+    HIP_TRY(hipMemsetAsync(s->counter, 0, sizeof(uint32_t), st));
     if (s->want_phase_stats) {
         const uint32_t FULLPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
         if ((F != 0u && F != FULLPDF) || !lds) return fail(VK_ERR_UNSUPPORTED, "phase statistics are only built for the LDS-resident sphere-only and full/PDF variants");
@@ -695,16 +803,7 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
         HIP_TRY(hipGetLastError());
         F = 0xFFFFFFFFu;   // launched
     }
-    const uint32_t F_CORNELL = VKF_RECT | VKF_LIST | VKF_INSTANCE | VKF_BOX;
-    switch (F) {
-        case 0xFFFFFFFFu: break;
-        case 0u: rc = launch_variant<0u>(s, A, lds, dim3(grid), shmem, st); break;
-        case VKF_INTEG_PDF: rc = launch_variant<VKF_INTEG_PDF>(s, A, lds, dim3(grid), shmem, st); break;
-        case F_CORNELL: rc = launch_variant<F_CORNELL>(s, A, lds, dim3(grid), shmem, st); break;
-        case F_CORNELL | VKF_INTEG_PDF: rc = launch_variant<(F_CORNELL | VKF_INTEG_PDF)>(s, A, lds, dim3(grid), shmem, st); break;
-        case VKF_ALL_SCENE: rc = launch_variant<VKF_ALL_SCENE>(s, A, lds, dim3(grid), shmem, st); break;
-        default: rc = launch_variant<(VKF_ALL_SCENE | VKF_INTEG_PDF)>(s, A, lds, dim3(grid), shmem, st); break;
-    }
+    if (F != 0xFFFFFFFFu) rc = launch_by_features(s, F, A, lds, dim3(grid), shmem, st, false);
     if (rc != VK_OK) return rc;
     uint32_t launches = 1;
     if (A.n_chunks > 1) {
@@ -798,6 +897,9 @@ void vk_scene_destroy(vk_scene *s) {
     if (s->partial) (void)hipFree(s->partial);
     if (s->debug) (void)hipFree(s->debug);
     if (s->phase_stats) (void)hipFree(s->phase_stats);
+    if (s->tile_cost) (void)hipFree(s->tile_cost);
+    if (s->tile_order) (void)hipFree(s->tile_order);
+    if (s->order_hist) (void)hipFree(s->order_hist);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
