@@ -6,6 +6,8 @@ host/device arithmetic, tile-partition invariance, determinism, error codes, and
 the BASELINE sizes."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -113,6 +115,13 @@ def test_tile_partition_and_determinism(device, host_scenes):
             pr = hs.params(200, 300, 50, tile_rank=r, tile_world=world)
             ds.render(cam, pr, out=acc)
         assert np.array_equal(acc, full), f"{world}-way tile partition changed pixel values"
+    # the heavy-first tile order (probe launch + bucket sort) only decides who renders a tile when
+    os.environ["VK_TILE_ORDER"] = "0"
+    try:
+        raster, _ = ds.render(cam, p)
+    finally:
+        del os.environ["VK_TILE_ORDER"]
+    assert np.array_equal(raster, full), "tile order changed pixel values"
     ds.close()
 
 
