@@ -11,7 +11,8 @@ out = {"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv
 for f in sorted(glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "render_kernel" in r["Kernel_Name"]:
+        # the production build of the megakernel only (..., false, false>): not the probe (COST) launch that precedes it
+        if "render_kernel" in r["Kernel_Name"] and ", true>(" not in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             out["dispatch"] = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
     for k, v in agg.items():
