@@ -713,7 +713,7 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
     // the mean, units that start mid-launch finish last).  So a probe launch of a few samples per pixel times every tile
     // (the COST build of the same kernel variant), three tiny kernels bucket-sort the tiles dearest first, and the real
     // launch takes its units in that order (longest processing time first).  The order never changes a pixel.
-    // One rank's 1/8 share of C2: 78.1 -> 66.9 ms (ideal 65.0); whole frame 522 -> 519 ms including the probe.
+    // One rank's 1/8 share of C2: 78.1 -> 68.6 ms (ideal 64.9); whole frame 522 -> 519 ms including the probe.
     bool use_order = A.n_local_tiles >= 64 && p->samples_per_pixel >= 64;
     if (const char *e = getenv("VK_TILE_ORDER")) use_order = use_order && e[0] != '0';      // diagnostics
     if (use_order) {
@@ -769,7 +769,9 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
     uint32_t F = pick_variant(s->host.features) | (p->integrator == VK_INTEGRATOR_PDF ? (uint32_t)VKF_INTEG_PDF : 0u);
     if (use_order && !s->want_phase_stats) {
         KArgs B = A;                                   // the probe: the same view at 1..4 samples per pixel, one unit per tile
-        B.C.spp = p->samples_per_pixel / 256u; B.C.spp = B.C.spp < 1u ? 1u : (B.C.spp > 4u ? 4u : B.C.spp);
+        // (C2, one rank's 1/8 share: probe of 1 / 2 / 4 / 8 / 16 spp -> 68.6 / 69.0 / 69.8 / 70.5 / 73.0 ms: more samples cost more than they sort better)
+        B.C.spp = p->samples_per_pixel / 1024u; B.C.spp = B.C.spp < 1u ? 1u : (B.C.spp > 4u ? 4u : B.C.spp);
+        if (const char *e = getenv("VK_PROBE_SPP")) { int v = atoi(e); if (v >= 1 && (uint32_t)v <= p->samples_per_pixel) B.C.spp = (uint32_t)v; }   // diagnostics
         B.n_chunks = 1; B.partial = nullptr; B.debug = nullptr; B.tile_order = nullptr;
         B.tile_cost = s->tile_cost;                    // its pixels land in d_out and are overwritten by the real launch
         HIP_TRY(hipMemsetAsync(s->tile_cost, 0, (size_t)tiles * sizeof(uint32_t), st));
