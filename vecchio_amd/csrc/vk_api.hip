@@ -47,7 +47,6 @@ int fail(int code, const std::string &m) { g_err = m; return code; }
         if (_e != hipSuccess) return fail(VK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
-constexpr int MAX_WG_THREADS = 1024;   // 16 waves = 4 per SIMD: the register budget (<= 128 VGPRs) every variant is held to
 constexpr size_t LDS_PER_CU = 160 * 1024;
 constexpr int TILE = 8;   // 8x8 pixels = one wave
 #ifndef VK_BOX_UNROLL
