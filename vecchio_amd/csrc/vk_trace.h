@@ -397,8 +397,9 @@ VK_HD void box_step_core(Lane &L, const Mem &M) {
     // both forms compute fl(b-o) identically and q~ = fl(fl(b-o)*fl(1/d)) differs from the reference's
     // fl(fl(b-o)/d) by < 3*2^-24 relative; the three per-axis early-outs equal one test
     // max(lo..) < min(hi..) because lo only grows and hi only shrinks.
-    // (scalar on purpose: v_pk_add_f32/v_pk_mul_f32 on (min,max) pairs was measured 5 % SLOWER —
-    // the broadcast operands need register pairs, which costs occupancy)
+    // (scalar on purpose: v_pk_add_f32/v_pk_mul_f32 on the (min,max) pair of each axis was measured SLOWER twice —
+    // -5 % as compiler vectors (the broadcast operands get materialised as register pairs), -14 % as inline asm
+    // with op_sel broadcasts of (o.x,o.y)/(inv.x,inv.y)/(o.z,inv.z): the packed ops do not issue at twice the rate here)
     float x0 = (n.mnx - L.o.x) * L.inv.x, x1 = (n.mxx - L.o.x) * L.inv.x;
     float y0 = (n.mny - L.o.y) * L.inv.y, y1 = (n.mxy - L.o.y) * L.inv.y;
     float z0 = (n.mnz - L.o.z) * L.inv.z, z1 = (n.mxz - L.o.z) * L.inv.z;
