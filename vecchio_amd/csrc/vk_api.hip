@@ -52,6 +52,15 @@ constexpr int TILE = 8;   // 8x8 pixels = one wave
 #ifndef VK_BOX_UNROLL
 #define VK_BOX_UNROLL 4
 #endif
+// The scheduler runs SHADE + REFILL only when its lanes outnumber the box lanes AND the primitive lanes SHADE_DEFER
+// times over: a shading phase costs ~700 issue slots against ~42 of a box step, so it pays to keep traversing with
+// thinning waves until nearly every lane waits for shading and then shade them all at once.  C2 / C4, Msamples/s:
+// 1 (plain plurality): 4 070 / 3 435; 1.5: 4 270 / 3 645; 2: 4 430 / 3 725; 3: 4 580 / 3 815; 4: 4 630 / 3 820;
+// 8: 4 600 / 3 765.  (Deferring only against BOX, not PRIM: 4 150.)
+#ifndef VK_SHADE_DEFER
+#define VK_SHADE_DEFER 4
+#endif
+constexpr uint32_t SHADE_DEFER = VK_SHADE_DEFER;
 constexpr int BOX_UNROLL = VK_BOX_UNROLL;   // box steps between two exit tests of the BOX loop
 
 struct KArgs {
@@ -278,7 +287,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             uint32_t n_sn = lanes_with(is_shade || need);
             if ((n_box | n_prim | n_sn) == 0) break;
             if (STATS) st_sched++;
-            if (n_box >= n_prim && n_box >= n_sn) {
+            if (n_box >= n_prim && n_box * SHADE_DEFER >= n_sn) {
                 // ---- BOX: UNROLL steps under a shrinking EXEC mask per exit test, while box lanes are the plurality
                 KArgsC P = kargs_fresh();
                 DScene S = KARG(P, S);
@@ -308,10 +317,10 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     uint32_t nb = lanes_with(is_box);
                     uint32_t np = lanes_with(active && has_prim_work(L));
                     uint32_t ns = live - nb - np;
-                    if (nb == 0 || nb < np || nb < ns) {               // another state now has more lanes parked than are stepping
+                    if (nb == 0 || nb < np || nb * SHADE_DEFER < ns) {               // another state now has more lanes parked than are stepping
                         // sphere-only variants: when that state is PRIM, test the pending spheres right here and
                         // keep stepping (saves the scheduler round trip that otherwise follows every ~10 box steps)
-                        if (!HAS_HEAVY && !(F & VKF_MEDIUM) && np != 0 && np >= ns) {
+                        if (!HAS_HEAVY && !(F & VKF_MEDIUM) && np != 0 && np * SHADE_DEFER >= ns) {
                             if (active && has_prim_work(L)) prim_step<F, Mem>(L, S, M);
                             is_box = active && !has_prim_work(L) && traversing(L);
                             continue;
@@ -320,7 +329,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     }
                 }
                 if (STATS) st_t_box += clock64() - st_t0;
-            } else if (n_prim >= n_sn) {
+            } else if (n_prim * SHADE_DEFER >= n_sn) {
                 // ---- PRIM: intersect / enter the pending object
                 KArgsC P = kargs_fresh();
                 DScene S = KARG(P, S);
