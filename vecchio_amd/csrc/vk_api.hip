@@ -56,7 +56,9 @@ constexpr int TILE = 8;   // 8x8 pixels = one wave
 // times over: a shading phase costs ~700 issue slots against ~42 of a box step, so it pays to keep traversing with
 // thinning waves until nearly every lane waits for shading and then shade them all at once.  C2 / C4, Msamples/s:
 // 1 (plain plurality): 4 070 / 3 435; 1.5: 4 270 / 3 645; 2: 4 430 / 3 725; 3: 4 580 / 3 815; 4: 4 630 / 3 820;
-// 8: 4 600 / 3 765.  (Deferring only against BOX, not PRIM: 4 150.)
+// 8: 4 600 / 3 765.  (Deferring only against BOX, not PRIM: 4 150.)  Scenes that miss L2 (C5) are bound by the
+// latency of the item gathers, not by issue slots: there every parked lane is a gather less in flight, and plain
+// plurality is better (C5: 69 against 58 Msamples/s), so the factor is a launch parameter.
 #ifndef VK_SHADE_DEFER
 #define VK_SHADE_DEFER 4
 #endif
@@ -76,6 +78,7 @@ struct KArgs {
     uint32_t n_local_tiles;  // tiles of this call's partition
     uint32_t tile_rank, tile_world;
     uint32_t n_chunks;
+    uint32_t shade_defer;    // SHADE + REFILL runs when its lanes outnumber box and primitive lanes this many times (see SHADE_DEFER)
     uint32_t lds_items, lds_spheres, lds_boxes;   // record counts staged into LDS (LDS variant)
     unsigned long long *phase_stats;   // optional (diagnostic build of the kernel): 16 counters, see vk_debug_phase_stats
 };
@@ -271,6 +274,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
         //   NEED   no path; the unit still has (pixel, sample) items     -> start_sample
         // SHADE and NEED run as one phase: a path that ends hands its lane straight to the
         // next item (ballot + prefix popcount = active-ray compaction).
+        const uint32_t shade_defer = KARG(U, shade_defer);
         for (;;) {
             bool is_prim = active && has_prim_work(L);
             bool is_box = active && !is_prim && traversing(L);
@@ -287,7 +291,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             uint32_t n_sn = lanes_with(is_shade || need);
             if ((n_box | n_prim | n_sn) == 0) break;
             if (STATS) st_sched++;
-            if (n_box >= n_prim && n_box * SHADE_DEFER >= n_sn) {
+            if (n_box >= n_prim && n_box * shade_defer >= n_sn) {
                 // ---- BOX: UNROLL steps under a shrinking EXEC mask per exit test, while box lanes are the plurality
                 KArgsC P = kargs_fresh();
                 DScene S = KARG(P, S);
@@ -317,10 +321,10 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     uint32_t nb = lanes_with(is_box);
                     uint32_t np = lanes_with(active && has_prim_work(L));
                     uint32_t ns = live - nb - np;
-                    if (nb == 0 || nb < np || nb * SHADE_DEFER < ns) {               // another state now has more lanes parked than are stepping
+                    if (nb == 0 || nb < np || nb * shade_defer < ns) {               // another state now has more lanes parked than are stepping
                         // sphere-only variants: when that state is PRIM, test the pending spheres right here and
                         // keep stepping (saves the scheduler round trip that otherwise follows every ~10 box steps)
-                        if (!HAS_HEAVY && !(F & VKF_MEDIUM) && np != 0 && np * SHADE_DEFER >= ns) {
+                        if (!HAS_HEAVY && !(F & VKF_MEDIUM) && np != 0 && np * shade_defer >= ns) {
                             if (active && has_prim_work(L)) prim_step<F, Mem>(L, S, M);
                             is_box = active && !has_prim_work(L) && traversing(L);
                             continue;
@@ -329,7 +333,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     }
                 }
                 if (STATS) st_t_box += clock64() - st_t0;
-            } else if (n_prim * SHADE_DEFER >= n_sn) {
+            } else if (n_prim * shade_defer >= n_sn) {
                 // ---- PRIM: intersect / enter the pending object
                 KArgsC P = kargs_fresh();
                 DScene S = KARG(P, S);
@@ -717,6 +721,8 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
     A.n_local_tiles = tiles > p->tile_rank ? (tiles - p->tile_rank + world - 1) / world : 0;
     A.n_chunks = choose_chunks(s, p);
     A.counter = s->counter;
+    A.shade_defer = s->hot_bytes > (4u << 20) ? 1u : SHADE_DEFER;
+    if (const char *e = getenv("VK_SHADE_DEFER")) { int v = atoi(e); if (v >= 1 && v <= 64) A.shade_defer = (uint32_t)v; }   // diagnostics
     // Heavy-first tile order.  A launch ends when its slowest unit does, and tile costs are skewed (C2's glass tiles cost 8x
     // the mean, units that start mid-launch finish last).  So a probe launch of a few samples per pixel times every tile
     // (the COST build of the same kernel variant), three tiny kernels bucket-sort the tiles dearest first, and the real
