@@ -391,7 +391,7 @@ VK_HD bool prim_is_heavy(uint32_t ref) { uint32_t k = VKD_KIND(ref); return k >=
 // bookkeeping is a handful of VALU selects (a fully predicated version that kept all 64 lanes in
 // EXEC and re-did item 0 on idle lanes spent 14 of its 45 VALU instructions on selects).
 template <uint32_t F, class Mem>
-VK_HD void box_step_core(Lane &L, const Mem &M) {
+VK_HD bool box_step_core(Lane &L, const Mem &M) {      // returns: a leaf's box was hit (objects queued in pend)
     DItem n = M.item(L.i);
     // AxisBB::hit decided from reciprocal multiplies; same boolean as the reference's (see slab_exact):
     // both forms compute fl(b-o) identically and q~ = fl(fl(b-o)*fl(1/d)) differs from the reference's
@@ -414,9 +414,11 @@ VK_HD void box_step_core(Lane &L, const Mem &M) {
     if (!(fabsf(dlt) >= __builtin_fmaf(hi, 2.0e-6f, L.xnan)))
         h = slab_exact(n, L.o, L.d, T_MIN, L.T);         // within rounding distance: the reference's divisions
     bool inner = (n.w0 >> 28) == 0u;
+    bool leaf_hit = h && !inner;
     L.i = (inner && !h) ? n.w0 : L.i + 1u;               // inner: hit -> left subtree, miss -> skip link
-    L.pend = (h && !inner) ? n.w0 : 0u;                  // leaf: left object first, then the right one
+    L.pend = leaf_hit ? n.w0 : 0u;                       // leaf: left object first, then the right one
     L.pend2 = n.w1;                                      // only read after pend, i.e. after a leaf hit
+    return leaf_hit;
 }
 
 // range end of the lane's current item range: wave-uniform when the scene has no instances
@@ -427,8 +429,8 @@ VK_HD uint32_t range_end(const Lane &L, const DScene &S) { return (F & VKF_INSTA
 template <uint32_t F, class Mem, int N>
 VK_HD void box_steps(Lane &L, const DScene &S, const Mem &M, bool go) {
     if (go) {
-        box_step_core<F, Mem>(L, M);
-        if (N > 1) box_steps<F, Mem, (N > 1 ? N - 1 : 1)>(L, S, M, L.pend == 0u && L.i < range_end<F>(L, S));
+        bool queued = box_step_core<F, Mem>(L, M);      // (the mask is at hand: cheaper than comparing pend with 0 again)
+        if (N > 1) box_steps<F, Mem, (N > 1 ? N - 1 : 1)>(L, S, M, !queued && L.i < range_end<F>(L, S));
     }
 }
 
