@@ -91,6 +91,18 @@ def test_special_scene_per_sample(name, device, oracle):
     ds.close()
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_scene_graph_per_sample(seed, device, oracle):
+    """the randomised scene graphs of tests/test_fuzz_scenes.py through the C ABI"""
+    from test_fuzz_scenes import Gen
+    desc, cam, p = Gen(2000 + seed).build()
+    ds = DeviceScene(desc)
+    img_d, ps_d = device_samples(ds, cam, p)
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    compare_samples(ps_o, ps_d, img_o, img_d)
+    ds.close()
+
+
 def test_sample_chunking_and_odd_sizes(device, oracle, host_scenes):
     """spp > 256 splits pixels into sample chunks (partial sums + resolve); odd image sizes give edge tiles"""
     hs, cam = host_scenes("cornell_box")
