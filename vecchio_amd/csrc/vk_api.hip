@@ -299,10 +299,10 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 if (STATS) st_t0 = clock64();
                 cold_load_world_ray<F>(cold, lane, L);
                 const uint32_t live = n_box + n_heavy + n_light + n_sn;   // lanes only change state here, none appear or vanish
-                // steps between two exit tests (compile time: a run-time trip count costs 4-13 %): 4, but 2 for
-                // the Rect/Boxy/instance variant, whose scenes are toy trees (Cornell: 7 items) where most lanes
-                // leave the BOX state within a step or two
-                constexpr int UNROLL = ((F & VKF_ALL_SCENE) == (VKF_RECT | VKF_LIST | VKF_INSTANCE | VKF_BOX)) ? 2 : BOX_UNROLL;
+                // steps between two exit tests (compile time: a run-time trip count costs 4-13 %).  With shading deferred the
+                // optimum is 3 for the sphere-only and Cornell-type variants (against 4: C2 +0.7 %, C4 +1.3 %; 2: -3 %, 6: -1 %,
+                // 8: -6 %) and 4 for the everything-variants (C3: 3 -> -2 %)
+                constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? BOX_UNROLL : BOX_UNROLL - 1;
                 for (;;) {
                     if (F & VKF_INSTANCE) {     // end of an instance's item range: back to the parent space (rare)
                         if (is_box && L.i >= L.end && L.cur_inst >= 0) leave_instance<F, Mem>(L, S);
