@@ -9,12 +9,19 @@ the ranks (fixed total work => "strong" scaling) and the step ends with the fram
 to rank 0 — the path's only exchange.
 
 Also reported in the same JSON line:
-  roofline     algorithmic bytes per launch (SURVEY §8d formula, visit counts from the oracle's
-               counters on a bounded sample of the same scene/seed) / HIP-event time of the launch
-  cpu_baseline the oracle (restated CPU path, "port") timed on this box's host cores on a bounded
-               sample of the same workload (N = 1 only)
+  verified     the framebuffer of the LAST TIMED STEP, compared on a sparse tile subset (all over the frame, at
+               the full spp) with the oracle's render of the same pixels: pixels checked, max |dRGB|
+  roofline     algorithmic bytes per launch (SURVEY §8d formula, visit counts from the oracle's counters on a
+               bounded sample of the same scene/seed) / HIP-event time of the launch; plus `issue`: the
+               physical bound of this kernel — VALU issue slots (wave-instructions per sample from the committed
+               rocprofv3 PMC pass of this command, 2 cycles each on a SIMD-32, 1024 SIMDs x 2.4 GHz)
+  cpu_baseline the oracle (restated CPU path, "port") timed on this box's host cores on a bounded sample of the
+               same workload (N = 1 only)
+  config.also  one step each of the other single-GPU BASELINE configs (C4, C3 full size; C5 at reduced spp, marked),
+               each verified the same way (N = 1 only; --no-also skips them)
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -24,6 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2.0   # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles, 2.4 GHz max clock
+PROFILE_ROUND = "r02"
 
 WORKLOADS = {
     # name: (scene builder, width, spp, max_depth, label)
@@ -41,6 +50,41 @@ def algorithmic_bytes_per_sample(c, spp):
             8.0 * c["n_medium"] + 16.0 * c["n_closest"] + 3.0 * c["n_texel"] + 8.0 * 24.0 * c["n_perlin"]) / n + 12.0 / spp
 
 
+def pmc_summary(workload):
+    """the committed rocprofv3 PMC summary of this workload's bench command (profiles/<round>/), or None"""
+    for rnd in (PROFILE_ROUND, "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, f"{workload.lower()}_pmc_summary.json")
+        if os.path.exists(path) and os.path.getsize(path) > 0:
+            try:
+                return json.load(open(path)), os.path.relpath(path, ROOT)
+            except Exception:
+                pass
+    return None, None
+
+
+def verify_against_oracle(O, hs, cam, img, width, spp, depth, budget_samples=1.5e6):
+    """Compares a sparse subset of 8x8 tiles of `img` (numpy, (h, w, 3), y up) with the oracle's render of exactly
+    those pixels at the same seed and the FULL spp.  Every k-th tile (k prime, so the subset wanders over the
+    whole frame) such that the oracle traces about `budget_samples` samples."""
+    import numpy as np
+    height = img.shape[0]
+    tiles = ((width + 7) // 8) * ((height + 7) // 8)
+    want_tiles = max(2, int(budget_samples / (64.0 * spp)))
+    k = max(1, tiles // want_tiles)
+    while k > 1 and any(k % d == 0 for d in range(2, int(k ** 0.5) + 1)):
+        k += 1
+    po = hs.params(width, spp, depth, seed=2, height=height, tile_rank=k // 2, tile_world=k)
+    ref = np.full((height, width, 3), -1.0, np.float32)
+    t0 = time.perf_counter()
+    st = O.load().oracle_render(hs.desc, C.byref(cam), C.byref(po), ref.ctypes.data, os.cpu_count() or 1, None)
+    if st != 0:
+        return {"error": f"oracle status {st}"}
+    mask = ref[..., 0] >= 0
+    err = float(np.abs(img[mask] - ref[mask]).max())
+    return {"pixels": int(mask.sum()), "tiles": f"every {k}th 8x8 tile", "spp": spp, "max_abs_err": err, "tolerance": 1e-4,
+            "ok": bool(err < 1e-4 and np.isfinite(img).all()), "oracle_seconds": round(time.perf_counter() - t0, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,6 +97,11 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override spp (marks the result as non-headline)")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU sample (0 = size it to ~15 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run check of the timed framebuffer against the oracle")
+    ap.add_argument("--no-also", action="store_true", help="skip the single steps of the other BASELINE configs")
+    ap.add_argument("--in-library", action="store_true",
+                    help="N GPUs from ONE process through vk_scene_create_multi (the library deals tiles, gathers on device 0) "
+                         "instead of one process per GPU; run without torchrun")
     args = ap.parse_args()
 
     import numpy as np
@@ -64,7 +113,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
+    if world != args.gpus and not args.in_library:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     # VK_BENCH_REHEARSAL=1: run the N-rank code path on ONE GPU (all ranks share device 0, gloo
@@ -80,131 +129,165 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
+    n_gpus = args.gpus if args.in_library else world
+    if args.in_library:
+        assert world == 1, "--in-library is one process driving N devices"
+    in_lib_devices = None
+    if args.in_library:
+        n_vis = torch.cuda.device_count()
+        in_lib_devices = [i % n_vis for i in range(args.gpus)] if rehearsal else list(range(args.gpus))
 
-    scene_name, width, spp, depth, label = WORKLOADS[args.workload]
-    if args.spp:
-        spp = args.spp
-    if args.bvh == "sah":
-        scene_name += "+sah"
-        label += " [SAH BVH over the same objects]"
-    hs = HostScene(scene_name, 1)                        # scene seed 1
-    cam = hs.next_camera()
-    params = hs.params(width, spp, depth, seed=2, tile_rank=rank, tile_world=world)   # render seed 2
-    height = params.height
-    ds = DeviceScene(hs.desc, device=dev_index)          # scene upload: outside the timed region
-    info = ds.info()
-    fb = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
-    full = torch.zeros_like(fb) if (world > 1 and rank == 0) else None
-    gather = FramebufferGather(width, height, rank, world, dev, stage_on_cpu=rehearsal)
-    stream = torch.cuda.current_stream().cuda_stream
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as O
+    cores = os.cpu_count() or 1
 
-    lib = ds._lib
-    import ctypes as C
-    lib.vk_scene_last_kernel_ms.restype = C.c_int
-    lib.vk_scene_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    def run_workload(name, steps, warmup, spp_override=0, want_cpu=False, bvh="reference"):
+        scene_name, width, spp, depth, label = WORKLOADS[name]
+        if spp_override:
+            spp = spp_override
+            label += f" [spp overridden to {spp}]"
+        if bvh == "sah":
+            scene_name += "+sah"
+            label += " [SAH BVH over the same objects]"
+        hs = HostScene(scene_name, 1)                        # scene seed 1
+        cam = hs.next_camera()
+        params = hs.params(width, spp, depth, seed=2, tile_rank=rank, tile_world=world)   # render seed 2
+        height = params.height
+        # scene upload: outside the timed region
+        ds = DeviceScene(hs.desc, devices=in_lib_devices) if args.in_library else DeviceScene(hs.desc, device=dev_index)
+        info = ds.info()
+        fb = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
+        full = torch.zeros_like(fb) if (world > 1 and rank == 0) else None
+        gather = FramebufferGather(width, height, rank, world, dev, stage_on_cpu=rehearsal)
+        stream = torch.cuda.current_stream().cuda_stream
+        kernel_ms = []
 
-    kernel_ms = []
+        def step(record=False):
+            st = ds.render_device(cam, params, fb.data_ptr(), stream)
+            if world > 1:
+                gather.gather(fb, full)
+            if record:
+                kernel_ms.append(ds.last_kernel_ms())      # waits for this step's end event
+            return st
 
-    def step(record=False):
-        st = ds.render_device(cam, params, fb.data_ptr(), stream)
+        for _ in range(warmup):
+            step()
         if world > 1:
-            gather.gather(fb, full)
-        if record:
-            ms = C.c_double()
-            if lib.vk_scene_last_kernel_ms(ds._h, C.byref(ms)) == 0:   # waits for this step's end event
-                kernel_ms.append(ms.value)
-        return st
-
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    local_samples = 0
-    for _ in range(args.steps):
-        st = step(record=True)
-        local_samples = st.samples
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
-    if rehearsal and world > 1 and rank == 0:
-        p1 = hs.params(width, spp, depth, seed=2)
-        ref, _ = ds.render(cam, p1)
-        same = bool((full.cpu().numpy() == ref).all())
-        print(f"rehearsal: gathered {world}-rank image bit-identical to 1-rank render: {same}", file=sys.stderr)
-        assert same
-    total_samples = width * height * spp                  # all ranks together, per step
-    if rank == 0:
-        value = total_samples * args.steps / elapsed / 1e6
-        # ---- bounded oracle sample: visit counters (algorithmic bytes) + CPU baseline
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_ffi as O
-        cores = os.cpu_count() or 1
-        cpu = None
-        cw = width if args.workload != "C5" else 1024     # C5's 16.7M pixels: sample a quarter-res grid on the CPU
-        want_cpu = world == 1 and not args.no_cpu
-        # probe pass (also gives the visit counters); the timed CPU sample is then sized to ~15 s
-        pc = hs.params(cw, 1, depth, seed=2)
-        tc0 = time.perf_counter()
-        _, cnt = O.render(hs.desc, cam, pc, threads=cores)
-        tc = time.perf_counter() - tc0
-        cpu_spp = 1
-        if want_cpu:
-            rate = cnt.samples / tc
-            cpu_spp = args.cpu_spp if args.cpu_spp > 0 else int(min(64, max(2, 15.0 * rate / (cw * pc.height))))
-            pc = hs.params(cw, cpu_spp, depth, seed=2)
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        local_samples = 0
+        for _ in range(steps):
+            st = step(record=True)
+            local_samples = st.samples
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        total_samples = width * height * spp                  # all ranks together, per step
+        res = None
+        if rank == 0:
+            value = total_samples * steps / elapsed / 1e6
+            final = (full if world > 1 else fb).cpu().numpy()    # the image the last timed step produced
+            verified = None
+            if not args.no_verify:
+                verified = verify_against_oracle(O, hs, cam, final, width, spp, depth)
+            # ---- bounded oracle sample: visit counters (algorithmic bytes) + CPU baseline
+            cw = width if name != "C5" else 1024     # C5's 16.7M pixels: sample a quarter-res grid on the CPU
+            pc = hs.params(cw, 1, depth, seed=2)
             tc0 = time.perf_counter()
             _, cnt = O.render(hs.desc, cam, pc, threads=cores)
             tc = time.perf_counter() - tc0
-        c = cnt.as_dict()
-        bps = algorithmic_bytes_per_sample(c, spp)
-        if world == 1 and not args.no_cpu:
-            cpu = {"value": round(c["samples"] / tc / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                   "sample": f"{cw}x{pc.height} px x {cpu_spp} spp = {c['samples']} samples of the same scene/seed/depth, "
-                             f"{tc:.1f} s, oracle (recursive CPU restatement) on {cores} threads"}
-        k_ms = float(np.mean(kernel_ms)) if kernel_ms else None
-        # measured HBM traffic per launch: PMC counters cannot be collected from inside this process, so the
-        # figure comes from the committed rocprofv3 passes of this same command (profiles/, tests/prof_r01.sh):
-        # WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950: FETCH_SIZE counts half the bytes of wide reads -> upper bound)
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01", f"{args.workload.lower()}_pmc_summary.json")
-        if world == 1 and not args.spp and os.path.exists(prof):
-            try:
-                d = json.load(open(prof))["derived"]
-                traffic = float(d["hbm_write_bytes_per_dispatch"] + d["hbm_read_bytes_per_dispatch"]["with_gfx950_x2_correction_upper_bound"])
-            except Exception:
-                traffic = None
-        roof = None
-        if k_ms:
-            achieved = bps * local_samples / (k_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "traffic_note": "HBM bytes per launch from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command (profiles/r01/), not re-measured in this run",
-                    "algorithmic_bytes_per_sample": round(bps, 1), "kernel_ms": round(k_ms, 3),
-                    "note": "algorithmic bytes (SURVEY 8d record sizes x oracle visit counts); the scene is LDS/L2 resident, "
-                            "so measured HBM traffic is far below this (see profiles/)"}
+            cpu = None
+            if want_cpu:
+                rate = cnt.samples / tc
+                cpu_spp = args.cpu_spp if args.cpu_spp > 0 else int(min(64, max(2, 15.0 * rate / (cw * pc.height))))
+                pc = hs.params(cw, cpu_spp, depth, seed=2)
+                tc0 = time.perf_counter()
+                _, cnt = O.render(hs.desc, cam, pc, threads=cores)
+                tc = time.perf_counter() - tc0
+                cpu = {"value": round(cnt.samples / tc / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                       "sample": f"{cw}x{pc.height} px x {cpu_spp} spp = {cnt.samples} samples of the same scene/seed/depth, "
+                                 f"{tc:.1f} s, oracle (recursive CPU restatement) on {cores} threads"}
+            c = cnt.as_dict()
+            bps = algorithmic_bytes_per_sample(c, spp)
+            k_ms = float(np.mean(kernel_ms)) if kernel_ms else None
+            # measured HBM traffic and instruction counts per launch: PMC counters cannot be collected from inside this
+            # process, so they come from the committed rocprofv3 passes of this same command (profiles/, tests/prof_r02.sh):
+            # WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950: FETCH_SIZE counts half the bytes of wide reads -> upper bound)
+            traffic, issue, prof_path = None, None, None
+            if n_gpus == 1 and not spp_override and bvh == "reference":
+                prof, prof_path = pmc_summary(name)
+                if prof:
+                    d = prof.get("derived", {})
+                    try:
+                        traffic = float(d["hbm_write_bytes_per_dispatch"] + d["hbm_read_bytes_per_dispatch"]["with_gfx950_x2_correction_upper_bound"])
+                    except Exception:
+                        traffic = None
+                    vi = d.get("SQ_INSTS_VALU_per_sample")
+                    if vi and k_ms:
+                        rate = vi * local_samples / (k_ms * 1e-3)
+                        issue = {"bound": "valu_issue", "valu_wave_instr_per_sample": round(vi, 1), "cycles_per_wave_instr": 2,
+                                 "peak_wave_instr_per_s": VALU_WAVE_INSTR_PER_S, "achieved_wave_instr_per_s": round(rate, 1),
+                                 "frac": round(rate / VALU_WAVE_INSTR_PER_S, 4), "lane_fill": round(d.get("valu_lane_utilisation", 0.0), 4),
+                                 "note": "instruction count per sample from the committed PMC pass (a property of the build), rate from THIS run's "
+                                         "kernel time; frac x lane_fill = share of the 78.6 T lane-instr/s the kernel's useful lanes occupy"}
+            roof = None
+            if k_ms:
+                achieved = bps * local_samples / (k_ms * 1e-3) / 1e9
+                roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                        "traffic_note": f"HBM bytes per launch from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command ({prof_path}), not re-measured in this run",
+                        "algorithmic_bytes_per_sample": round(bps, 1), "kernel_ms": round(k_ms, 3),
+                        "note": "algorithmic bytes (SURVEY 8d record sizes x oracle visit counts); the scene is LDS/L2 resident, so this is not "
+                                "a physical bound (it can exceed 1): the physical one is `issue`",
+                        "issue": issue}
+            res = {"value": round(value, 2), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+                   "label": label, "integrator": "scatter" if hs.integrator else "pdf", "bvh_items": info.n_items,
+                   "scene_in_lds": bool(info.lds_bytes), "verified": verified, "roofline": roof, "cpu_baseline": cpu}
+        if rehearsal and world > 1 and rank == 0:
+            ds1 = DeviceScene(hs.desc, device=0)
+            ref, _ = ds1.render(cam, hs.params(width, spp, depth, seed=2))
+            same = bool((full.cpu().numpy() == ref).all())
+            ds1.close()
+            print(f"rehearsal: gathered {world}-rank image bit-identical to 1-rank render: {same}", file=sys.stderr)
+            assert same
+        ds.close()
+        hs.close()
+        return res
+
+    main_res = run_workload(args.workload, args.steps, args.warmup, args.spp, want_cpu=(n_gpus == 1 and not args.no_cpu), bvh=args.bvh)
+    also = []
+    if n_gpus == 1 and not args.no_also and args.workload == "C2" and not args.spp:
+        for name, spp_o in (("C4", 0), ("C3", 0), ("C5", 32)):
+            r = run_workload(name, 1, 0, spp_o)
+            also.append({"workload": r["label"], "Msamples_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": 1,
+                         "verified": r["verified"], "roofline_frac": r["roofline"]["frac"] if r["roofline"] else None,
+                         "issue_frac": (r["roofline"] or {}).get("issue", None) and r["roofline"]["issue"]["frac"]})
+    if rank == 0:
+        r = main_res
+        mode = "one process per GPU" if not args.in_library else "one process, vk_scene_create_multi (in-library tile deal + gather)"
         out = {
-            "metric": "Msamples/sec (pixels x spp)", "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "metric": "Msamples/sec (pixels x spp)", "value": r["value"], "unit": "Msamples/s", "n_gpus": n_gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
-            "config": {"workload": label if not args.spp else label + f" [spp overridden to {spp}]", "scene_seed": 1, "render_seed": 2,
-                       "integrator": "scatter" if hs.integrator else "pdf", "tiles": "8x8 round-robin over ranks",
-                       "bvh_builder": args.bvh, "bvh_items": info.n_items, "scene_in_lds": bool(info.lds_bytes)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "config": {"workload": r["label"], "scene_seed": 1, "render_seed": 2,
+                       "integrator": r["integrator"], "tiles": "8x8 round-robin over ranks", "multi_gpu": mode,
+                       "bvh_builder": args.bvh, "bvh_items": r["bvh_items"], "scene_in_lds": r["scene_in_lds"], "also": also},
+            "verified": r["verified"], "roofline": r["roofline"], "cpu_baseline": r["cpu_baseline"],
         }
         print(json.dumps(out), flush=True)
+        if r["verified"] and not r["verified"].get("ok", False):
+            print("bench.py: the timed framebuffer does NOT match the oracle", file=sys.stderr)
+            sys.exit(3)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ds.close()
 
 
 if __name__ == "__main__":

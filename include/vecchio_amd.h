@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 1
+#define VK_ABI_VERSION 2
 
 /* ---- status codes (reference convention is panic!/unwrap, main.rs:166,202) ---------- */
 enum {
@@ -208,7 +208,13 @@ typedef struct vk_render_params {
     /* pixel-tile partition for multi-GPU: 8x8-pixel tiles are dealt round-robin; this call
      * renders tiles t with t % tile_world == tile_rank.  (0,1) or (0,0) = whole image. */
     uint32_t tile_rank, tile_world;
+    /* what vk_render / vk_render_device write (ABI 2): VK_OUTPUT_F32 = the pixel means as above;
+     * VK_OUTPUT_RGB8 = the reference's output stage fused behind the render: Vec3::to_color
+     * (vec3.rs:54-61) per pixel and the PPM writer's top-down row order (main.rs:209) —
+     * width*height*3 BYTES, row 0 = TOP.  A multi-GPU host gathers these (4x less xGMI traffic). */
+    uint32_t output_format;
 } vk_render_params;
+enum { VK_OUTPUT_F32 = 0, VK_OUTPUT_RGB8 = 1 };
 
 typedef struct vk_stats {
     uint64_t samples;          /* pixel-samples rendered by this call            */
@@ -229,22 +235,35 @@ const char *vk_last_error(void);
 
 /* replaces: the ownership hand-off at main.rs:168-169 (Arc::new(BVHNode::new(..)),
  * Arc::new(config.lights)): deep-copies the described graph, linearises it and uploads it
- * to `device`.  The scene is immutable afterwards and may be rendered many times
- * (RotatingCamera, scene.rs:65-91).                                                    */
+ * to `device`.  The scene DESCRIPTION is immutable afterwards and may be rendered many times
+ * (RotatingCamera, scene.rs:65-91).  The handle also owns per-launch scratch (work counter,
+ * chunk partials, tile order): AT MOST ONE render may be in flight per vk_scene — calls on one
+ * scene must be made from one thread at a time and be stream-ordered (the reference's frame loop,
+ * main.rs:176, is exactly that); concurrent frames need one vk_scene each.                */
 int vk_scene_create(const vk_scene_desc *desc, int device, vk_scene **out);
+/* same, uploaded to EVERY device in devices[0..n_devices) ("uploads to every participating
+ * GPU").  vk_render / vk_render_device on such a scene deal this call's 8x8 tiles round-robin over the
+ * devices, render each share on that device's own stream, move the tile slabs to devices[0] with peer
+ * copies over xGMI (one message per device: the path's only exchange), de-interleave them
+ * on devices[0] and, for vk_render, do ONE device-to-host copy.  The image is bit-identical to the
+ * one-device image.  A device may be listed more than once (shares run concurrently on it).       */
+int vk_scene_create_multi(const vk_scene_desc *desc, const int *devices, int n_devices, vk_scene **out);
 void vk_scene_destroy(vk_scene *scene);
 
 /* replaces: the closure body at main.rs:181-198 for one Camera yielded by cam_iter
  * (main.rs:176).  Blocking.  rgb_out is caller-owned, width*height*3 floats, index
- * (y*width + x)*3 with y = 0 the BOTTOM row (main.rs:182-183,209).  Pixels outside this
- * call's tile partition are left untouched.                                            */
+ * (y*width + x)*3 with y = 0 the BOTTOM row (main.rs:182-183,209) — or, with
+ * params->output_format == VK_OUTPUT_RGB8, width*height*3 bytes, top row first.  Pixels outside
+ * this call's tile partition are left untouched.  max_depth == 0 renders the reference's result
+ * for MAX_DEPTH = 0: every sample is (0,0,0) (main.rs:126-128).                            */
 int vk_render(vk_scene *scene, const vk_camera *cam, const vk_render_params *params,
               float *rgb_out, vk_stats *stats_out);
 
 /* same as vk_render but the framebuffer is a device pointer on the scene's device and the
  * work is enqueued on `hip_stream` (a hipStream_t, or NULL for the default stream) without
  * a host synchronisation; used by the multi-GPU host (one process per GPU) so the RCCL
- * gather can be enqueued behind it.  stats_out->kernel_ms is not filled.               */
+ * gather can be enqueued behind it.  stats_out->kernel_ms is not filled.  For a multi-device
+ * scene the pointer and the stream belong to devices[0].                                 */
 int vk_render_device(vk_scene *scene, const vk_camera *cam, const vk_render_params *params,
                      void *d_rgb_out, void *hip_stream, vk_stats *stats_out);
 
@@ -265,23 +284,12 @@ typedef struct vk_scene_info {
 } vk_scene_info;
 int vk_scene_get_info(const vk_scene *scene, vk_scene_info *out);
 
-/* ---- diagnostics (used by tests/ and bench.py; not needed by the Rust shim) ------------ */
 /* HIP-event time (ms) of the launches enqueued by the last vk_render / vk_render_device on
- * this scene, on the stream they were launched on; waits for their end event.            */
+ * this scene, on the stream they were launched on; waits for their end event.  (For a
+ * multi-device scene: the slowest device's time.)                                         */
 int vk_scene_last_kernel_ms(vk_scene *scene, double *ms_out);
-/* as vk_render, also returning every sample: samples_out[(pixel*spp + s)*4 + 0..2] = radiance
- * before the finite filter (main.rs:192), [+3] = the sample's u32 draw count (bit pattern) */
-int vk_debug_render_samples(vk_scene *scene, const vk_camera *cam, const vk_render_params *params,
-                            float *rgb_out, float *samples_out);
-/* render with the instrumented build of the sphere-only kernel and return the wave scheduler's
- * counters: [0] box steps (wave level) [1] lanes with box work summed over them [2] PRIM phases
- * [3] lanes with primitive work in them [4] SHADE+REFILL phases [5] lanes in them [6] rounds
- * [7] heavy-primitive phases; wave clocks spent in [8] BOX [9] light PRIM [10] heavy PRIM
- * [11] SHADE+REFILL phases, [12] total wave clocks                                           */
-int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, uint64_t out[16]);
-/* evaluate the shared host/device arithmetic ON THE DEVICE (host arrays in/out):
- * op 0 sin, 1 cos, 2 ln, 3 asin, 4 atan2(a,b), 5 pow5, 6 a/b, 7 sqrt(a), 8 draws, 9 a*b+a  */
-int vk_debug_math(int device, int op, const float *a, const float *b, float *out, size_t n);
+
+/* test/diagnostic entry points (vk_debug_*) are declared in vecchio_amd_debug.h */
 
 #ifdef __cplusplus
 }

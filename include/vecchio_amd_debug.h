@@ -1,0 +1,33 @@
+/*
+ * vecchio_amd_debug.h — test and diagnostic entry points of libvecchio_amd.so.
+ *
+ * Not part of the drop-in boundary (include/vecchio_amd.h): nothing here replaces a reference
+ * interface, and the Rust shim does not bind it.  Used by tests/ and bench.py only.
+ */
+#ifndef VECCHIO_AMD_DEBUG_H
+#define VECCHIO_AMD_DEBUG_H
+
+#include "vecchio_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* as vk_render, also returning every sample: samples_out[(pixel*spp + s)*4 + 0..2] = radiance
+ * before the finite filter (main.rs:192), [+3] = the sample's u32 draw count (bit pattern) */
+int vk_debug_render_samples(vk_scene *scene, const vk_camera *cam, const vk_render_params *params,
+                            float *rgb_out, float *samples_out);
+/* render with the instrumented build of the sphere-only kernel and return the wave scheduler's
+ * counters: [0] box steps (wave level) [1] lanes with box work summed over them [2] PRIM phases
+ * [3] lanes with primitive work in them [4] SHADE+REFILL phases [5] lanes in them [6] rounds
+ * [7] heavy-primitive phases; wave clocks spent in [8] BOX [9] light PRIM [10] heavy PRIM
+ * [11] SHADE+REFILL phases, [12] total wave clocks                                           */
+int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, uint64_t out[16]);
+/* evaluate the shared host/device arithmetic ON THE DEVICE (host arrays in/out):
+ * op 0 sin, 1 cos, 2 ln, 3 asin, 4 atan2(a,b), 5 pow5, 6 a/b, 7 sqrt(a), 8 draws, 9 a*b+a  */
+int vk_debug_math(int device, int op, const float *a, const float *b, float *out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VECCHIO_AMD_DEBUG_H */

@@ -1,6 +1,7 @@
 #!/bin/bash
 # kernel experiments: bench the alternate builds in vecchio_amd/lib/exp/*.so (see ffi.device_lib_path)
 # usage (GPU box): bash tests/exp_bench.sh "C2 C4" [steps]
+mkdir -p gpurun_out
 WLS=${1:-C2}
 STEPS=${2:-2}
 for lib in default vecchio_amd/lib/exp/*.so; do

@@ -5,8 +5,10 @@ import glob
 import json
 import sys
 
+import os
 src, dst, samples = sys.argv[1], sys.argv[2], float(sys.argv[3])
-out = {"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu (separate passes; see tests/prof_r01.sh)",
+cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "bench.py --steps 2 --warmup 1 --no-cpu"
+out = {"command": f"rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 {cmd} (separate passes; see tests/prof_r02.sh)",
        "samples_per_dispatch": samples, "counters_per_dispatch": {}}
 for f in sorted(glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv")):
     agg = collections.defaultdict(list)
@@ -30,7 +32,17 @@ if "SQ_WAVE_CYCLES" in c and "SQ_WAIT_ANY" in c:
     d["wave_time_split"] = {"issuing": c["SQ_ACTIVE_INST_ANY"] / w, "waiting(s_waitcnt)": c["SQ_WAIT_ANY"] / w, "issue_stall": c["SQ_WAIT_INST_ANY"] / w}
 if "SQ_LDS_BANK_CONFLICT" in c:
     d["lds_bank_conflict_fraction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
-for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_FLAT"):
+if "SQ_INSTS_VALU" in c and "SQ_BUSY_CYCLES" in c:
+    # VALU issue: one wave64 VALU instruction occupies its SIMD for 2 cycles (MI355X_MICROARCH.md); 1024 SIMDs
+    d["valu_wave_instr_per_sample"] = c["SQ_INSTS_VALU"] / samples
+if "TCC_HIT_sum" in c:
+    d["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    d["l2_misses_per_sample"] = c["TCC_MISS_sum"] / samples
+if "TCP_TCC_READ_REQ_sum" in c and "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
+    d["l1_miss_rate(TCP->TCC reads / TCP accesses)"] = c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+if "TCC_EA0_RDREQ_sum" in c:
+    d["memory_read_requests_per_sample"] = c["TCC_EA0_RDREQ_sum"] / samples
+for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM", "SQ_INSTS_FLAT", "SQ_INSTS_VALU_TRANS"):
     if k in c:
         d[k + "_per_sample"] = c[k] / samples
 out["derived"] = d

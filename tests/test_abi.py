@@ -10,18 +10,22 @@ from vecchio_amd import ffi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "vecchio_amd.h")
+HEADERS = sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h"))
 
 
 def declared_functions():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(vk_[a-z_0-9]+)\s*\(", src)))
+    """every function declared in include/*.h (the boundary and the debug header)"""
+    names = set()
+    for h in HEADERS:
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(vk_[a-z_0-9]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_exports_every_declared_symbol(built):
     names = declared_functions()
     assert {"vk_scene_create", "vk_render", "vk_render_device", "vk_scene_destroy", "vk_last_error", "vk_abi_version",
-            "vk_device_count", "vk_to_color_device"} <= set(names)
+            "vk_device_count", "vk_to_color_device", "vk_scene_create_multi", "vk_debug_render_samples"} <= set(names)
     lib = C.CDLL(ffi.device_lib_path())
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, f"declared in include/vecchio_amd.h but not exported: {missing}"

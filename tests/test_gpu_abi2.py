@@ -1,0 +1,129 @@
+"""-m gpu: the ABI-2 additions of include/vecchio_amd.h through the C ABI —
+multi-device scenes (vk_scene_create_multi: SURVEY §8b "uploads to every participating GPU", §8e gather to
+devices[0] + de-interleave + one D2H), the fused output stage (VK_OUTPUT_RGB8 = Vec3::to_color vec3.rs:44-61 +
+top-down rows main.rs:209) and the MAX_DEPTH = 0 corner (main.rs:126-128)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_checks as G
+from vecchio_amd import DeviceScene, HostScene, ffi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_to_color_kernel_against_numpy_restatement(device, host_scenes):
+    """vk_to_color_device against an independent numpy restatement of Vec3::clamp / to_color (vec3.rs:44-61):
+    NaN (falls through the clamp, `as u32` -> 0), negatives (sqrt -> NaN -> 0), -0, values >= 1 and +inf (clamped
+    to 0.999 -> 255), the 0.999 boundary, denormals, and random values — and the top-down row flip (main.rs:209)."""
+    import torch
+    hs, cam = host_scenes("cornell_box")
+    ds = DeviceScene(hs.desc)
+    w, h = 64, 37
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 1.2, (h, w, 3)).astype(np.float32)
+    b = np.float32(0.999) ** 2
+    special = np.array([np.nan, -1.0, -0.0, 0.0, 1.0, 2.0, np.inf, -np.inf, b, np.nextafter(b, np.float32(0)), np.nextafter(b, np.float32(2)),
+                        1e-45, 1e-38, (255.0 / 256) ** 2, (1.0 / 256) ** 2, np.nextafter(np.float32((1.0 / 256) ** 2), np.float32(0)), 0.25, 1e30],
+                       np.float32)
+    img.reshape(-1)[:len(special)] = special
+    img[5, 7] = (np.nan, 0.5, -3.0)
+    d_rgb = torch.from_numpy(img).cuda()
+    d_out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    ds.to_color_device(d_rgb.data_ptr(), w, h, d_out.data_ptr())
+    torch.cuda.synchronize()
+    with np.errstate(invalid="ignore"):
+        want = G.to_color(img)[::-1]                     # rows top-down
+    assert np.array_equal(d_out.cpu().numpy(), want)
+    ds.close()
+
+
+def test_rgb8_output_is_to_color_of_the_f32_image(device, host_scenes):
+    for name, w, spp in (("cornell_box", 100, 64), ("random_spheres_iow", 150, 70)):
+        hs, cam = host_scenes(name)
+        ds = DeviceScene(hs.desc)
+        p = hs.params(w, spp, 30)
+        img, _ = ds.render(cam, p)
+        p8 = hs.params(w, spp, 30, output_format=ffi.VK_OUTPUT_RGB8)
+        img8, _ = ds.render(cam, p8)
+        assert np.array_equal(img8, G.to_color(img)[::-1])
+        # tile partitions of an RGB8 image leave the other tiles alone
+        acc = np.full_like(img8, 7)
+        for r in range(3):
+            ds.render(cam, hs.params(w, spp, 30, tile_rank=r, tile_world=3, output_format=ffi.VK_OUTPUT_RGB8), out=acc)
+        assert np.array_equal(acc, img8)
+        ds.close()
+
+
+@pytest.mark.parametrize("name,w,spp", [("random_spheres_iow", 203, 130), ("cornell_box", 96, 70), ("final_scene", 64, 8)])
+def test_multi_device_scene_is_bit_identical(name, w, spp, device, host_scenes):
+    """vk_scene_create_multi with the one visible device listed 1, 2 and 5 times (each entry = one share with its own
+    stream, slab and peer copy): vk_render must give the one-device image bit for bit, f32 and RGB8, also when
+    the call itself is one rank of an outer tile partition."""
+    hs, cam = host_scenes(name)
+    single = DeviceScene(hs.desc)
+    p = hs.params(w, spp, 50)
+    p8 = hs.params(w, spp, 50, output_format=ffi.VK_OUTPUT_RGB8)
+    want, st1 = single.render(cam, p)
+    want8, _ = single.render(cam, p8)
+    for n in (1, 2, 5):
+        multi = DeviceScene(hs.desc, devices=[0] * n)
+        assert multi.info().n_items == single.info().n_items
+        got, st = multi.render(cam, p)
+        assert st.samples == st1.samples
+        assert np.array_equal(got, want), f"{n} shares: f32 image differs"
+        got8, _ = multi.render(cam, p8)
+        assert np.array_equal(got8, want8), f"{n} shares: RGB8 image differs"
+        again, _ = multi.render(cam, p)                   # frame after frame on the same handle (main.rs:176)
+        assert np.array_equal(again, want)
+        acc = np.zeros_like(want)
+        for r in range(2):                                # the group as one rank of an outer 2-way partition
+            multi.render(cam, hs.params(w, spp, 50, tile_rank=r, tile_world=2), out=acc)
+        assert np.array_equal(acc, want)
+        assert multi.last_kernel_ms() > 0
+        multi.close()
+    single.close()
+
+
+def test_multi_device_render_device_and_errors(device, host_scenes):
+    import torch
+    hs, cam = host_scenes("cornell_box")
+    multi = DeviceScene(hs.desc, devices=[0, 0])
+    p = hs.params(80, 64, 20)
+    fb = torch.zeros((p.height, p.width, 3), dtype=torch.float32, device="cuda")
+    st = multi.render_device(cam, p, fb.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want, _ = multi.render(cam, p)
+    assert np.array_equal(fb.cpu().numpy(), want) and st.samples == 80 * p.height * 64
+    multi.close()
+    lib = device
+    h = C.c_void_p()
+    assert lib.vk_scene_create_multi(hs.desc, (C.c_int * 2)(0, 99), 2, C.byref(h)) == ffi.VK_ERR_BAD_ARG and not h.value
+    assert lib.vk_scene_create_multi(hs.desc, None, 2, C.byref(h)) == ffi.VK_ERR_BAD_ARG
+    assert lib.vk_scene_create_multi(hs.desc, (C.c_int * 1)(0), 0, C.byref(h)) == ffi.VK_ERR_BAD_ARG
+    ds = DeviceScene(hs.desc)
+    bad = hs.params(16, 4, 10, output_format=5)
+    out = np.zeros((bad.height, 16, 3), np.float32)
+    assert lib.vk_render(ds._h, C.byref(cam), C.byref(bad), out.ctypes.data, None) == ffi.VK_ERR_BAD_ARG
+    lib.vk_debug_phase_stats.restype = C.c_int
+    lib.vk_debug_phase_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.vk_debug_phase_stats(ds._h, None, None, None) == ffi.VK_ERR_BAD_ARG          # used to dereference params first
+    ds.close()
+
+
+def test_max_depth_zero_and_one(device, oracle, host_scenes):
+    """MAX_DEPTH = 0: ray_color returns (0,0,0) before tracing (depth 1 > 0, main.rs:126-128) — a black image, also
+    under a sky; MAX_DEPTH = 1 and 2 against the oracle."""
+    for name in ("random_spheres_iow", "cornell_box"):
+        hs, cam = host_scenes(name)
+        ds = DeviceScene(hs.desc)
+        for depth in (0, 1, 2):
+            p = hs.params(48, 6, depth)
+            got = np.full((p.height, 48, 3), 5.0, np.float32)
+            ds.render(cam, p, out=got)
+            ref, _ = oracle.render(hs.desc, cam, p)
+            assert np.abs(got - ref).max() < 1e-4, (name, depth)
+            if depth == 0:
+                assert ref.max() == 0.0 and got.max() == 0.0
+        ds.close()

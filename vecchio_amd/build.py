@@ -32,14 +32,43 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
+def _run_atomic(cmd_before_out, out, cmd_after_out):
+    """compile to a temporary name, then rename into place: a concurrent loader never sees a half-written file"""
+    tmp = f"{out}.tmp.{os.getpid()}"
+    try:
+        _run(cmd_before_out + [tmp] + cmd_after_out)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
+def _host_deps():
+    srcs = [os.path.join(HOST, f) for f in ("host.cpp", "scene.cpp", "host_api.cpp")]
+    return srcs, srcs + [os.path.join(HOST, "vecchio_host.hpp"), os.path.join(HOST, "host_api.h"),
+                         os.path.join(CSRC, "vk_math.h"), os.path.join(ROOT, "include", "vecchio_amd.h")]
+
+
+def _device_deps():
+    srcs = [os.path.join(CSRC, "vk_api.hip"), os.path.join(CSRC, "vk_linearize.cpp")]
+    return srcs, srcs + [os.path.join(CSRC, f) for f in ("vk_kernels.h", "vk_trace.h", "vk_math.h", "vk_device_scene.h", "vk_linearize.h")] + \
+        [os.path.join(ROOT, "include", "vecchio_amd.h"), os.path.join(ROOT, "include", "vecchio_amd_debug.h")]
+
+
+def host_is_stale():
+    return _newer(os.path.join(LIB, "libvecchio_host.so"), _host_deps()[1])
+
+
+def device_is_stale():
+    return _newer(os.path.join(LIB, "libvecchio_amd.so"), _device_deps()[1]) or not os.path.exists(kernel_resources_path())
+
+
 def build_host(force=False):
     out = os.path.join(LIB, "libvecchio_host.so")
-    srcs = [os.path.join(HOST, f) for f in ("host.cpp", "scene.cpp", "host_api.cpp")]
-    deps = srcs + [os.path.join(HOST, "vecchio_host.hpp"), os.path.join(HOST, "host_api.h"),
-                   os.path.join(CSRC, "vk_math.h"), os.path.join(ROOT, "include", "vecchio_amd.h")]
+    srcs, deps = _host_deps()
     if force or _newer(out, deps):
         os.makedirs(LIB, exist_ok=True)
-        _run([CXX] + CXXFLAGS + ["-shared", "-o", out] + srcs)
+        _run_atomic([CXX] + CXXFLAGS + ["-shared", "-o"], out, srcs)
     return out
 
 
@@ -56,15 +85,14 @@ def build_cli(force=False):
 def build_device(force=False):
     """hipcc cross-compiles for gfx950 without a GPU present."""
     out = os.path.join(LIB, "libvecchio_amd.so")
-    srcs = [os.path.join(CSRC, "vk_api.hip"), os.path.join(CSRC, "vk_linearize.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("vk_trace.h", "vk_math.h", "vk_device_scene.h", "vk_linearize.h")] + \
-        [os.path.join(ROOT, "include", "vecchio_amd.h")]
+    srcs, deps = _device_deps()
     if force or _newer(out, deps) or not os.path.exists(kernel_resources_path()):
         os.makedirs(LIB, exist_ok=True)
         # -save-temps in a scratch directory: the gfx950 assembly is read back for the per-kernel spill counts
         import tempfile
         with tempfile.TemporaryDirectory() as tmp:
-            cmd = [HIPCC] + HIPFLAGS + ["-Rpass-analysis=kernel-resource-usage", "-save-temps", "-shared", "-o", out] + srcs
+            tmp_out = f"{out}.tmp.{os.getpid()}"
+            cmd = [HIPCC] + HIPFLAGS + ["-Rpass-analysis=kernel-resource-usage", "-save-temps", "-shared", "-o", tmp_out] + srcs
             print("+", " ".join(cmd), file=sys.stderr)
             r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True, cwd=tmp)
             remarks = [l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" in l]
@@ -72,7 +100,10 @@ def build_device(force=False):
             if other:
                 print("\n".join(other), file=sys.stderr)
             if r.returncode != 0:
+                if os.path.exists(tmp_out):
+                    os.remove(tmp_out)
                 raise subprocess.CalledProcessError(r.returncode, cmd)
+            os.replace(tmp_out, out)
             spills = {}
             for f in os.listdir(tmp):
                 if f.endswith("gfx950.s"):

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 
-VK_ABI_VERSION = 1
+VK_ABI_VERSION = 2
 VK_OK, VK_ERR_BAD_ARG, VK_ERR_UNSUPPORTED, VK_ERR_HIP, VK_ERR_NO_DEVICE, VK_ERR_OOM = range(6)
 
 (VK_KIND_NONE, VK_KIND_BVH, VK_KIND_SPHERE, VK_KIND_MOVING_SPHERE, VK_KIND_RECT, VK_KIND_LIST,
@@ -23,6 +23,7 @@ VK_REF_INDEX_MASK = 0x07FFFFFF
 VK_TEX_SOLID, VK_TEX_CHECKER, VK_TEX_IMAGE, VK_TEX_NOISE = range(4)
 VK_INTEGRATOR_PDF, VK_INTEGRATOR_SCATTER = 0, 1
 VK_BACKGROUND_SOLID, VK_BACKGROUND_SKY = 0, 1
+VK_OUTPUT_F32, VK_OUTPUT_RGB8 = 0, 1
 
 
 def make_ref(kind, index, flip=False):
@@ -114,7 +115,7 @@ class RenderParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples_per_pixel", C.c_uint32),
                 ("max_depth", C.c_uint32), ("seed", C.c_uint64), ("integrator", C.c_uint32),
                 ("background", C.c_uint32), ("background_color", F3), ("tile_rank", C.c_uint32),
-                ("tile_world", C.c_uint32)]
+                ("tile_world", C.c_uint32), ("output_format", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -131,15 +132,31 @@ _host = None
 _dev = None
 
 
+def _build_locked(target, builder):
+    """Build `target` (if missing or older than its sources) under an exclusive file lock, so that N ranks
+    started together on a fresh checkout run ONE compile and nobody loads a half-written library: the
+    builder writes to a temporary name and renames it into place."""
+    import fcntl
+    os.makedirs(LIB_DIR, exist_ok=True)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            builder()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    if not os.path.exists(target):
+        raise RuntimeError(f"{target} was not built")
+
+
 def load_host_lib():
     """libvecchio_host.so: scene builders / BVHNode::new / Camera::new (C++ mirror of scene.rs)."""
     global _host
     if _host is not None:
         return _host
     path = os.path.join(LIB_DIR, "libvecchio_host.so")
-    if not os.path.exists(path):
-        from . import build
-        build.build_host()          # a fresh checkout: compile (g++), never substitute anything
+    from . import build
+    if build.host_is_stale():
+        _build_locked(path, build.build_host)   # a fresh or edited checkout: compile (g++), never substitute anything
     lib = C.CDLL(path)
     lib.vkh_scene_build.restype = C.c_void_p
     lib.vkh_scene_build.argtypes = [C.c_char_p, C.c_uint64]
@@ -160,7 +177,8 @@ def load_host_lib():
 
 DEVICE_SYMBOLS = [
     "vk_abi_version", "vk_device_count", "vk_last_error", "vk_scene_create", "vk_scene_destroy",
-    "vk_render", "vk_render_device", "vk_to_color_device", "vk_scene_get_info",
+    "vk_render", "vk_render_device", "vk_to_color_device", "vk_scene_get_info", "vk_scene_create_multi",
+    "vk_scene_last_kernel_ms",
 ]
 
 
@@ -175,12 +193,12 @@ def load_device_lib():
     if _dev is not None:
         return _dev
     path = device_lib_path()
-    if not os.path.exists(path):
-        from . import build
-        try:
-            build.build_device()    # a fresh checkout: compile with hipcc; there is no CPU fallback to use instead
+    from . import build
+    if not os.environ.get("VK_DEVICE_LIB") and build.device_is_stale():
+        try:                        # a fresh or edited checkout: compile with hipcc; there is no CPU fallback to use instead
+            _build_locked(path, build.build_device)
         except Exception as e:
-            raise RuntimeError(f"{path} missing and hipcc could not build it ({e}); the HIP extension is required "
+            raise RuntimeError(f"{path} missing or stale and hipcc could not build it ({e}); the HIP extension is required "
                                "(no CPU fallback exists)") from e
     lib = C.CDLL(path)
     lib.vk_abi_version.restype = C.c_int
@@ -188,7 +206,11 @@ def load_device_lib():
     lib.vk_last_error.restype = C.c_char_p
     lib.vk_scene_create.restype = C.c_int
     lib.vk_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
+    lib.vk_scene_create_multi.restype = C.c_int
+    lib.vk_scene_create_multi.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     lib.vk_scene_destroy.argtypes = [C.c_void_p]
+    lib.vk_scene_last_kernel_ms.restype = C.c_int
+    lib.vk_scene_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.vk_render.restype = C.c_int
     lib.vk_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
     lib.vk_render_device.restype = C.c_int

@@ -11,7 +11,7 @@ use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
 pub type vk_ref = u32;
-pub const VK_ABI_VERSION: u32 = 1;
+pub const VK_ABI_VERSION: u32 = 2;
 pub const VK_REF_FLIP: u32 = 0x0800_0000;
 pub const VK_KIND_BVH: u32 = 1;
 pub const VK_KIND_SPHERE: u32 = 2;
@@ -66,6 +66,7 @@ pub struct vk_camera {          // the ten fields of main.rs:57-68 (add #[repr(C
 pub struct vk_render_params {
     pub width: u32, pub height: u32, pub samples_per_pixel: u32, pub max_depth: u32, pub seed: u64,
     pub integrator: u32, pub background: u32, pub background_color: [f32; 3], pub tile_rank: u32, pub tile_world: u32,
+    pub output_format: u32,     // VK_OUTPUT_F32 = 0 | VK_OUTPUT_RGB8 = 1 (Vec3::to_color + top-down rows fused, vec3.rs:54-61, main.rs:209)
 }
 
 #[repr(C)] #[derive(Copy, Clone, Default)]
@@ -79,6 +80,7 @@ extern "C" {
     pub fn vk_device_count() -> c_int;
     pub fn vk_last_error() -> *const c_char;
     pub fn vk_scene_create(desc: *const vk_scene_desc, device: c_int, out: *mut *mut vk_scene) -> c_int;
+    pub fn vk_scene_create_multi(desc: *const vk_scene_desc, devices: *const c_int, n_devices: c_int, out: *mut *mut vk_scene) -> c_int;
     pub fn vk_scene_destroy(scene: *mut vk_scene);
     pub fn vk_render(scene: *mut vk_scene, cam: *const vk_camera, params: *const vk_render_params, rgb_out: *mut f32, stats: *mut vk_stats) -> c_int;
     pub fn vk_render_device(scene: *mut vk_scene, cam: *const vk_camera, params: *const vk_render_params, d_rgb: *mut c_void, stream: *mut c_void, stats: *mut vk_stats) -> c_int;
@@ -131,6 +133,14 @@ impl GpuScene {
         let mut h: *mut vk_scene = std::ptr::null_mut();
         let d = fb.desc();
         check(unsafe { vk_scene_create(&d, device, &mut h) })?;
+        Ok(GpuScene { handle: h })
+    }
+    /// One handle over every listed GPU: `render` then deals the tiles over them and gathers on devices[0]
+    /// (what `main()`'s single-threaded frame loop, main.rs:176, calls on an 8-GPU node).
+    pub fn new_multi(fb: &FlatBuilder, devices: &[i32]) -> Result<GpuScene, std::io::Error> {
+        let mut h: *mut vk_scene = std::ptr::null_mut();
+        let d = fb.desc();
+        check(unsafe { vk_scene_create_multi(&d, devices.as_ptr(), devices.len() as c_int, &mut h) })?;
         Ok(GpuScene { handle: h })
     }
     /// `pixels`: width*height Vec3 (#[repr(C)] added to vec3.rs:3-8), y = 0 bottom row as in main.rs:182-183.

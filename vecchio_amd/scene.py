@@ -34,7 +34,7 @@ class HostScene:
             return None
         return cam
 
-    def params(self, width, spp, max_depth, seed=2, height=None, tile_rank=0, tile_world=1):
+    def params(self, width, spp, max_depth, seed=2, height=None, tile_rank=0, tile_world=1, output_format=ffi.VK_OUTPUT_F32):
         """vk_render_params with the scene's integrator/background; height = width/aspect (main.rs:172)."""
         p = ffi.RenderParams()
         p.width = width
@@ -47,6 +47,7 @@ class HostScene:
         p.background_color = ffi.F3(*self.background_color)
         p.tile_rank = tile_rank
         p.tile_world = tile_world
+        p.output_format = output_format
         return p
 
     def close(self):
@@ -67,10 +68,17 @@ def check(lib, status):
 
 
 class DeviceScene:
-    def __init__(self, desc, device=0):
+    def __init__(self, desc, device=0, devices=None):
+        """device: one MI355X (vk_scene_create).  devices=[...]: one handle over several (vk_scene_create_multi):
+        render() then deals the tiles over them and gathers on devices[0] inside the library."""
         self._lib = ffi.load_device_lib()
         h = C.c_void_p()
-        check(self._lib, self._lib.vk_scene_create(desc, device, C.byref(h)))
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            check(self._lib, self._lib.vk_scene_create_multi(desc, arr, len(devices), C.byref(h)))
+            device = devices[0]
+        else:
+            check(self._lib, self._lib.vk_scene_create(desc, device, C.byref(h)))
         self._h = h
         self.device = device
 
@@ -80,9 +88,12 @@ class DeviceScene:
         return inf
 
     def render(self, cam, params, out=None):
-        """Blocking render into a host numpy array (height, width, 3) float32, y = 0 bottom row."""
+        """Blocking render into a host numpy array (height, width, 3): float32 with y = 0 the bottom row, or
+        (params.output_format == VK_OUTPUT_RGB8) uint8 with row 0 the top row."""
+        dt = np.uint8 if params.output_format == ffi.VK_OUTPUT_RGB8 else np.float32
         if out is None:
-            out = np.zeros((params.height, params.width, 3), dtype=np.float32)
+            out = np.zeros((params.height, params.width, 3), dtype=dt)
+        assert out.dtype == dt
         stats = ffi.Stats()
         check(self._lib, self._lib.vk_render(self._h, C.byref(cam), C.byref(params), out.ctypes.data_as(C.c_void_p), C.byref(stats)))
         return out, stats
@@ -93,6 +104,12 @@ class DeviceScene:
         check(self._lib, self._lib.vk_render_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(d_ptr),
                                                     C.c_void_p(stream or 0), C.byref(stats)))
         return stats
+
+    def last_kernel_ms(self):
+        """HIP-event time of the launches of the last render (waits for them)."""
+        ms = C.c_double()
+        check(self._lib, self._lib.vk_scene_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def to_color_device(self, d_rgb, width, height, d_rgb8, stream=None):
         check(self._lib, self._lib.vk_to_color_device(self._h, C.c_void_p(d_rgb), width, height, C.c_void_p(d_rgb8), C.c_void_p(stream or 0)))
