@@ -102,7 +102,7 @@ struct vk_scene {
     uint32_t *counter = nullptr;
     float *fb = nullptr; size_t fb_bytes = 0;        // f32 framebuffer (vk_render; RGB8 output; the parts' render targets)
     uint8_t *fb8 = nullptr; size_t fb8_bytes = 0;    // RGB8 image for vk_render with VK_OUTPUT_RGB8
-    float *partial = nullptr; size_t partial_bytes = 0;
+    long long *accum = nullptr; size_t accum_bytes = 0;   // fixed-point pixel sums of the render in flight
     float4 *debug = nullptr; size_t debug_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cus = 256;
@@ -162,8 +162,8 @@ uint32_t pick_variant(const vk_scene *s) {
     return VKF_ALL_SCENE;
 }
 
-size_t per_wave_lds_bytes(uint32_t F) {   // pixel accumulators + cold lane state of one wave
-    return (size_t)64 * (3 + ((F & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE)) * sizeof(float) + sizeof(uint32_t);   // + the unit's start time
+size_t per_wave_lds_bytes(uint32_t F) {   // cold lane state of one wave + its tile's fixed-point sums (64 x 3 x 8 B) + its unit state
+    return (size_t)64 * ((F & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE) * sizeof(float) + 64 * 3 * sizeof(unsigned long long) + WAVE_STATE_WORDS * sizeof(uint32_t);
 }
 
 // LDS residency plan.  `hot` = bytes of items + spheres + boxes.  Measured on MI355X with the VALU-bound
@@ -230,7 +230,7 @@ int launch_by_features(vk_scene *s, uint32_t F, const KArgs &A, bool lds, dim3 g
 int check_render_args(vk_scene *scene, const vk_camera *cam, const vk_render_params *p) {
     if (!scene || !cam || !p) return fail(VK_ERR_BAD_ARG, "null argument");
     if (p->width < 2 || p->height < 2) return fail(VK_ERR_BAD_ARG, "width and height must be >= 2 (u,v divide by width-1/height-1, main.rs:187-188)");
-    if ((uint64_t)p->width * p->height > (1ull << 31) / 3) return fail(VK_ERR_BAD_ARG, "image too large");
+    if ((uint64_t)p->width * p->height > (1ull << 31) / 3 || p->width > 65535u || p->height > 65535u) return fail(VK_ERR_BAD_ARG, "image too large");
     if (p->samples_per_pixel == 0 || p->samples_per_pixel > (1u << 26)) return fail(VK_ERR_BAD_ARG, "samples_per_pixel must be in 1..2^26");
     if (!(cam->time0 < cam->time1)) return fail(VK_ERR_BAD_ARG, "camera time0 >= time1 (gen_range panics, main.rs:118)");
     if (p->integrator > VK_INTEGRATOR_SCATTER || p->background > VK_BACKGROUND_SKY) return fail(VK_ERR_BAD_ARG, "bad integrator/background");
@@ -273,8 +273,8 @@ uint64_t partition_samples(const vk_render_params *p, const TileGeom &g) {
     return px * p->samples_per_pixel;
 }
 
-// number of sample chunks per tile: a function of the image and spp ONLY (never of the tile
-// partition), so 1-GPU and N-GPU renders sum every pixel in the same order
+// number of sample chunks per tile.  Pixel sums are order independent, so this only sets the granularity of the work
+// units (locality of a wave's samples against the spread of expensive tiles over many waves), never a pixel's value
 uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
     // Samples per pixel per unit: large enough that the end-of-unit tail (lanes idling while the last long
     // paths of a unit finish) stays small, small enough that tiles of very different cost (fog, glass,
@@ -300,9 +300,6 @@ uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
     uint32_t lo = cap < 32 ? cap : 32;
     uint32_t chunk_spp = (uint32_t)(c > cap ? cap : (c < lo ? lo : c));
     uint32_t n = (p->samples_per_pixel + chunk_spp - 1) / chunk_spp;
-    // the chunk partials cost n x framebuffer bytes: keep them under 8 GiB
-    const uint64_t fb = (uint64_t)p->width * p->height * 12u;
-    while (n > 1 && (uint64_t)n * fb > (8ull << 30)) n = (n + 1) / 2;
     if (n < 1) n = 1;
     return n;
 }
@@ -362,10 +359,11 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         if (rc != VK_OK) return rc;
         if (!s->order_hist) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->order_hist), ORDER_BUCKETS * sizeof(uint32_t)));
     }
-    if (A.n_chunks > 1) {
-        int rc = ensure(s->partial, s->partial_bytes, (size_t)A.n_chunks * n_pixels * 3 * sizeof(float));
+    {   // order-independent pixel sums (vk_kernels.h to_fixed): zeroed per frame, resolved into d_out after the launch
+        int rc = ensure(s->accum, s->accum_bytes, n_pixels * 3 * sizeof(long long));
         if (rc != VK_OK) return rc;
-        A.partial = s->partial;
+        HIP_TRY(hipMemsetAsync(s->accum, 0, n_pixels * 3 * sizeof(long long), st));
+        A.accum = s->accum;
     }
     // LDS residency of the hot records
     bool lds = s->lds_bytes != 0;
@@ -386,8 +384,8 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         // (C2, one rank's 1/8 share: probe of 1 / 2 / 4 / 8 / 16 spp -> 68.6 / 69.0 / 69.8 / 70.5 / 73.0 ms: more samples cost more than they sort better)
         B.C.spp = p->samples_per_pixel / 1024u; B.C.spp = B.C.spp < 1u ? 1u : (B.C.spp > 4u ? 4u : B.C.spp);
         if (s->env.probe_spp >= 1 && (uint32_t)s->env.probe_spp <= p->samples_per_pixel) B.C.spp = (uint32_t)s->env.probe_spp;   // diagnostics
-        B.n_chunks = 1; B.partial = nullptr; B.debug = nullptr; B.tile_order = nullptr;
-        B.tile_cost = s->tile_cost;                    // its pixels land in d_out and are overwritten by the real launch
+        B.n_chunks = 1; B.accum = nullptr; B.debug = nullptr; B.tile_order = nullptr;   // no sums: the probe only times the tiles
+        B.tile_cost = s->tile_cost;
         HIP_TRY(hipMemsetAsync(s->tile_cost, 0, (size_t)tiles * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(s->counter, 0, sizeof(uint32_t), st));
         uint32_t pgrid = (uint32_t)s->num_cus * s->wgs_per_cu, pneed = (A.n_local_tiles + waves_per_wg - 1) / waves_per_wg;
@@ -405,25 +403,27 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     HIP_TRY(hipMemsetAsync(s->counter, 0, sizeof(uint32_t), st));
     if (s->want_phase_stats) {
         const uint32_t FULLPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
-        if ((F != 0u && F != FULLPDF) || !lds) return fail(VK_ERR_UNSUPPORTED, "phase statistics are only built for the LDS-resident sphere-only and full/PDF variants");
+        if ((F != 0u && F != FULLPDF) || (!lds && F != 0u))
+            return fail(VK_ERR_UNSUPPORTED, "phase statistics are only built for the sphere-only variants and the LDS-resident full/PDF variant");
         if (!s->phase_stats) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->phase_stats), 16 * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(s->phase_stats, 0, 16 * sizeof(unsigned long long), st));
         A.phase_stats = s->phase_stats;
-        if (F == 0u) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<0u, true, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-            hipLaunchKernelGGL((render_kernel<0u, true, 6, true>), dim3(grid), dim3(s->wg_threads), shmem, st, A);
-        } else {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel<FULLPDF, true, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-            hipLaunchKernelGGL((render_kernel<FULLPDF, true, 4, true>), dim3(grid), dim3(s->wg_threads), shmem, st, A);
-        }
+        auto go = [&](auto kernel) -> int {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(s->wg_threads), shmem, st, A);
+            return VK_OK;
+        };
+        if (F == 0u) rc = lds ? go(&render_kernel<0u, true, 6, true>) : go(&render_kernel<0u, false, 6, true>);
+        else rc = go(&render_kernel<FULLPDF, true, 4, true>);
+        if (rc != VK_OK) return rc;
         HIP_TRY(hipGetLastError());
         F = 0xFFFFFFFFu;   // launched
     }
     if (F != 0xFFFFFFFFu) rc = launch_by_features(s, F, A, lds, dim3(grid), shmem, st, false);
     if (rc != VK_OK) return rc;
-    if (A.n_chunks > 1) {
+    {
         uint32_t blocks = (uint32_t)((n_pixels + 255) / 256);
-        hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(256), 0, st, (const float *)A.partial, d_out, p->width, p->height, A.n_chunks,
+        hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(256), 0, st, (const long long *)A.accum, d_out, p->width, p->height,
                            p->samples_per_pixel, A.tiles_x, A.tile_rank, A.tile_world);
         HIP_TRY(hipGetLastError());
         if (stats) stats->kernel_launches = 2;
@@ -517,7 +517,7 @@ void destroy_one(vk_scene *s) {
     for (vk_scene *q : s->parts) destroy_one(q);
     (void)hipSetDevice(s->device);
     for (void *p : s->allocs) (void)hipFree(p);
-    for (void *p : {(void *)s->counter, (void *)s->fb, (void *)s->fb8, (void *)s->partial, (void *)s->debug, (void *)s->phase_stats, (void *)s->tile_cost,
+    for (void *p : {(void *)s->counter, (void *)s->fb, (void *)s->fb8, (void *)s->accum, (void *)s->debug, (void *)s->phase_stats, (void *)s->tile_cost,
                     (void *)s->tile_order, (void *)s->order_hist, s->slab})
         if (p) (void)hipFree(p);
     if (s->landing) { (void)hipSetDevice(s->landing_device); (void)hipFree(s->landing); (void)hipSetDevice(s->device); }

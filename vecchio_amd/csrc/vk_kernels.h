@@ -38,7 +38,7 @@ struct KArgs {
     DScene S;
     RenderConsts C;
     float *out;              // full framebuffer (width*height*3)
-    float *partial;          // [n_chunks][width*height*3] when n_chunks > 1
+    long long *accum;        // [width*height*3] fixed-point pixel sums (see to_fixed); null in the probe launch
     float4 *debug;           // optional per-sample (rgb, draws) dump
     uint32_t *counter;       // work-unit counter
     uint32_t *tile_cost;     // [tiles of the image] time spent on each tile (1.6 us ticks): written by the probe (COST) build only
@@ -113,63 +113,80 @@ __device__ __forceinline__ typename std::conditional<LDS_SCENE, LdsMem, GlobalMe
     return M;
 }
 
-// Cold per-lane path state (throughput, radiance, RNG, pixel/sample ids, world ray) lives in
-// LDS between SHADE phases, SoA by field (word f of lane l at cold[f*64 + l]: conflict-free),
-// so that the box/primitive loops keep only the traversal state in VGPRs.
-constexpr int NCOLD_BASE = 11;      // thr3 acc3 depth key2 ctr (q | sample << 6)
-constexpr int NCOLD_INST = 17;      // + world-space ray (o3 d3) for scenes with instances
+// Cold per-lane path state lives in LDS between SHADE phases, SoA by field (word f of lane l at cold[f*64 + l]:
+// conflict-free), so that the box/primitive loops keep only the traversal state in VGPRs: throughput (3), depth, RNG key (2)
+// + counter, the sample's pixel (x | y << 16) and sample index (+ the world-space ray (o3 d3) for scenes with instances).
+// Radiance is not kept: no material both emits and scatters (material.rs:30-40,215-225), so it is 0 — or its NaN is implied
+// by a non-finite throughput — until the path ends.
+enum : int { CF_THR = 0, CF_DEPTH = 3, CF_KEY = 4, CF_CTR = 6, CF_XY = 7, CF_SAMPLE = 8, CF_WORLD_RAY = 9 };
+constexpr int NCOLD_BASE = 9;
+constexpr int NCOLD_INST = 15;
 template <uint32_t F> constexpr int ncold() { return (F & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE; }
+constexpr int WAVE_STATE_WORDS = 4;   // per-wave, wave-uniform: the unit whose samples are being handed out (see render_kernel)
+enum : int { WS_TXY = 0, WS_S0 = 1, WS_TOTAL = 2, WS_NEXT = 3 };   // one 16-byte record: tile origin (x | y << 16), first sample, items, items handed out
+
+// Pixel sums are ORDER-INDEPENDENT: every finished sample is added to its pixel's three 64-bit fixed-point accumulators
+// (2^-26 units: 1.5e-8 absolute per sample, sums up to 1.4e11) with integer atomics, so the image does not depend on which
+// lane, wave, work unit, tile partition or GPU traced a sample, nor on the order they finished in — without any lane ever
+// waiting for another one's path.  (The reference's `c += color` in f32, main.rs:193, is re-associated anyway: it never
+// feeds control flow.)  A sample beyond +-1e10 is clamped to it.
+constexpr float ACCUM_SCALE = 67108864.0f;          // 2^26
+constexpr float ACCUM_CLAMP = 1.0e10f;
+__device__ __forceinline__ long long to_fixed(float v) {
+    v = fminf(fmaxf(v, -ACCUM_CLAMP), ACCUM_CLAMP);
+    return (long long)(v * ACCUM_SCALE);             // scaling by a power of two is exact; the cast truncates toward zero
+}
 
 template <uint32_t F>
-__device__ __forceinline__ void cold_store(float *c, uint32_t lane, const Lane &L, uint32_t q) {
-    c[0 * 64 + lane] = L.thr.x; c[1 * 64 + lane] = L.thr.y; c[2 * 64 + lane] = L.thr.z;
-    c[3 * 64 + lane] = L.acc.x; c[4 * 64 + lane] = L.acc.y; c[5 * 64 + lane] = L.acc.z;
-    c[6 * 64 + lane] = __uint_as_float(L.depth);
-    c[7 * 64 + lane] = __uint_as_float((uint32_t)L.rng.key); c[8 * 64 + lane] = __uint_as_float((uint32_t)(L.rng.key >> 32));
-    c[9 * 64 + lane] = __uint_as_float(L.rng.ctr);
-    c[10 * 64 + lane] = __uint_as_float(q | (L.sample << 6));   // the pixel is implied by the unit's tile and q
+__device__ __forceinline__ void cold_store_path(float *c, uint32_t lane, const Lane &L) {
+    c[(CF_THR + 0) * 64 + lane] = L.thr.x; c[(CF_THR + 1) * 64 + lane] = L.thr.y; c[(CF_THR + 2) * 64 + lane] = L.thr.z;
+    c[CF_DEPTH * 64 + lane] = __uint_as_float(L.depth);
+    c[CF_KEY * 64 + lane] = __uint_as_float((uint32_t)L.rng.key); c[(CF_KEY + 1) * 64 + lane] = __uint_as_float((uint32_t)(L.rng.key >> 32));
+    c[CF_CTR * 64 + lane] = __uint_as_float(L.rng.ctr);
     if (F & VKF_INSTANCE) {
-        c[11 * 64 + lane] = L.wo.x; c[12 * 64 + lane] = L.wo.y; c[13 * 64 + lane] = L.wo.z;
-        c[14 * 64 + lane] = L.wd.x; c[15 * 64 + lane] = L.wd.y; c[16 * 64 + lane] = L.wd.z;
-    }
-}
-template <uint32_t F>
-__device__ __forceinline__ void cold_load(const float *c, uint32_t lane, Lane &L, uint32_t &q) {
-    L.thr = v3(c[0 * 64 + lane], c[1 * 64 + lane], c[2 * 64 + lane]);
-    L.acc = v3(c[3 * 64 + lane], c[4 * 64 + lane], c[5 * 64 + lane]);
-    L.depth = __float_as_uint(c[6 * 64 + lane]);
-    L.rng.key = (uint64_t)__float_as_uint(c[7 * 64 + lane]) | ((uint64_t)__float_as_uint(c[8 * 64 + lane]) << 32);
-    L.rng.ctr = __float_as_uint(c[9 * 64 + lane]);
-    uint32_t qs = __float_as_uint(c[10 * 64 + lane]);
-    q = qs & 63u; L.sample = qs >> 6; L.pixel = 0;
-    if (F & VKF_INSTANCE) {
-        L.wo = v3(c[11 * 64 + lane], c[12 * 64 + lane], c[13 * 64 + lane]);
-        L.wd = v3(c[14 * 64 + lane], c[15 * 64 + lane], c[16 * 64 + lane]);
-    } else {
-        L.wo = L.o; L.wd = L.d;       // no instances: the current space IS world space
+        c[(CF_WORLD_RAY + 0) * 64 + lane] = L.wo.x; c[(CF_WORLD_RAY + 1) * 64 + lane] = L.wo.y; c[(CF_WORLD_RAY + 2) * 64 + lane] = L.wo.z;
+        c[(CF_WORLD_RAY + 3) * 64 + lane] = L.wd.x; c[(CF_WORLD_RAY + 4) * 64 + lane] = L.wd.y; c[(CF_WORLD_RAY + 5) * 64 + lane] = L.wd.z;
     }
 }
 template <uint32_t F>
 __device__ __forceinline__ void cold_load_world_ray(const float *c, uint32_t lane, Lane &L) {
     if (F & VKF_INSTANCE) {
-        L.wo = v3(c[11 * 64 + lane], c[12 * 64 + lane], c[13 * 64 + lane]);
-        L.wd = v3(c[14 * 64 + lane], c[15 * 64 + lane], c[16 * 64 + lane]);
+        L.wo = v3(c[(CF_WORLD_RAY + 0) * 64 + lane], c[(CF_WORLD_RAY + 1) * 64 + lane], c[(CF_WORLD_RAY + 2) * 64 + lane]);
+        L.wd = v3(c[(CF_WORLD_RAY + 3) * 64 + lane], c[(CF_WORLD_RAY + 4) * 64 + lane], c[(CF_WORLD_RAY + 5) * 64 + lane]);
     }
 }
+template <uint32_t F>
+__device__ __forceinline__ void cold_load_path(const float *c, uint32_t lane, Lane &L) {
+    L.thr = v3(c[(CF_THR + 0) * 64 + lane], c[(CF_THR + 1) * 64 + lane], c[(CF_THR + 2) * 64 + lane]);
+    L.acc = v3s(0.0f);
+    L.depth = __float_as_uint(c[CF_DEPTH * 64 + lane]);
+    L.rng.key = (uint64_t)__float_as_uint(c[CF_KEY * 64 + lane]) | ((uint64_t)__float_as_uint(c[(CF_KEY + 1) * 64 + lane]) << 32);
+    L.rng.ctr = __float_as_uint(c[CF_CTR * 64 + lane]);
+    L.pixel = 0; L.sample = 0;
+    if (F & VKF_INSTANCE) cold_load_world_ray<F>(c, lane, L);
+    else { L.wo = L.o; L.wd = L.d; }       // no instances: the current space IS world space
+}
 
-// LDS word of a wave that holds the time its previous unit ended.  Re-derived from freshly loaded kernel arguments at
-// its uses (kernel start, unit end) so that no pointer stays live across the traversal loops.
-template <uint32_t F, bool LDS_SCENE>
-__device__ __forceinline__ uint32_t *unit_t0_word(uint32_t wave) {
-    KArgsC P = kargs_fresh();
-    uint32_t scene16 = LDS_SCENE ? 2u * KARG(P, lds_items) + KARG(P, lds_spheres) + 2u * KARG(P, lds_boxes) : 0u;
-    float *dyn = reinterpret_cast<float *>(smem + scene16);
-    return reinterpret_cast<uint32_t *>(dyn + (blockDim.x >> 6) * (64 * 3 + 64 * ncold<F>())) + wave;
+// adds the wave's LDS sums of tile `txy` (x | y << 16 of its origin; lane = pixel slot) to the frame's accumulators and clears them
+__device__ __forceinline__ void flush_tile_sums(unsigned long long *tile_sum, long long *accum, uint32_t txy, uint32_t lane, uint32_t width, uint32_t height) {
+    uint32_t px = (txy & 0xFFFFu) + (lane & 7u), py = (txy >> 16) + (lane >> 3);
+    if (!accum || txy == 0xFFFFFFFFu || px >= width || py >= height) return;
+    unsigned long long *a = reinterpret_cast<unsigned long long *>(accum) + ((size_t)py * width + px) * 3;
+    for (int c = 0; c < 3; c++) {
+        unsigned long long v = tile_sum[lane * 3 + c];
+        if (v) { atomicAdd(a + c, v); tile_sum[lane * 3 + c] = 0ull; }
+    }
 }
 
 // number of lanes of the wave for which p holds (v_cmp -> s_bcnt1, no VGPR round trip)
 __device__ __forceinline__ uint32_t lanes_with(bool p) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
 
+// Work distribution.  A work UNIT is (8x8 tile, sample chunk), pulled by a WAVE from a global atomic counter and handed
+// out to its lanes sample by sample (item k -> pixel slot k & 63, sample s0 + (k >> 6): the 64 primary rays of one sample
+// index start together, which keeps the first segments coherent).  A lane whose path ended takes the next item by ballot +
+// prefix popcount (active-ray compaction), and the wave pulls the NEXT unit the moment the current one is handed out:
+// nobody waits for the slowest path of a unit (the "drain" cost 5 % on C2 and most of the lanes on C5, whose tile costs
+// are heavy tailed).  That is possible because pixel sums are order independent (to_fixed above).
 template <uint32_t F, bool LDS_SCENE, int MINW, bool STATS, bool COST = false>
 __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ? 768 : 1024))), MINW) void render_kernel(KArgs A_byval) {
     (void)A_byval;
@@ -181,17 +198,21 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
     unsigned long long st_t_box = 0, st_t_light = 0, st_t_heavy = 0, st_t_shade = 0, st_heavy_execs = 0, st_t0 = 0, st_t_total = 0, st_t_mat = 0, st_t_refill = 0, st_t_install = 0, st_t1 = 0;
     if (STATS) st_t_total = clock64();
 
-    // ---- LDS layout: [items][spheres][per-wave pixel accumulators][per-wave cold lane state]
+    // ---- LDS layout: [items][spheres][boxes][per-wave cold lane state][per-wave tile sums][per-wave unit state]
     uint32_t lds_items = 0;
-    float *acc_lds, *cold;
+    float *cold;
+    unsigned long long *tile_sum;   // the wave's current tile: 64 pixels x 3 fixed-point sums
+    uint32_t *wstate;
     {
         KArgsC P = kargs_fresh();
         lds_items = LDS_SCENE ? KARG(P, lds_items) : 0u;
         uint32_t lds_spheres = LDS_SCENE ? KARG(P, lds_spheres) : 0u;
         uint32_t lds_boxes = LDS_SCENE ? KARG(P, lds_boxes) : 0u;
         float *dyn = reinterpret_cast<float *>(smem + (2u * lds_items + lds_spheres + 2u * lds_boxes));
-        acc_lds = dyn + wave * (64 * 3);
-        cold = dyn + (blockDim.x >> 6) * (64 * 3) + wave * (64 * ncold<F>());
+        const uint32_t n_waves = blockDim.x >> 6;
+        cold = dyn + wave * (64 * ncold<F>());
+        tile_sum = reinterpret_cast<unsigned long long *>(dyn + n_waves * (64 * ncold<F>())) + wave * (64 * 3);
+        wstate = reinterpret_cast<uint32_t *>(dyn + n_waves * (64 * ncold<F>() + 64 * 3 * 2)) + wave * WAVE_STATE_WORDS;
         if (LDS_SCENE) {
             const uint4 *gi = reinterpret_cast<const uint4 *>(KARG(P, S.items));
             for (uint32_t k = threadIdx.x; k < 2u * lds_items; k += blockDim.x) smem[(k >> 1) + ((k & 1u) ? lds_items : 0u)] = gi[k];
@@ -202,220 +223,219 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             __syncthreads();
         }
     }
+    // the wave has no unit yet: the first SHADE + REFILL phase pulls one
+    tile_sum[lane * 3 + 0] = 0ull; tile_sum[lane * 3 + 1] = 0ull; tile_sum[lane * 3 + 2] = 0ull;
+    if (lane == 0) { wstate[WS_TXY] = 0xFFFFFFFFu; wstate[WS_NEXT] = 0u; wstate[WS_TOTAL] = 0u; }
 
-    if (COST) { if (lane == 0) *unit_t0_word<F, LDS_SCENE>(wave) = (uint32_t)(wall_clock64() >> 4); }
+    Lane L;
+    memset(&L, 0, sizeof(L));
+    uint32_t cost_t0 = 0;      // probe (COST) build only: when this lane's current sample started
+    (void)cost_t0;
+    bool need = true;          // lane has no path and wants a sample (false once the launch's units are all handed out)
+    bool active = false;       // lane holds a live path
+    // Wave-level phase scheduler.  Every lane is in one of four states; each round the
+    // wave runs the code of the most populated state with the lanes in it (64-bit ballots
+    // + s_bcnt1), so the long box loop, the primitive tests and the (expensive, rare)
+    // shading / ray-generation code each execute with as many lanes as possible instead
+    // of all being paid for on every iteration:
+    //   BOX    pend == 0 and items (or an instance to leave) remain  -> box_step
+    //   PRIM   pend != 0                                             -> prim_step
+    //   SHADE  live path whose segment is fully traversed            -> shade
+    //   NEED   no path; samples remain                               -> start_sample
+    // SHADE and NEED run as one phase: a path that ends hands its lane straight to the
+    // next sample (ballot + prefix popcount = active-ray compaction).
     // (per-XCD work queues — contiguous image bands per XCD, stealing when empty — were tried for L2 locality on
     // C5: no gain there, -1.7 % on C2, and the two extra live scalars doubled the everything-variant's spills)
+    uint32_t shade_defer;
+    { KArgsC U = kargs_fresh(); shade_defer = KARG(U, shade_defer); }
     for (;;) {
-        KArgsC U = kargs_fresh();
-        uint32_t unit = 0;
-        if (lane == 0) unit = atomicAdd(KARG(U, counter), 1u);
-        unit = __builtin_amdgcn_readfirstlane(unit);
-        const uint32_t n_chunks = KARG(U, n_chunks);
-        if (unit >= KARG(U, n_local_tiles) * n_chunks) break;
-        const uint32_t chunk = unit % n_chunks;
-        // tiles are visited dearest-first when the probe launch left an order (see enqueue_render)
-        uint32_t tslot = unit / n_chunks;
-        { const uint32_t *ord = KARG(U, tile_order); if (ord) tslot = ord[tslot]; }
-        const uint32_t tile = KARG(U, tile_rank) + tslot * KARG(U, tile_world);
-        const uint32_t tiles_x = KARG(U, tiles_x);
-        const uint32_t tx = (tile % tiles_x) * TILE, ty = (tile / tiles_x) * TILE;
-        const uint32_t spp = KARG(U, C.spp);
-        const uint32_t s0 = (uint32_t)(((uint64_t)spp * chunk) / n_chunks);
-        const uint32_t s1 = (uint32_t)(((uint64_t)spp * (chunk + 1)) / n_chunks);
-        const uint32_t total = 64u * (s1 - s0);       // items: k -> (pixel slot k & 63, sample s0 + (k >> 6))
-
-        acc_lds[lane] = 0.0f; acc_lds[64 + lane] = 0.0f; acc_lds[128 + lane] = 0.0f;
-
-        Lane L;
-        memset(&L, 0, sizeof(L));
-        bool need = true;          // lane wants a new (pixel, sample)
-        bool active = false;       // lane holds a live path
-        uint32_t next_item = 0;    // wave-uniform
-        // Wave-level phase scheduler.  Every lane is in one of four states; each round the
-        // wave runs the code of the most populated state with the lanes in it (64-bit ballots
-        // + s_bcnt1), so the long box loop, the primitive tests and the (expensive, rare)
-        // shading / ray-generation code each execute with as many lanes as possible instead
-        // of all being paid for on every iteration:
-        //   BOX    pend == 0 and items (or an instance to leave) remain  -> box_step
-        //   PRIM   pend != 0                                             -> prim_step
-        //   SHADE  live path whose segment is fully traversed            -> shade
-        //   NEED   no path; the unit still has (pixel, sample) items     -> start_sample
-        // SHADE and NEED run as one phase: a path that ends hands its lane straight to the
-        // next item (ballot + prefix popcount = active-ray compaction).
-        const uint32_t shade_defer = KARG(U, shade_defer);
-        for (;;) {
-            bool is_prim = active && has_prim_work(L);
-            bool is_box = active && !is_prim && traversing(L);
-            bool is_shade = active && !is_prim && !is_box;
-            // primitives come in two weights (sphere/rect ~50 instructions; Boxy, list, medium, instance
-            // entry several times that): scheduled separately so cheap tests never pay for heavy ones
-            const bool HAS_HEAVY = (F & (VKF_LIST | VKF_MEDIUM | VKF_INSTANCE | VKF_BOX)) != 0;
-            bool is_heavy = HAS_HEAVY && is_prim && prim_is_heavy(L.pend);
-            uint32_t n_box = lanes_with(is_box);
-            uint32_t n_heavy = HAS_HEAVY ? lanes_with(is_heavy) : 0u;
-            uint32_t n_light = lanes_with(is_prim && !is_heavy);
-            if (n_heavy > n_light) { is_prim = is_heavy; } else { is_prim = is_prim && !is_heavy; }
-            uint32_t n_prim = n_heavy > n_light ? n_heavy : n_light;
-            uint32_t n_sn = lanes_with(is_shade || need);
-            if ((n_box | n_prim | n_sn) == 0) break;
-            if (STATS) st_sched++;
-            if (n_box >= n_prim && n_box * shade_defer >= n_sn) {
-                // ---- BOX: UNROLL steps under a shrinking EXEC mask per exit test, while box lanes are the plurality
-                KArgsC P = kargs_fresh();
-                DScene S = KARG(P, S);
-                Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
-                if (STATS) st_t0 = clock64();
-                cold_load_world_ray<F>(cold, lane, L);
-                const uint32_t live = n_box + n_heavy + n_light + n_sn;   // lanes only change state here, none appear or vanish
-                // steps between two exit tests (compile time: a run-time trip count costs 4-13 %).  With shading deferred the
-                // optimum is 3 for the sphere-only and Cornell-type variants (against 4: C2 +0.7 %, C4 +1.3 %; 2: -3 %, 6: -1 %,
-                // 8: -6 %) and 4 for the everything-variants (C3: 3 -> -2 %)
-                constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? BOX_UNROLL : BOX_UNROLL - 1;
-                for (;;) {
-                    if (F & VKF_INSTANCE) {     // end of an instance's item range: back to the parent space (rare)
-                        if (is_box && L.i >= L.end && L.cur_inst >= 0) leave_instance<F, Mem>(L, S);
+        bool is_prim = active && has_prim_work(L);
+        bool is_box = active && !is_prim && traversing(L);
+        bool is_shade = active && !is_prim && !is_box;
+        // primitives come in two weights (sphere/rect ~50 instructions; Boxy, list, medium, instance
+        // entry several times that): scheduled separately so cheap tests never pay for heavy ones
+        const bool HAS_HEAVY = (F & (VKF_LIST | VKF_MEDIUM | VKF_INSTANCE | VKF_BOX)) != 0;
+        bool is_heavy = HAS_HEAVY && is_prim && prim_is_heavy(L.pend);
+        uint32_t n_box = lanes_with(is_box);
+        uint32_t n_heavy = HAS_HEAVY ? lanes_with(is_heavy) : 0u;
+        uint32_t n_light = lanes_with(is_prim && !is_heavy);
+        if (n_heavy > n_light) { is_prim = is_heavy; } else { is_prim = is_prim && !is_heavy; }
+        uint32_t n_prim = n_heavy > n_light ? n_heavy : n_light;
+        uint32_t n_sn = lanes_with(is_shade || need);
+        if ((n_box | n_prim | n_sn) == 0) break;
+        if (STATS) st_sched++;
+        if (n_box >= n_prim && n_box * shade_defer >= n_sn) {
+            // ---- BOX: UNROLL steps under a shrinking EXEC mask per exit test, while box lanes are the plurality
+            KArgsC P = kargs_fresh();
+            DScene S = KARG(P, S);
+            Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
+            if (STATS) st_t0 = clock64();
+            cold_load_world_ray<F>(cold, lane, L);
+            const uint32_t live = n_box + n_heavy + n_light + n_sn;   // lanes only change state here, none appear or vanish
+            // steps between two exit tests (compile time: a run-time trip count costs 4-13 %).  With shading deferred the
+            // optimum is 3 for the sphere-only and Cornell-type variants (against 4: C2 +0.7 %, C4 +1.3 %; 2: -3 %, 6: -1 %,
+            // 8: -6 %) and 4 for the everything-variants (C3: 3 -> -2 %)
+            constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? BOX_UNROLL : BOX_UNROLL - 1;
+            for (;;) {
+                if (F & VKF_INSTANCE) {     // end of an instance's item range: back to the parent space (rare)
+                    if (is_box && L.i >= L.end && L.cur_inst >= 0) leave_instance<F, Mem>(L, S);
+                }
+                bool go = active && L.pend == 0u && L.i < range_end<F>(L, S);
+                if (STATS) {        // diagnostic build: same steps one at a time, counting the lanes in each
+                    for (int u = 0; u < UNROLL; u++) {
+                        st_box_steps += 1; st_box_lanes += lanes_with(go);
+                        box_steps<F, Mem, 1>(L, S, M, go);
+                        go = active && L.pend == 0u && L.i < range_end<F>(L, S);
                     }
-                    bool go = active && L.pend == 0u && L.i < range_end<F>(L, S);
-                    if (STATS) {        // diagnostic build: same steps one at a time, counting the lanes in each
-                        for (int u = 0; u < UNROLL; u++) {
-                            st_box_steps += 1; st_box_lanes += lanes_with(go);
-                            box_steps<F, Mem, 1>(L, S, M, go);
-                            go = active && L.pend == 0u && L.i < range_end<F>(L, S);
-                        }
-                    } else {
-                        box_steps<F, Mem, UNROLL>(L, S, M, go);
+                } else {
+                    box_steps<F, Mem, UNROLL>(L, S, M, go);
+                }
+                is_box = active && !has_prim_work(L) && traversing(L);
+                uint32_t nb = lanes_with(is_box);
+                uint32_t np = lanes_with(active && has_prim_work(L));
+                uint32_t ns = live - nb - np;
+                if (STATS && !HAS_HEAVY) { st_heavy_execs += live; st_t_light += np; st_t_heavy += ns; st_prim_execs += 1; }   // sphere-only diagnostic: lanes per exit test
+                if (nb == 0 || nb < np || nb * shade_defer < ns) {               // another state now has more lanes parked than are stepping
+                    // sphere-only variants: when that state is PRIM, test the pending spheres right here and
+                    // keep stepping (saves the scheduler round trip that otherwise follows every ~10 box steps)
+                    if (!HAS_HEAVY && !(F & VKF_MEDIUM) && np != 0 && np * shade_defer >= ns) {
+                        if (active && has_prim_work(L)) prim_step<F, Mem>(L, S, M);
+                        is_box = active && !has_prim_work(L) && traversing(L);
+                        continue;
                     }
-                    is_box = active && !has_prim_work(L) && traversing(L);
-                    uint32_t nb = lanes_with(is_box);
-                    uint32_t np = lanes_with(active && has_prim_work(L));
-                    uint32_t ns = live - nb - np;
-                    if (nb == 0 || nb < np || nb * shade_defer < ns) {               // another state now has more lanes parked than are stepping
-                        // sphere-only variants: when that state is PRIM, test the pending spheres right here and
-                        // keep stepping (saves the scheduler round trip that otherwise follows every ~10 box steps)
-                        if (!HAS_HEAVY && !(F & VKF_MEDIUM) && np != 0 && np * shade_defer >= ns) {
-                            if (active && has_prim_work(L)) prim_step<F, Mem>(L, S, M);
-                            is_box = active && !has_prim_work(L) && traversing(L);
-                            continue;
+                    break;
+                }
+            }
+            if (STATS) st_t_box += clock64() - st_t0;
+        } else if (n_prim * shade_defer >= n_sn) {
+            // ---- PRIM: intersect / enter the pending object
+            KArgsC P = kargs_fresh();
+            DScene S = KARG(P, S);
+            Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
+            if (STATS) { st_prim_execs++; st_prim_lanes += n_prim; st_t0 = clock64(); if (n_heavy > n_light) st_heavy_execs++; }
+            if (is_prim) {
+                if (F & VKF_MEDIUM) {    // ConstantMedium::hit draws inside traversal (hittable.rs:473)
+                    L.rng.key = (uint64_t)__float_as_uint(cold[CF_KEY * 64 + lane]) | ((uint64_t)__float_as_uint(cold[(CF_KEY + 1) * 64 + lane]) << 32);
+                    L.rng.ctr = __float_as_uint(cold[CF_CTR * 64 + lane]);
+                }
+                prim_step<F, Mem>(L, S, M);
+                if (F & VKF_MEDIUM) cold[CF_CTR * 64 + lane] = __uint_as_float(L.rng.ctr);
+            }
+            if (STATS) { if (n_heavy > n_light) st_t_heavy += clock64() - st_t0; else st_t_light += clock64() - st_t0; }
+        } else {
+            // ---- SHADE + REFILL
+            KArgsC P = kargs_fresh();
+            RenderConsts C = KARG(P, C);
+            DScene S = KARG(P, S);
+            Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
+            if (STATS) { st_shade_execs++; st_shade_lanes += n_sn; st_t0 = clock64(); }
+            bool touched = is_shade;      // lanes whose path state is in registers during this phase
+            bool fresh = false;           // lanes that leave this phase with a new ray to install; it is parked in the
+                                          // (dead) world-ray fields L.wo / L.wd / L.time, so it costs no registers
+            // (the everything-variant keeps one begin_segment per call site: merging them there doubled its spills)
+            constexpr bool ONE_INSTALL = (F & VKF_ALL_SCENE) != VKF_ALL_SCENE;
+            if (is_shade) {
+                cold_load_path<F>(cold, lane, L);
+                if (STATS) st_t1 = clock64();
+                bool cont;
+                if (ONE_INSTALL) {
+                    V3 no, nd; float nt;
+                    cont = shade_core<F, Mem>(L, S, M, C, no, nd, nt);
+                    if (cont) { L.wo = no; L.wd = nd; L.time = nt; fresh = true; }
+                } else {
+                    cont = shade<F, Mem>(L, S, M, C);
+                }
+                if (STATS) st_t_mat += clock64() - st_t1;
+                if (!cont) {
+                    uint32_t xy = __float_as_uint(cold[CF_XY * 64 + lane]);
+                    size_t pix = (size_t)(xy >> 16) * C.width + (xy & 0xFFFFu);
+                    float4 *dbg = KARG(P, debug);
+                    if (dbg) dbg[pix * C.spp + __float_as_uint(cold[CF_SAMPLE * 64 + lane])] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(L.rng.ctr));
+                    long long *acc = KARG(P, accum);
+                    if (acc && isfinite(L.acc.x) && isfinite(L.acc.y) && isfinite(L.acc.z)) {   // main.rs:192-194; c += color (main.rs:193)
+                        unsigned long long fx = (unsigned long long)to_fixed(L.acc.x), fy = (unsigned long long)to_fixed(L.acc.y), fz = (unsigned long long)to_fixed(L.acc.z);
+                        // a sample of the tile the wave is handing out (nearly all of them) lands in the wave's LDS sums, which
+                        // reach the frame's accumulators once per unit; a straggler of an earlier unit goes there directly
+                        if ((xy & 0xFFF8FFF8u) == __builtin_amdgcn_readfirstlane(wstate[WS_TXY])) {
+                            unsigned long long *t = tile_sum + ((xy & 7u) | ((xy >> 13) & 0x38u)) * 3u;
+                            atomicAdd(t + 0, fx); atomicAdd(t + 1, fy); atomicAdd(t + 2, fz);
+                        } else {
+                            unsigned long long *a = reinterpret_cast<unsigned long long *>(acc) + pix * 3;
+                            atomicAdd(a + 0, fx); atomicAdd(a + 1, fy); atomicAdd(a + 2, fz);
                         }
+                    }
+                    if (COST) {   // probe launch: the lane-time this sample took, charged to its tile
+                        uint32_t *tc = KARG(P, tile_cost);
+                        uint32_t now = (uint32_t)(wall_clock64() >> 4);
+                        if (tc) atomicAdd(&tc[((xy >> 16) / TILE) * KARG(P, tiles_x) + (xy & 0xFFFFu) / TILE], now - cost_t0);
+                    }
+                    active = false;
+                    need = true;
+                }
+            }
+            if (STATS) st_t1 = clock64();
+            // ---- hand out samples of the wave's current unit to the lanes without a path; pull the next unit when it is used up
+            for (;;) {
+                unsigned long long need_mask = __builtin_amdgcn_ballot_w64(need);
+                if (!need_mask) break;
+                uint4 ws = *reinterpret_cast<const uint4 *>(wstate);       // one ds_read_b128, the same address in every lane
+                uint32_t txy = __builtin_amdgcn_readfirstlane(ws.x), s0 = __builtin_amdgcn_readfirstlane(ws.y);
+                uint32_t total = __builtin_amdgcn_readfirstlane(ws.z), next = __builtin_amdgcn_readfirstlane(ws.w);
+                if (next >= total) {
+                    uint32_t unit = 0;
+                    if (lane == 0) unit = atomicAdd(KARG(P, counter), 1u);
+                    unit = __builtin_amdgcn_readfirstlane(unit);
+                    const uint32_t n_chunks = KARG(P, n_chunks);
+                    if (unit >= KARG(P, n_local_tiles) * n_chunks) {                      // the launch's units are all handed out:
+                        need = false;                                                     // these lanes idle until the wave's last path ends
                         break;
                     }
+                    flush_tile_sums(tile_sum, KARG(P, accum), txy, lane, C.width, C.height);  // the finished unit's sums so far
+                    const uint32_t chunk = unit % n_chunks;
+                    // tiles are visited dearest-first when the probe launch left an order (see enqueue_render)
+                    uint32_t tslot = unit / n_chunks;
+                    { const uint32_t *ord = KARG(P, tile_order); if (ord) tslot = ord[tslot]; }
+                    const uint32_t tile = KARG(P, tile_rank) + tslot * KARG(P, tile_world);
+                    const uint32_t tiles_x = KARG(P, tiles_x);
+                    s0 = (uint32_t)(((uint64_t)C.spp * chunk) / n_chunks);
+                    const uint32_t s1 = (uint32_t)(((uint64_t)C.spp * (chunk + 1)) / n_chunks);
+                    txy = ((tile % tiles_x) * TILE) | (((tile / tiles_x) * TILE) << 16);
+                    next = 0u; total = 64u * (s1 - s0);
+                    if (lane == 0) { wstate[WS_TXY] = txy; wstate[WS_S0] = s0; wstate[WS_TOTAL] = total; }
                 }
-                if (STATS) st_t_box += clock64() - st_t0;
-            } else if (n_prim * shade_defer >= n_sn) {
-                // ---- PRIM: intersect / enter the pending object
-                KArgsC P = kargs_fresh();
-                DScene S = KARG(P, S);
-                Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
-                if (STATS) { st_prim_execs++; st_prim_lanes += n_prim; st_t0 = clock64(); if (n_heavy > n_light) st_heavy_execs++; }
-                if (is_prim) {
-                    if (F & VKF_MEDIUM) {    // ConstantMedium::hit draws inside traversal (hittable.rs:473)
-                        L.rng.key = (uint64_t)__float_as_uint(cold[7 * 64 + lane]) | ((uint64_t)__float_as_uint(cold[8 * 64 + lane]) << 32);
-                        L.rng.ctr = __float_as_uint(cold[9 * 64 + lane]);
-                    }
-                    prim_step<F, Mem>(L, S, M);
-                    if (F & VKF_MEDIUM) cold[9 * 64 + lane] = __uint_as_float(L.rng.ctr);
-                }
-                if (STATS) { if (n_heavy > n_light) st_t_heavy += clock64() - st_t0; else st_t_light += clock64() - st_t0; }
-            } else {
-                // ---- SHADE + REFILL
-                KArgsC P = kargs_fresh();
-                RenderConsts C = KARG(P, C);
-                DScene S = KARG(P, S);
-                Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
-                if (STATS) { st_shade_execs++; st_shade_lanes += n_sn; st_t0 = clock64(); }
-                uint32_t q = 0;
-                bool touched = is_shade;      // lanes whose cold state is in registers during this phase
-                bool fresh = false;           // lanes that leave this phase with a new ray to install; it is parked in the
-                                              // (dead) world-ray fields L.wo / L.wd / L.time, so it costs no registers
-                // (the everything-variant keeps one begin_segment per call site: merging them there doubled its spills)
-                constexpr bool ONE_INSTALL = (F & VKF_ALL_SCENE) != VKF_ALL_SCENE;
-                if (is_shade) {
-                    cold_load<F>(cold, lane, L, q);
-                    if (STATS) st_t1 = clock64();
-                    bool cont;
-                    if (ONE_INSTALL) {
-                        V3 no, nd; float nt;
-                        cont = shade_core<F, Mem>(L, S, M, C, no, nd, nt);
-                        if (cont) { L.wo = no; L.wd = nd; L.time = nt; fresh = true; }
-                    } else {
-                        cont = shade<F, Mem>(L, S, M, C);
-                    }
-                    if (STATS) st_t_mat += clock64() - st_t1;
-                    if (!cont) {
-                        float4 *dbg = KARG(P, debug);
-                        if (dbg) dbg[((size_t)(ty + (q >> 3)) * C.width + (tx + (q & 7u))) * C.spp + L.sample] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(L.rng.ctr));
-                        if (isfinite(L.acc.x) && isfinite(L.acc.y) && isfinite(L.acc.z)) {   // main.rs:192-194
-                            atomicAdd(&acc_lds[q * 3 + 0], L.acc.x);
-                            atomicAdd(&acc_lds[q * 3 + 1], L.acc.y);
-                            atomicAdd(&acc_lds[q * 3 + 2], L.acc.z);
-                        }
-                        active = false;
-                        need = true;
-                    }
-                }
-                if (STATS) st_t1 = clock64();
-                unsigned long long need_mask = __builtin_amdgcn_ballot_w64(need);
-                if (need_mask) {
-                    uint32_t rank = __popcll(need_mask & ((1ull << lane) - 1ull));
-                    if (need) {
-                        uint32_t k = next_item + rank;
-                        if (k < total) {
-                            q = k & 63u;
-                            uint32_t s = s0 + (k >> 6);
-                            uint32_t px = tx + (q & 7u), py = ty + (q >> 3);
-                            if (px < C.width && py < C.height) {   // slots outside the image (edge tiles) are skipped
-                                if (ONE_INSTALL) {
-                                    V3 no, nd; float nt;
-                                    start_sample_core(L, C, px, py, s, no, nd, nt);
-                                    L.wo = no; L.wd = nd; L.time = nt;
-                                    fresh = true;
-                                } else {
-                                    start_sample(L, S, C, px, py, s);
-                                }
-                                active = true;
-                                need = false;
-                                touched = true;
-                            }
+                uint32_t k = next + (uint32_t)__popcll(need_mask & ((1ull << lane) - 1ull));
+                if (need && k < total) {
+                    uint32_t q = k & 63u, smp = s0 + (k >> 6);
+                    uint32_t px = (txy & 0xFFFFu) + (q & 7u), py = (txy >> 16) + (q >> 3);
+                    if (px < C.width && py < C.height) {   // slots outside the image (edge tiles) are skipped: the lane asks again
+                        cold[CF_XY * 64 + lane] = __uint_as_float(px | (py << 16));
+                        cold[CF_SAMPLE * 64 + lane] = __uint_as_float(smp);
+                        if (COST) cost_t0 = (uint32_t)(wall_clock64() >> 4);
+                        if (ONE_INSTALL) {                 // the lane's next sample (main.rs:186-190)
+                            V3 no, nd; float nt;
+                            start_sample_core(L, C, px, py, smp, no, nd, nt);
+                            L.wo = no; L.wd = nd; L.time = nt;
+                            fresh = true;
                         } else {
-                            need = false;                           // unit exhausted: this lane idles until the wave drains
+                            start_sample(L, S, C, px, py, smp);
                         }
+                        active = true;
+                        need = false;
+                        touched = true;
                     }
-                    next_item += (uint32_t)__popcll(need_mask);
                 }
-                if (STATS) { st_t_refill += clock64() - st_t1; st_t1 = clock64(); }
-                if (ONE_INSTALL && fresh) begin_segment(L, S, L.wo, L.wd, L.time);   // one copy of the exact reciprocals for both kinds of new ray
-                if (active && touched) cold_store<F>(cold, lane, L, q);
-                if (STATS) { st_t_shade += clock64() - st_t0; st_t_install += clock64() - st_t1; }
+                uint32_t taken = (uint32_t)__popcll(need_mask);
+                if (lane == 0) wstate[WS_NEXT] = next + taken < total ? next + taken : total;
             }
+            if (STATS) { st_t_refill += clock64() - st_t1; st_t1 = clock64(); }
+            if (ONE_INSTALL && fresh) begin_segment(L, S, L.wo, L.wd, L.time);   // one copy of the exact reciprocals for both kinds of new ray
+            if (active && touched) cold_store_path<F>(cold, lane, L);
+            if (STATS) { st_t_shade += clock64() - st_t0; st_t_install += clock64() - st_t1; }
         }
-        // ---- write the unit's pixel sums
-        {
-            KArgsC P = kargs_fresh();
-            if (COST) {   // probe launch: time since this wave's previous unit ended = this unit's cost (units run back to back)
-                uint32_t *tc = KARG(P, tile_cost);
-                if (tc && lane == 0) {
-                    uint32_t *w = unit_t0_word<F, LDS_SCENE>(wave);
-                    uint32_t now = (uint32_t)(wall_clock64() >> 4);
-                    atomicAdd(&tc[(ty / TILE) * KARG(P, tiles_x) + tx / TILE], now - *w);
-                    *w = now;
-                }
-            }
-            uint32_t width = KARG(P, C.width), height = KARG(P, C.height);
-            uint32_t px = tx + (lane & 7u), py = ty + (lane >> 3);
-            if (px < width && py < height) {
-                size_t pix = (size_t)py * width + px;
-                float r = acc_lds[lane * 3 + 0], g = acc_lds[lane * 3 + 1], b = acc_lds[lane * 3 + 2];
-                if (n_chunks == 1) {
-                    float n = (float)KARG(P, C.spp);                         // main.rs:196
-                    float *o = KARG(P, out);
-                    o[pix * 3 + 0] = r / n; o[pix * 3 + 1] = g / n; o[pix * 3 + 2] = b / n;
-                } else {
-                    float *p = KARG(P, partial) + ((size_t)chunk * ((size_t)width * height) + pix) * 3;
-                    p[0] = r; p[1] = g; p[2] = b;
-                }
-            }
-        }
+    }
+    {   // the last unit's sums
+        KArgsC P = kargs_fresh();
+        flush_tile_sums(tile_sum, KARG(P, accum), __builtin_amdgcn_readfirstlane(wstate[WS_TXY]), lane, KARG(P, C.width), KARG(P, C.height));
     }
     if (STATS) {
         KArgsC P = kargs_fresh();
@@ -454,8 +474,8 @@ __global__ void order_scatter_kernel(uint32_t *cost, uint32_t n_local, uint32_t 
     order[atomicAdd(&hist[cost_bucket(cost[t])], 1u)] = i;
 }
 
-// sums the sample chunks of each pixel in chunk order (deterministic) and divides by spp
-__global__ void resolve_kernel(const float *partial, float *out, uint32_t width, uint32_t height, uint32_t n_chunks, uint32_t spp,
+// pixel mean = fixed-point sum / spp (main.rs:196), for the pixels of this call's tile partition
+__global__ void resolve_kernel(const long long *accum, float *out, uint32_t width, uint32_t height, uint32_t spp,
                                uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world) {
     uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_pixels = width * height;
@@ -463,13 +483,12 @@ __global__ void resolve_kernel(const float *partial, float *out, uint32_t width,
     uint32_t x = pix % width, y = pix / width;
     uint32_t tile = (y / TILE) * tiles_x + (x / TILE);
     if (tile % tile_world != tile_rank) return;
-    float r = 0.0f, g = 0.0f, b = 0.0f;
-    for (uint32_t c = 0; c < n_chunks; c++) {
-        const float *p = partial + ((size_t)c * n_pixels + pix) * 3;
-        r += p[0]; g += p[1]; b += p[2];
-    }
     float n = (float)spp;
-    out[(size_t)pix * 3 + 0] = r / n; out[(size_t)pix * 3 + 1] = g / n; out[(size_t)pix * 3 + 2] = b / n;
+    const long long *a = accum + (size_t)pix * 3;
+    const float inv_scale = 1.0f / ACCUM_SCALE;
+    out[(size_t)pix * 3 + 0] = ((float)a[0] * inv_scale) / n;
+    out[(size_t)pix * 3 + 1] = ((float)a[1] * inv_scale) / n;
+    out[(size_t)pix * 3 + 2] = ((float)a[2] * inv_scale) / n;
 }
 
 // Vec3::to_color (vec3.rs:44-61): sqrt gamma, hand-written clamp (NaN falls through it), *256, `as u32`
