@@ -73,6 +73,7 @@ struct EnvSwitches {
     int shade_defer = 0;               // VK_SHADE_DEFER=n
     bool tile_order = true;            // VK_TILE_ORDER=0: raster order, no probe launch
     int probe_spp = 0;                 // VK_PROBE_SPP=n
+    int prim_weight = 0;               // VK_PRIM_WEIGHT=n
     static int int_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
     static EnvSwitches read() {
         EnvSwitches v;
@@ -83,6 +84,7 @@ struct EnvSwitches {
         v.chunk_cap = int_env("VK_CHUNK_CAP");
         v.shade_defer = int_env("VK_SHADE_DEFER");
         v.probe_spp = int_env("VK_PROBE_SPP");
+        v.prim_weight = int_env("VK_PRIM_WEIGHT");
         return v;
     }
 };
@@ -276,26 +278,16 @@ uint64_t partition_samples(const vk_render_params *p, const TileGeom &g) {
 // number of sample chunks per tile.  Pixel sums are order independent, so this only sets the granularity of the work
 // units (locality of a wave's samples against the spread of expensive tiles over many waves), never a pixel's value
 uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
-    // Samples per pixel per unit: large enough that the end-of-unit tail (lanes idling while the last long
-    // paths of a unit finish) stays small, small enough that tiles of very different cost (fog, glass,
-    // grazing rays over 1M spheres) are spread over many waves; small images get smaller chunks so that
-    // there are still ~64K units for ~6K waves.
-    // A function of the image, spp and scene only, never of the tile partition (see above).
-    // (Tried for the multi-GPU tail — one rank of 8 renders C2's 1/8 in 77.7 ms against 65.3 ideal: cutting the last
-    // chunk of every tile into 8 small ones and ordering the units chunk by chunk so that the launch ends on short
-    // units.  Slower, 80.4 ms: short units pay the per-unit drain; the tail is heavy tiles, not the last unit.)
+    // Samples per pixel per unit: a unit keeps a wave on one tile (coherent primary rays, LDS tile sums flushed once per
+    // unit); small enough that tiles of very different cost (fog, glass, grazing rays over 1M spheres) are spread over many
+    // waves and that small images still give ~64K units for ~6K waves.  (C2: 32 / 64 / 128 spp per unit -> 5 218 / 5 235 / 5 221.)
     uint64_t tiles = (uint64_t)((p->width + TILE - 1) / TILE) * ((p->height + TILE - 1) / TILE);
     uint64_t c = (uint64_t)p->samples_per_pixel * tiles / 65536u;
-    uint32_t cap = 64;    // measured on C2: 64..128 samples per pixel per unit is the optimum (256: -3 %, 32: -5 %)
-    // Scenes that exceed an XCD's L2 (C5): tile costs are skewed by orders of magnitude (rays grazing a million
-    // spheres at the horizon) and one wave's 64-spp unit of the dearest tile was the critical path of the whole
-    // launch (C5 at 64 spp: 67 s, 28 s with 8-spp units).  Short units pay the per-unit drain (lanes idle while
-    // the unit's last paths finish), so: at least 8 units per tile, 8..32 spp each (C5 at 256 spp: 8 -> 44, 16 -> 54,
-    // 32 -> 55, 64 -> 45 Msamples/s).
-    if (s->hot_bytes > (4u << 20)) {      // bigger than one XCD's L2
-        uint32_t v = p->samples_per_pixel / 8u;
-        cap = v < 8u ? 8u : (v > 32u ? 32u : v);
-    }
+    uint32_t cap = 64;
+    // Scenes that exceed an XCD's L2 (C5): tile costs are skewed by orders of magnitude (rays grazing a million spheres at
+    // the horizon), and the launch ends with the last units of the dearest tiles: small units spread them over more waves
+    // (C5 at 256 spp: 4 -> 191, 8 -> 189, 16 -> 185, 32 -> 175 Msamples/s; at 32 spp: 4 -> 121, 8 -> 92, 16 -> 60, 32 -> 36)
+    if (s->hot_bytes > (4u << 20)) cap = p->samples_per_pixel >= 128u ? 8u : 4u;     // bigger than one XCD's L2
     if (s->env.chunk_cap >= 1) cap = (uint32_t)s->env.chunk_cap;   // diagnostics
     uint32_t lo = cap < 32 ? cap : 32;
     uint32_t chunk_spp = (uint32_t)(c > cap ? cap : (c < lo ? lo : c));
@@ -324,6 +316,8 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     A.counter = s->counter;
     A.shade_defer = s->hot_bytes > (4u << 20) ? 1u : SHADE_DEFER;
     if (s->env.shade_defer >= 1 && s->env.shade_defer <= 64) A.shade_defer = (uint32_t)s->env.shade_defer;   // diagnostics
+    A.prim_weight = 1u;
+    if (s->env.prim_weight >= 1 && s->env.prim_weight <= 64) A.prim_weight = (uint32_t)s->env.prim_weight;   // diagnostics
     size_t n_pixels = (size_t)p->width * p->height;
     if (stats) {
         stats->samples = partition_samples(p, g);

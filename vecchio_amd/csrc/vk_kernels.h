@@ -48,6 +48,7 @@ struct KArgs {
     uint32_t tile_rank, tile_world;
     uint32_t n_chunks;
     uint32_t shade_defer;    // SHADE + REFILL runs when its lanes outnumber box and primitive lanes this many times (see SHADE_DEFER)
+    uint32_t prim_weight;    // pending primitive tests run when prim_weight x their lanes outnumber the box lanes
     uint32_t lds_items, lds_spheres, lds_boxes;   // record counts staged into LDS (LDS variant)
     unsigned long long *phase_stats;   // optional (diagnostic build of the kernel): 16 counters, see vk_debug_phase_stats
 };
@@ -246,8 +247,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
     // next sample (ballot + prefix popcount = active-ray compaction).
     // (per-XCD work queues — contiguous image bands per XCD, stealing when empty — were tried for L2 locality on
     // C5: no gain there, -1.7 % on C2, and the two extra live scalars doubled the everything-variant's spills)
-    uint32_t shade_defer;
-    { KArgsC U = kargs_fresh(); shade_defer = KARG(U, shade_defer); }
+    uint32_t shade_defer, prim_weight;
+    { KArgsC U = kargs_fresh(); shade_defer = KARG(U, shade_defer); prim_weight = KARG(U, prim_weight); }
     for (;;) {
         bool is_prim = active && has_prim_work(L);
         bool is_box = active && !is_prim && traversing(L);
@@ -264,7 +265,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
         uint32_t n_sn = lanes_with(is_shade || need);
         if ((n_box | n_prim | n_sn) == 0) break;
         if (STATS) st_sched++;
-        if (n_box >= n_prim && n_box * shade_defer >= n_sn) {
+        if (n_box >= n_prim * prim_weight && n_box * shade_defer >= n_sn) {
             // ---- BOX: UNROLL steps under a shrinking EXEC mask per exit test, while box lanes are the plurality
             KArgsC P = kargs_fresh();
             DScene S = KARG(P, S);
@@ -295,7 +296,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 uint32_t np = lanes_with(active && has_prim_work(L));
                 uint32_t ns = live - nb - np;
                 if (STATS && !HAS_HEAVY) { st_heavy_execs += live; st_t_light += np; st_t_heavy += ns; st_prim_execs += 1; }   // sphere-only diagnostic: lanes per exit test
-                if (nb == 0 || nb < np || nb * shade_defer < ns) {               // another state now has more lanes parked than are stepping
+                if (nb == 0 || nb < np * prim_weight || nb * shade_defer < ns) {   // another state now has more lanes parked than are stepping
                     // sphere-only variants: when that state is PRIM, test the pending spheres right here and
                     // keep stepping (saves the scheduler round trip that otherwise follows every ~10 box steps)
                     if (!HAS_HEAVY && !(F & VKF_MEDIUM) && np != 0 && np * shade_defer >= ns) {

@@ -447,6 +447,15 @@ VK_HD void box_step(Lane &L, const DScene &S, const Mem &M, bool on) {
 template <uint32_t F, class Mem>
 VK_HD void prim_step(Lane &L, const DScene &S, const Mem &M) {
     uint32_t ref = L.pend;
+    if ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) {
+        // sphere-only variants: both objects of the leaf in ONE step (left first, the right one sees the tmax the left one
+        // left behind, accel.rs:64-70): the lane is back in the box loop after one primitive phase instead of two
+        uint32_t ref2 = L.pend2;
+        L.pend = 0; L.pend2 = 0;
+        process_ref<F, Mem>(L, S, M, ref);
+        if (ref2) process_ref<F, Mem>(L, S, M, ref2);
+        return;
+    }
     L.pend = L.pend2;
     L.pend2 = 0;
     process_ref<F, Mem>(L, S, M, ref);
