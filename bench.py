@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run check of the timed framebuffer against the oracle")
     ap.add_argument("--no-also", action="store_true", help="skip the single steps of the other BASELINE configs")
+    ap.add_argument("--fast-accel", action="store_true",
+                    help="set VK_SCENE_FAST_ACCEL in the scene description: the library rebuilds draw-free subtrees with its SAH builder "
+                         "(opt-in; not the headline: see include/vecchio_amd.h)")
     ap.add_argument("--in-library", action="store_true",
                     help="N GPUs from ONE process through vk_scene_create_multi (the library deals tiles, gathers on device 0) "
                          "instead of one process per GPU; run without torchrun")
@@ -141,7 +144,7 @@ def main():
     import oracle_ffi as O
     cores = os.cpu_count() or 1
 
-    def run_workload(name, steps, warmup, spp_override=0, want_cpu=False, bvh="reference"):
+    def run_workload(name, steps, warmup, spp_override=0, want_cpu=False, bvh="reference", fast_accel=False):
         scene_name, width, spp, depth, label = WORKLOADS[name]
         if spp_override:
             spp = spp_override
@@ -150,6 +153,10 @@ def main():
             scene_name += "+sah"
             label += " [SAH BVH over the same objects]"
         hs = HostScene(scene_name, 1)                        # scene seed 1
+        if fast_accel:
+            from vecchio_amd import ffi
+            hs.desc.contents.flags = ffi.VK_SCENE_FAST_ACCEL
+            label += " [VK_SCENE_FAST_ACCEL: draw-free subtrees rebuilt by the library]"
         cam = hs.next_camera()
         params = hs.params(width, spp, depth, seed=2, tile_rank=rank, tile_world=world)   # render seed 2
         height = params.height
@@ -220,7 +227,7 @@ def main():
             # process, so they come from the committed rocprofv3 passes of this same command (profiles/, tests/prof_r02.sh):
             # WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950: FETCH_SIZE counts half the bytes of wide reads -> upper bound)
             traffic, issue, prof_path = None, None, None
-            if n_gpus == 1 and not spp_override and bvh == "reference":
+            if n_gpus == 1 and not spp_override and bvh == "reference" and not fast_accel:
                 prof, prof_path = pmc_summary(name)
                 if prof:
                     d = prof.get("derived", {})
@@ -260,11 +267,12 @@ def main():
         hs.close()
         return res
 
-    main_res = run_workload(args.workload, args.steps, args.warmup, args.spp, want_cpu=(n_gpus == 1 and not args.no_cpu), bvh=args.bvh)
+    main_res = run_workload(args.workload, args.steps, args.warmup, args.spp, want_cpu=(n_gpus == 1 and not args.no_cpu), bvh=args.bvh,
+                            fast_accel=args.fast_accel)
     also = []
     if n_gpus == 1 and not args.no_also and args.workload == "C2" and not args.spp:
-        for name, spp_o in (("C4", 0), ("C3", 0), ("C5", 32)):
-            r = run_workload(name, 1, 0, spp_o)
+        for name, spp_o, fa in (("C4", 0, False), ("C3", 0, False), ("C5", 32, False), ("C2", 0, True)):
+            r = run_workload(name, 1, 0, spp_o, fast_accel=fa)
             also.append({"workload": r["label"], "Msamples_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": 1,
                          "verified": r["verified"], "roofline_frac": r["roofline"]["frac"] if r["roofline"] else None,
                          "issue_frac": (r["roofline"] or {}).get("issue", None) and r["roofline"]["issue"]["frac"]})

@@ -12,9 +12,18 @@
 #include "../../vecchio_amd/csrc/vk_linearize.h"
 #include "../../vecchio_amd/csrc/vk_trace.h"
 
+#include <cstdlib>
+
 using namespace vkd;
 
 static thread_local std::string g_err;
+
+// VK_RETREE=0/1 forces re-treeing off / on (same switch as the device library); default: vk_scene_desc.flags
+static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string &err) {
+    LinearizeOptions opt;
+    if (const char *e = getenv("VK_RETREE")) opt.retree = e[0] != '0' ? 1 : 0;
+    return linearize(desc, LS, err, opt);
+}
 
 template <uint32_t F>
 static void trace_one(const DScene &S, const GlobalMem &M, const RenderConsts &C, uint32_t pixel, uint32_t sample, V3 &rgb, uint32_t &draws, uint64_t *steps) {
@@ -48,7 +57,7 @@ static const uint32_t FPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
 int emu_sample(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *p, uint32_t pixel, uint32_t sample,
                float rgb[3], uint32_t *draws) {
     LinearScene LS;
-    int st = linearize(desc, LS, g_err);
+    int st = linearize_env(desc, LS, g_err);
     if (st != VK_OK) return st;
     DScene S = LS.host_view();
     GlobalMem M{S.items, S.spheres, S.sphere_mat, S.boxes};
@@ -61,11 +70,27 @@ int emu_sample(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
     return VK_OK;
 }
 
+// debug: the primary ray of (pixel, sample) and the closest hit of its first segment: out = o3, d3, T, best_prim (bits)
+int emu_first_hit(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *p, uint32_t pixel, uint32_t sample, float out[8]) {
+    LinearScene LS;
+    int st = linearize_env(desc, LS, g_err);
+    if (st != VK_OK) return st;
+    DScene S = LS.host_view();
+    GlobalMem M{S.items, S.spheres, S.sphere_mat, S.boxes};
+    RenderConsts C = make_consts(cam, p);
+    Lane L;
+    start_sample(L, S, C, pixel % C.width, pixel / C.width, sample);
+    out[0] = L.o.x; out[1] = L.o.y; out[2] = L.o.z; out[3] = L.d.x; out[4] = L.d.y; out[5] = L.d.z;
+    while (traversing(L)) traverse_step<FALL, GlobalMem>(L, S, M);
+    out[6] = L.T; memcpy(&out[7], &L.best_prim, 4);
+    return VK_OK;
+}
+
 // per-sample outputs: out_rgbd[(pixel*spp + s)*4 + {0,1,2}] = radiance, [3] = draw count (as float bits of uint)
 int emu_render(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *p, float *rgb_out,
                float *per_sample_out, int n_threads, uint64_t *steps_out, uint32_t *info_out) {
     LinearScene LS;
-    int st = linearize(desc, LS, g_err);
+    int st = linearize_env(desc, LS, g_err);
     if (st != VK_OK) return st;
     if (p->integrator == VK_INTEGRATOR_PDF && LS.lights.empty()) { g_err = "PDF integrator needs a non-empty lights list (hittable.rs:431 would panic)"; return VK_ERR_UNSUPPORTED; }
     DScene S = LS.host_view();

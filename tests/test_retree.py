@@ -1,0 +1,119 @@
+"""Re-treeing (vk_linearize.cpp; opt-in, vk_scene_desc.flags & VK_SCENE_FAST_ACCEL): the lineariser rebuilds draw-free subtrees (>= 16 Sphere / Rect / Boxy / list objects, no
+ConstantMedium, no Translate/Rotate) with a SAH builder, because BVHNode::hit's result (accel.rs:58-83) does not depend on
+the tree over such objects — except for EXACT ties in t, where the reference's choice (Rect::hit's inclusive bound
+hittable.rs:232, Sphere::hit's strict one :75, the list scan's strict one :386, BVHNode::hit's `l.t < r.t` accel.rs:73)
+is reproduced from the objects' positions in the reference's visiting order.  These scenes are crowds of such objects with
+deliberately coincident geometry (every hit of a duplicated object is an exact tie between two materials), in random tree
+shapes, and the kernel's formulation must agree with the recursive oracle on every sample — with and without re-treeing."""
+import os
+
+import numpy as np
+import pytest
+
+from descs import Desc, camera, params
+from test_emu_parity import compare
+from test_fuzz_scenes import Gen, _union
+from vecchio_amd import ffi
+
+
+class Crowd(Gen):
+    def crowd(self, n):
+        objs = []
+        while len(objs) < n:
+            k = self.r.uniform()
+            if k < 0.45:
+                ref, bb = self.sphere()
+            elif k < 0.7:
+                ref, bb = self.rect()
+            elif k < 0.85:
+                ref, bb = self.boxy()
+            else:                                           # a generic list of spheres / rects (no moving spheres: those are not re-treed)
+                items, bb = [], None
+                for _ in range(int(self.r.integers(1, 4))):
+                    r_, b = (self.sphere if self.r.uniform() < 0.5 else self.rect)()
+                    items.append(Desc.flip(r_) if self.r.uniform() < 0.3 else r_); bb = b if bb is None else _union(bb, b)
+                ref = self.d.list_(items)
+            if self.r.uniform() < 0.2:
+                ref = Desc.flip(ref)
+            objs.append((ref, bb))
+            # coincident copies with another material: same geometry, so every hit of it is an exact tie
+            if self.r.uniform() < 0.35:
+                kind, idx = ref >> 28, ref & ffi.VK_REF_INDEX_MASK
+                if kind == ffi.VK_KIND_SPHERE:
+                    s = self.d.spheres[idx]
+                    objs.append((self.d.sphere(tuple(s.center), s.radius, self.mat()), bb))
+                elif kind == ffi.VK_KIND_RECT:
+                    q = self.d.rects[idx]
+                    dup = self.d.rect(q.c0, q.c1, q.d0, q.d1, q.k, (q.axis0, q.axis1, q.axis2), self.mat())
+                    objs.append((dup, bb))
+                    if self.r.uniform() < 0.5:              # ... and a Boxy whose face lies in the same plane
+                        lo, hi = np.array(bb[0]) + 1e-3, np.array(bb[1]) - 1e-3
+                        lo[q.axis2] = q.k; hi[q.axis2] = q.k + 1.0
+                        objs.append((self.d.boxy(tuple(lo), tuple(hi), self.mat()), (lo - 1e-3, hi + 1e-3)))
+                if self.r.uniform() < 0.3 and len(objs) >= 2:
+                    objs.append(objs[-2])                   # the very same object twice in the tree (a shared Arc)
+        return objs
+
+    def build(self):
+        n = int(self.r.integers(18, 56))
+        objs = self.crowd(n)
+        order = self.r.permutation(len(objs))
+        ref, bb = self.tree([objs[i] for i in order])
+        top = [(ref, bb)]
+        if self.r.uniform() < 0.5:                          # the crowd under a transform (an instance's own item range)
+            off = self.r.uniform(-1, 1, 3)
+            top = [(self.d.translate(ref, tuple(off)), (bb[0] + off, bb[1] + off))]
+        if self.r.uniform() < 0.6:                          # something that draws during traversal next to it: only the crowd is re-treed
+            top.append(self.medium())
+        if self.r.uniform() < 0.5:
+            top.append(self.moving())
+        lref, lbb = self.rect(m=self.emit)
+        top.append((Desc.flip(lref), lbb)); self.lights.append(lref)
+        world, _ = self.tree([top[i] for i in self.r.permutation(len(top))])
+        if (world >> 28) != ffi.VK_KIND_BVH:
+            world = self.d.big_box(world, world)
+        desc = self.d.finish(world, self.lights if self.use_pdf else [])
+        desc.contents.flags = ffi.VK_SCENE_FAST_ACCEL
+        ang = self.r.uniform(0, 6.28)
+        cam = camera((5 + 13 * np.cos(ang), self.r.uniform(3, 8), 5 + 13 * np.sin(ang)), (5, 5, 5), vfov=50.0)
+        kw = {} if self.use_pdf else dict(integrator=ffi.VK_INTEGRATOR_SCATTER, background=ffi.VK_BACKGROUND_SKY)
+        return desc, cam, params(24, 20, 4, max_depth=int(self.r.choice([3, 12, 50])), seed=int(self.r.integers(1, 1000)), **kw)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_retreed_crowd_matches_oracle_per_sample(seed, oracle, emu, built):
+    desc, cam, p = Crowd(5000 + seed).build()
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    img_e, ps_e, steps, info = emu.render_samples(desc, cam, p)
+    compare(ps_o, ps_e, img_o, img_e)
+    # the same scene on the reference's own tree: same samples, more steps
+    desc.contents.flags = 0
+    img_r, ps_r, steps_r, info_r = emu.render_samples(desc, cam, p)
+    compare(ps_o, ps_r, img_o, img_r)
+    assert info_r[0] != info[0] or steps_r == steps     # a different item array unless nothing qualified
+
+
+def test_retree_cuts_the_box_tests_of_the_headline_scene(emu, built):
+    from vecchio_amd import HostScene
+    hs = HostScene("random_spheres_iow", 1)
+    cam = hs.next_camera()
+    p = hs.params(64, 2, 50)
+    _, ps_r, steps_r, info_r = emu.render_samples(hs.desc, cam, p)          # flags = 0: the tree handed over
+    hs.desc.contents.flags = ffi.VK_SCENE_FAST_ACCEL
+    _, ps, steps, info = emu.render_samples(hs.desc, cam, p)
+    assert np.array_equal(ps.view(np.uint32), ps_r.view(np.uint32))      # bit-identical samples
+    assert info_r[0] == 511 and steps < 0.7 * steps_r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_retreed_crowd_on_the_gpu(seed, device, oracle):
+    import ctypes as C
+    from test_gpu_parity import compare_samples, device_samples
+    from vecchio_amd import DeviceScene
+    desc, cam, p = Crowd(5100 + seed).build()
+    ds = DeviceScene(desc)
+    img_d, ps_d = device_samples(ds, cam, p)
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    compare_samples(ps_o, ps_d, img_o, img_d)
+    ds.close()

@@ -74,12 +74,14 @@ struct EnvSwitches {
     bool tile_order = true;            // VK_TILE_ORDER=0: raster order, no probe launch
     int probe_spp = 0;                 // VK_PROBE_SPP=n
     int prim_weight = 0;               // VK_PRIM_WEIGHT=n
+    int retree = -1;                   // VK_RETREE=0/1: force the SAH rebuild of draw-free subtrees off / on (default: vk_scene_desc.flags)
     static int int_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
     static EnvSwitches read() {
         EnvSwitches v;
         if (const char *e = getenv("VK_FORCE_FULL_VARIANT")) v.force_full_variant = e[0] == '1';
         if (const char *e = getenv("VK_NO_LDS_SCENE")) v.no_lds_scene = e[0] == '1';
         if (const char *e = getenv("VK_TILE_ORDER")) v.tile_order = e[0] != '0';
+        if (const char *e = getenv("VK_RETREE")) v.retree = e[0] != '0' ? 1 : 0;
         v.max_waves_per_cu = int_env("VK_MAX_WAVES_PER_CU");
         v.chunk_cap = int_env("VK_CHUNK_CAP");
         v.shade_defer = int_env("VK_SHADE_DEFER");
@@ -397,8 +399,8 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     HIP_TRY(hipMemsetAsync(s->counter, 0, sizeof(uint32_t), st));
     if (s->want_phase_stats) {
         const uint32_t FULLPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
-        if ((F != 0u && F != FULLPDF) || (!lds && F != 0u))
-            return fail(VK_ERR_UNSUPPORTED, "phase statistics are only built for the sphere-only variants and the LDS-resident full/PDF variant");
+        if (F != 0u && F != FULLPDF)
+            return fail(VK_ERR_UNSUPPORTED, "phase statistics are only built for the sphere-only/scatter and the full/PDF variants");
         if (!s->phase_stats) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->phase_stats), 16 * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(s->phase_stats, 0, 16 * sizeof(unsigned long long), st));
         A.phase_stats = s->phase_stats;
@@ -408,7 +410,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
             return VK_OK;
         };
         if (F == 0u) rc = lds ? go(&render_kernel<0u, true, 6, true>) : go(&render_kernel<0u, false, 6, true>);
-        else rc = go(&render_kernel<FULLPDF, true, 4, true>);
+        else rc = lds ? go(&render_kernel<FULLPDF, true, 4, true>) : go(&render_kernel<FULLPDF, false, 4, true>);
         if (rc != VK_OK) return rc;
         HIP_TRY(hipGetLastError());
         F = 0xFFFFFFFFu;   // launched
@@ -552,7 +554,9 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
     UP(lists, lists); UP(list_refs, list_refs); UP(media, media); UP(instances, instances);
     UP(materials, materials); UP(textures, textures); UP(images, images); UP(image_bytes, image_bytes);
     UP(perlins, perlins); UP(lights, lights);
+    if (!H.tie_rank.empty()) UP(tie_rank, tie_rank);
 #undef UP
+    D.tie_base_rect = H.tie_base_rect; D.tie_base_box = H.tie_base_box; D.tie_base_list = H.tie_base_list;
     D.n_items = (uint32_t)H.items.size(); D.n_world_items = H.world_items; D.n_spheres = (uint32_t)H.spheres.size();
     D.n_lights = (uint32_t)H.lights.size(); D.features = H.features; D.n_boxes = (uint32_t)H.boxes.size();
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->counter), 256));
@@ -573,7 +577,9 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
 int linearize_desc(const vk_scene_desc *desc, std::shared_ptr<const LinearScene> &out) {
     auto h = std::make_shared<LinearScene>();
     std::string err;
-    int rc = linearize(desc, *h, err);
+    LinearizeOptions opt;
+    opt.retree = EnvSwitches::read().retree;
+    int rc = linearize(desc, *h, err, opt);
     if (rc != VK_OK) return fail(rc, err);
     out = h;
     return VK_OK;

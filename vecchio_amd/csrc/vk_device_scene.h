@@ -104,6 +104,11 @@ struct DScene {
     const DPerlin *perlins;
     const uint32_t *lights; uint32_t n_lights;
     uint32_t features;
+    // Tie table: null unless the lineariser rebuilt a draw-free subtree (vk_linearize.cpp).  Inside such a block objects are
+    // visited in another order than the reference's, which is unobservable except when two of them are hit at EXACTLY the same
+    // t; then the reference's choice is reproduced from their positions in ITS visiting order: entry = block << 20 | position,
+    // indexed by object id = sphere index | tie_base_rect + rect | tie_base_box + box | tie_base_list + list.
+    const uint32_t *tie_rank; uint32_t tie_base_rect, tie_base_box, tie_base_list;
 };
 
 }  // namespace vkd

@@ -1,6 +1,7 @@
 // vk_linearize.cpp — see vk_linearize.h
 #include "vk_linearize.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <deque>
@@ -22,6 +23,8 @@ DScene LinearScene::host_view() const {
     s.perlins = perlins.data();
     s.lights = lights.data(); s.n_lights = (uint32_t)lights.size();
     s.features = features;
+    s.tie_rank = tie_rank.empty() ? nullptr : tie_rank.data();
+    s.tie_base_rect = tie_base_rect; s.tie_base_box = tie_base_box; s.tie_base_list = tie_base_list;
     return s;
 }
 
@@ -226,6 +229,259 @@ struct Builder {
 
     static bool draw_free(uint32_t dref) { uint32_t k = VKD_KIND(dref); return k == DK_SPHERE || k == DK_MOVING || k == DK_RECT || k == DK_LIST || k == DK_BOX; }
 
+    // ------------------------------------------------------------------ re-treeing of draw-free subtrees
+    // BVHNode::hit (accel.rs:58-83) returns the closest hit of its subtree, and for a subtree whose objects are all
+    // Sphere / Rect / Boxy / lists of those (no ConstantMedium: nothing draws during traversal; no Translate/Rotate) that
+    // result does not depend on the tree over them — only on the objects, the (tmin, tmax) it was called with and, when two
+    // objects are hit at EXACTLY the same t, on which one the reference reaches last (tie rules, see tie_rank below).
+    // BVHNode::new's trees (random axis, median split, accel.rs:98-136) cost ~2x the box tests of a surface-area-heuristic
+    // tree over the same objects, so such subtrees are rebuilt here with a binned SAH builder and emitted in the same
+    // threaded pre-order format; the kernel, the item records and the visit order OUTSIDE the subtree are unchanged.
+    bool retree = true;                     // LinearizeOptions::retree
+    static constexpr uint32_t RETREE_MIN = 16;     // objects: below this the reference's tree is kept as it is
+    std::vector<int32_t> simple_count;      // per vk_bvh_node: number of object slots if the subtree is draw-free, -1 if not, -2 unknown
+    uint32_t n_blocks = 0;
+
+    static bool retree_kind(uint32_t k) { return k == VK_KIND_SPHERE || k == VK_KIND_RECT || k == VK_KIND_LIST; }
+
+    // simple_count for every node of the BVH rooted at `root` (iterative post-order; a cyclic graph is caught by emit_bvh's guard)
+    bool classify(uint32_t root) {
+        if (simple_count.empty()) simple_count.assign(d->n_bvh, -2);
+        struct Fr { uint32_t node; int stage; };
+        std::vector<Fr> st;
+        st.push_back(Fr{root, 0});
+        size_t guard = 0;
+        while (!st.empty()) {
+            if (++guard > (size_t)8 * (d->n_bvh + 16) + 1024) return fail(VK_ERR_BAD_ARG, "BVH graph is cyclic");
+            Fr fr = st.back();
+            const vk_bvh_node &n = d->bvh[fr.node];
+            if (fr.stage == 0) {
+                if (!check_ref(n.left) || !check_ref(n.right)) return false;
+                st.back().stage = 1;
+                for (vk_ref c : {n.left, n.right})
+                    if (VK_REF_KIND(c) == VK_KIND_BVH && simple_count[VK_REF_INDEX(c)] == -2) st.push_back(Fr{VK_REF_INDEX(c), 0});
+                continue;
+            }
+            int64_t total = 0;
+            for (vk_ref c : {n.left, n.right}) {
+                uint32_t k = VK_REF_KIND(c);
+                int32_t v = k == VK_KIND_BVH ? simple_count[VK_REF_INDEX(c)] : (retree_kind(k) ? 1 : -1);
+                if (v < 0 || total < 0) total = -1; else total += v;
+            }
+            simple_count[fr.node] = total > 0x3FFFFFFF ? -1 : (int32_t)total;
+            st.pop_back();
+        }
+        return true;
+    }
+
+    struct RtObj { float mn[3], mx[3], c[3]; uint32_t dref; };
+    static float rt_half_area(const float *mn, const float *mx) {
+        float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    static void rt_grow(float *mn, float *mx, const float *omn, const float *omx) {
+        for (int a = 0; a < 3; a++) { mn[a] = fminf(mn[a], omn[a]); mx[a] = fmaxf(mx[a], omx[a]); }
+    }
+    // bounding_box() of a simple object, as the reference computes it (hittable.rs:97-102 Sphere, 258-269 Rect,
+    // 355-357 Boxy = its corners, 396-418 Vec = surrounding boxes)
+    bool rt_bounds(vk_ref r, float *mn, float *mx) {
+        uint32_t k = VK_REF_KIND(r), i = VK_REF_INDEX(r);
+        if (k == VK_KIND_SPHERE) {
+            const vk_sphere &sp = d->spheres[i];
+            float rad = fabsf(sp.radius);
+            for (int a = 0; a < 3; a++) { mn[a] = sp.center[a] - rad; mx[a] = sp.center[a] + rad; }
+            return true;
+        }
+        if (k == VK_KIND_RECT) {
+            const vk_rect &q = d->rects[i];
+            if (q.axis0 > 2 || q.axis1 > 2 || q.axis2 > 2) return fail(VK_ERR_BAD_ARG, "rect axis out of range");
+            mn[q.axis0] = q.c0; mx[q.axis0] = q.c1; mn[q.axis1] = q.d0; mx[q.axis1] = q.d1;
+            mn[q.axis2] = q.k - 0.0001f; mx[q.axis2] = q.k + 0.0001f;
+            return true;
+        }
+        const vk_list &l = d->lists[i];
+        if (l.count == 0 || (uint64_t)l.first + l.count > d->n_list_items) return false;
+        for (uint32_t j = 0; j < l.count; j++) {
+            vk_ref it = d->list_items[l.first + j];
+            if (!check_ref(it)) return false;
+            uint32_t ik = VK_REF_KIND(it);
+            if (ik != VK_KIND_SPHERE && ik != VK_KIND_RECT) return false;
+            float a[3], b[3];
+            if (!rt_bounds(it, a, b)) return false;
+            if (j == 0) { memcpy(mn, a, 12); memcpy(mx, b, 12); } else rt_grow(mn, mx, a, b);
+        }
+        return true;
+    }
+
+    // objects of the subtree in the REFERENCE's visiting order (pre-order, left first)
+    bool rt_collect(uint32_t root, uint32_t flip0, int32_t inst, std::vector<RtObj> &out, bool &ok) {
+        struct Fr { vk_ref ref; uint32_t flip; };
+        std::vector<Fr> st;
+        st.push_back(Fr{VK_MAKE_REF(VK_KIND_BVH, root), flip0});
+        ok = true;
+        while (!st.empty()) {
+            Fr fr = st.back(); st.pop_back();
+            if (VK_REF_KIND(fr.ref) == VK_KIND_BVH) {
+                const vk_bvh_node &n = d->bvh[VK_REF_INDEX(fr.ref)];
+                bool dup = n.left == n.right && VK_REF_KIND(n.left) != VK_KIND_BVH;   // len == 1: the same object twice, the second test is a no-op
+                if (!dup) st.push_back(Fr{n.right, fr.flip ^ ((VK_REF_KIND(n.right) == VK_KIND_BVH && (n.right & VK_REF_FLIP)) ? DREF_FLIP : 0u)});
+                st.push_back(Fr{n.left, fr.flip ^ ((VK_REF_KIND(n.left) == VK_KIND_BVH && (n.left & VK_REF_FLIP)) ? DREF_FLIP : 0u)});
+                continue;
+            }
+            RtObj o;
+            if (!rt_bounds(fr.ref, o.mn, o.mx)) { ok = false; return status == VK_OK; }
+            for (int a = 0; a < 3; a++) {
+                if (!(o.mn[a] <= o.mx[a]) || !std::isfinite(o.mn[a]) || !std::isfinite(o.mx[a])) { ok = false; return true; }   // NaN / inverted box: keep the reference's tree
+                o.c[a] = 0.5f * o.mn[a] + 0.5f * o.mx[a];
+            }
+            if (!convert_object(fr.ref, fr.flip, inst, o.dref)) return false;
+            out.push_back(o);
+        }
+        return true;
+    }
+
+    // binned surface-area-heuristic build over objs[begin, end), emitted in threaded pre-order; leaves hold two objects
+    void rt_emit(std::vector<RtObj> &objs, size_t begin, size_t end, int depth) {
+        struct Job { size_t begin, end; int depth; uint32_t parent_item; };      // parent_item: INNER item whose skip link ends here
+        // explicit stack: emit node, then left, then right; skip links are patched when a subtree is complete
+        struct Fr { size_t begin, end; int depth; uint32_t item; int stage; size_t mid; };
+        std::vector<Fr> st;
+        st.push_back(Fr{begin, end, depth, 0, 0, 0});
+        while (!st.empty()) {
+            Fr &fr = st.back();
+            size_t len = fr.end - fr.begin;
+            if (fr.stage == 0) {
+                DItem it; memset(&it, 0, sizeof(it));
+                float mn[3], mx[3];
+                memcpy(mn, objs[fr.begin].mn, 12); memcpy(mx, objs[fr.begin].mx, 12);
+                for (size_t i = fr.begin + 1; i < fr.end; i++) rt_grow(mn, mx, objs[i].mn, objs[i].mx);
+                it.mnx = mn[0]; it.mny = mn[1]; it.mnz = mn[2]; it.mxx = mx[0]; it.mxy = mx[1]; it.mxz = mx[2];
+                if (len <= 2) {
+                    size_t a = fr.begin, b = fr.begin + 1;
+                    // the larger object first: its hit's t culls more of what follows in this fixed-order walk
+                    if (len == 2 && rt_half_area(objs[b].mn, objs[b].mx) > rt_half_area(objs[a].mn, objs[a].mx)) std::swap(a, b);
+                    it.w0 = objs[a].dref; it.w1 = len == 2 ? objs[b].dref : 0u;
+                    L.items.push_back(it);
+                    L.n_prims += (uint32_t)len;
+                    st.pop_back();
+                    continue;
+                }
+                fr.item = (uint32_t)L.items.size();
+                L.items.push_back(it);
+                // ---- choose the split: 16 centroid bins per axis, cost = A(left) n(left) + A(right) n(right)
+                float cmin[3], cmax[3];
+                memcpy(cmin, objs[fr.begin].c, 12); memcpy(cmax, objs[fr.begin].c, 12);
+                for (size_t i = fr.begin + 1; i < fr.end; i++) rt_grow(cmin, cmax, objs[i].c, objs[i].c);
+                const int NB = 16;
+                int best_axis = -1, best_split = 0; double best_cost = 1e300;
+                if (fr.depth < 64) {
+                    for (int ax = 0; ax < 3; ax++) {
+                        if (!(cmax[ax] > cmin[ax])) continue;
+                        float scale = (float)NB / (cmax[ax] - cmin[ax]);
+                        float bmn[NB][3], bmx[NB][3]; size_t cnt[NB];
+                        for (int b = 0; b < NB; b++) cnt[b] = 0;
+                        for (size_t i = fr.begin; i < fr.end; i++) {
+                            int b = (int)((objs[i].c[ax] - cmin[ax]) * scale);
+                            b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                            if (cnt[b]++ == 0) { memcpy(bmn[b], objs[i].mn, 12); memcpy(bmx[b], objs[i].mx, 12); } else rt_grow(bmn[b], bmx[b], objs[i].mn, objs[i].mx);
+                        }
+                        double la[NB]; size_t ln[NB];
+                        float amn[3], amx[3]; size_t n = 0;
+                        for (int b = 0; b < NB; b++) {
+                            if (cnt[b]) { if (n == 0) { memcpy(amn, bmn[b], 12); memcpy(amx, bmx[b], 12); } else rt_grow(amn, amx, bmn[b], bmx[b]); n += cnt[b]; }
+                            la[b] = n ? (double)rt_half_area(amn, amx) : 0.0; ln[b] = n;
+                        }
+                        n = 0;
+                        for (int b = NB - 1; b >= 1; b--) {
+                            if (cnt[b]) { if (n == 0) { memcpy(amn, bmn[b], 12); memcpy(amx, bmx[b], 12); } else rt_grow(amn, amx, bmn[b], bmx[b]); n += cnt[b]; }
+                            if (n == 0 || ln[b - 1] == 0) continue;
+                            double cost = la[b - 1] * (double)ln[b - 1] + (double)rt_half_area(amn, amx) * (double)n;
+                            if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = b; }
+                        }
+                    }
+                }
+                size_t mid = fr.begin + len / 2;
+                if (best_axis >= 0) {
+                    float lo = cmin[best_axis], scale = (float)NB / (cmax[best_axis] - cmin[best_axis]);
+                    int ax = best_axis, sp = best_split;
+                    auto itp = std::stable_partition(objs.begin() + fr.begin, objs.begin() + fr.end, [&](const RtObj &q) {
+                        int b = (int)((q.c[ax] - lo) * scale);
+                        b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                        return b < sp;
+                    });
+                    size_t m = (size_t)(itp - objs.begin());
+                    if (m > fr.begin && m < fr.end) mid = m;
+                }
+                // the child with the larger box first (see above): swap the two slices if the right one is larger
+                float lmn[3], lmx[3], rmn[3], rmx[3];
+                memcpy(lmn, objs[fr.begin].mn, 12); memcpy(lmx, objs[fr.begin].mx, 12);
+                for (size_t i = fr.begin + 1; i < mid; i++) rt_grow(lmn, lmx, objs[i].mn, objs[i].mx);
+                memcpy(rmn, objs[mid].mn, 12); memcpy(rmx, objs[mid].mx, 12);
+                for (size_t i = mid + 1; i < fr.end; i++) rt_grow(rmn, rmx, objs[i].mn, objs[i].mx);
+                if (rt_half_area(rmn, rmx) > rt_half_area(lmn, lmx)) {
+                    std::rotate(objs.begin() + fr.begin, objs.begin() + mid, objs.begin() + fr.end);
+                    mid = fr.begin + (fr.end - mid);
+                }
+                fr.mid = mid; fr.stage = 1;
+                Fr child{fr.begin, mid, fr.depth + 1, 0, 0, 0};
+                st.push_back(child);           // (fr is invalid after this)
+                continue;
+            }
+            if (fr.stage == 1) {
+                fr.stage = 2;
+                Fr child{fr.mid, fr.end, fr.depth + 1, 0, 0, 0};
+                st.push_back(child);
+                continue;
+            }
+            L.items[fr.item].w0 = (uint32_t)L.items.size();   // skip link
+            st.pop_back();
+        }
+    }
+
+    // dense object id of a dref for the tie table: [spheres][rects][boxes][lists]
+    uint32_t tie_id(uint32_t dref) const {
+        uint32_t k = VKD_KIND(dref), i = VKD_INDEX(dref);
+        if (k == DK_SPHERE) return i;
+        if (k == DK_RECT) return d->n_spheres + i;
+        if (k == DK_BOX) return d->n_spheres + d->n_rects + i;
+        return d->n_spheres + d->n_rects + d->n_lists + i;     // DK_LIST (boxes and lists are both converted vk_lists: <= n_lists each)
+    }
+
+    // tries to replace the subtree rooted at BVH node `root` by a rebuilt one; `done` says whether it did
+    bool try_retree(uint32_t root, uint32_t flip, int32_t inst, bool &done) {
+        done = false;
+        if (!retree) return true;
+        if (simple_count.empty() || simple_count[root] == -2) { if (!classify(root)) return false; }
+        if (simple_count[root] < (int32_t)RETREE_MIN || n_blocks >= 4095u) return true;
+        const size_t items0 = L.items.size(), boxes0 = L.boxes.size(), lists0 = L.lists.size(), refs0 = L.list_refs.size();
+        const uint32_t prims0 = L.n_prims, feat0 = L.features;
+        std::vector<RtObj> objs;
+        objs.reserve((size_t)simple_count[root]);
+        bool ok = true;
+        if (!rt_collect(root, flip, inst, objs, ok)) return false;
+        if (!ok || objs.size() < RETREE_MIN || objs.size() >= (1u << 20)) {
+            // keep the reference's tree for this subtree: undo what collecting converted (memo entries past the old sizes)
+            L.items.resize(items0); L.boxes.resize(boxes0); L.lists.resize(lists0); L.list_refs.resize(refs0); L.n_prims = prims0; L.features = feat0;
+            for (auto it = box_memo.begin(); it != box_memo.end();) { if (it->second != 0xFFFFFFFFu && it->second >= boxes0) it = box_memo.erase(it); else ++it; }
+            for (auto it = list_memo.begin(); it != list_memo.end();) { if (it->second >= lists0) it = list_memo.erase(it); else ++it; }
+            return true;
+        }
+        // tie ranks: position in the reference's visiting order, tagged with the block (ties are only re-ordered inside a block)
+        n_blocks++;
+        if (L.tie_rank.empty()) L.tie_rank.assign((size_t)d->n_spheres + d->n_rects + 2u * (size_t)d->n_lists, 0u);
+        // An object that occurs more than once in the block (a shared Arc): among exact ties the reference ends up with the LAST
+        // Rect it reaches, else with the FIRST object it reached (see tie_replaces in vk_trace.h), so a Rect is ranked by its last
+        // occurrence and everything else by its first.
+        for (size_t i = 0; i < objs.size(); i++) {
+            uint32_t id = tie_id(objs[i].dref);
+            bool first = (L.tie_rank[id] >> 20) != n_blocks;
+            if (first || VKD_KIND(objs[i].dref) == DK_RECT) L.tie_rank[id] = (n_blocks << 20) | (uint32_t)i;
+        }
+        rt_emit(objs, 0, objs.size(), 0);
+        done = true;
+        return true;
+    }
+
     // pre-order emission of one BVH (accel.rs:58-83 order: box, left, right); iterative to
     // survive 1M-primitive trees and degenerate depth
     bool emit_bvh(uint32_t root, uint32_t flip0, int32_t inst) {
@@ -239,6 +495,12 @@ struct Builder {
             const vk_bvh_node &n = d->bvh[fr.node];
             if (fr.stage == 0) {
                 if (!check_ref(n.left) || !check_ref(n.right)) return false;
+                {
+                    bool done = false;
+                    uint32_t node = fr.node, flip = fr.flip;
+                    if (!try_retree(node, flip, inst, done)) return false;
+                    if (done) { st.pop_back(); continue; }
+                }
                 DItem it; memset(&it, 0, sizeof(it));
                 it.mnx = n.bb_min[0]; it.mny = n.bb_min[1]; it.mnz = n.bb_min[2];
                 it.mxx = n.bb_max[0]; it.mxy = n.bb_max[1]; it.mxz = n.bb_max[2];
@@ -351,6 +613,7 @@ struct Builder {
     bool run() {
         if (!d) return fail(VK_ERR_BAD_ARG, "null scene description");
         if (d->abi_version != VK_ABI_VERSION) return fail(VK_ERR_BAD_ARG, "abi version mismatch");
+        L.tie_base_rect = d->n_spheres; L.tie_base_box = d->n_spheres + d->n_rects; L.tie_base_list = d->n_spheres + d->n_rects + d->n_lists;
         if (!materials_and_textures()) return false;
         for (uint32_t i = 0; i < d->n_spheres; i++) {
             const vk_sphere &s = d->spheres[i];
@@ -411,8 +674,9 @@ struct Builder {
 
 }  // namespace
 
-int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err) {
+int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, const LinearizeOptions &opt) {
     Builder b(desc, out, err);
+    b.retree = opt.retree >= 0 ? opt.retree != 0 : (desc && (desc->flags & VK_SCENE_FAST_ACCEL) != 0);
     if (!b.run()) return b.status == VK_OK ? VK_ERR_BAD_ARG : b.status;
     out.world_items = b.world_items;
     return VK_OK;

@@ -29,6 +29,10 @@ struct LinearScene {
     std::vector<uint8_t> image_bytes;
     std::vector<DPerlin> perlins;
     std::vector<uint32_t> lights;
+    // tie table (empty when no subtree was rebuilt): per object id ([spheres][rects][boxes][lists]) its block (bits 31..20, 0 = not
+    // in a rebuilt subtree) and its position in the reference's visiting order inside the block (bits 19..0)
+    std::vector<uint32_t> tie_rank;
+    uint32_t tie_base_rect = 0, tie_base_box = 0, tie_base_list = 0;
     uint32_t features = 0;
     uint32_t n_prims = 0;
     uint32_t world_items = 0;   // items[0, world_items) is the world BVH; instance child ranges follow
@@ -36,8 +40,14 @@ struct LinearScene {
     DScene host_view() const;   // DScene whose pointers address these vectors
 };
 
+struct LinearizeOptions {
+    // rebuild draw-free subtrees with the SAH builder (vk_linearize.cpp): -1 = as vk_scene_desc.flags & VK_SCENE_FAST_ACCEL says
+    // (default off: the reference's tree everywhere), 0 / 1 = force (diagnostic switch VK_RETREE)
+    int retree = -1;
+};
+
 // returns VK_OK or an error code with `err` set
-int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err);
+int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, const LinearizeOptions &opt = LinearizeOptions());
 
 }  // namespace vkd
 #endif

@@ -78,6 +78,9 @@ struct Lane {
     uint32_t pixel, sample;
 };
 
+// the next f32 above a positive finite t (+inf stays +inf)
+VK_HD float nextafter_up(float t) { return (t > 0.0f && t < INFINITY) ? vk::bits_f32(vk::f32_bits(t) + 1u) : t; }
+
 VK_HD void set_space(Lane &L, V3 o, V3 d) {
     L.o = o; L.d = d;
     L.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -144,6 +147,23 @@ VK_HD bool sphere_t(float cx, float cy, float cz, float r, V3 o, V3 d, float a, 
         if (tmin < t1 && t1 < tmax) { t = t1; return true; }
         float t2 = (-half_b + root) / a;
         if (tmin < t2 && t2 < tmax) { t = t2; return true; }
+    }
+    return false;
+}
+// the same with t == tmax reported too (`tie`): the root Sphere::hit would have taken had its bound been inclusive.  The near
+// root is taken when it is in (tmin, tmax]; a near root at tmax leaves no far root below tmax, so the choice is the reference's.
+VK_HD bool sphere_t_tie(float cx, float cy, float cz, float r, V3 o, V3 d, float a, float tmin, float tmax, float &t, bool &tie) {
+    V3 oc = o - v3(cx, cy, cz);
+    float half_b = dot(oc, d);
+    float c = length2(oc) - r * r;
+    float disc = half_b * half_b - a * c;
+    tie = false;
+    if (disc > 0.0f) {
+        float root = sqrtf(disc);
+        float t1 = (-half_b - root) / a;
+        if (tmin < t1 && t1 <= tmax) { t = t1; tie = t1 == tmax; return true; }
+        float t2 = (-half_b + root) / a;
+        if (tmin < t2 && t2 <= tmax) { t = t2; tie = t2 == tmax; return true; }
     }
     return false;
 }
@@ -270,6 +290,27 @@ VK_HD void accept(Lane &L, float t, uint32_t prim, float aux) {
     L.T = t; L.best_prim = prim; L.best_inst = L.cur_inst; L.best_aux = aux;
 }
 
+// ---- exact ties.  In the reference an object hit at EXACTLY the closest-so-far t replaces it only when its own test
+// accepts t == tmax: Rect::hit does (hittable.rs:232: `t > tmax` rejects), Sphere::hit (hittable.rs:75: `t < tmax`) and the
+// list scan (hittable.rs:386: `rec.t < closest`) do not; BVHNode::hit then keeps the later one (accel.rs:73-77).  Outside a
+// rebuilt block the walk IS the reference's order, so the tests below with want_tie = false are the reference's.  Inside a
+// rebuilt block (vk_linearize.cpp) the same outcome is computed from the two objects' positions in the reference's order.
+VK_HD uint32_t tie_entry(const DScene &S, uint32_t ref) {
+    uint32_t k = VKD_KIND(ref), i = VKD_INDEX(ref);
+    uint32_t id = k == DK_SPHERE ? i : (k == DK_RECT ? S.tie_base_rect + i : (k == DK_BOX ? S.tie_base_box + i : S.tie_base_list + i));
+    return (k == DK_SPHERE || k == DK_RECT || k == DK_BOX || k == DK_LIST) ? S.tie_rank[id] : 0u;
+}
+// x was just hit at exactly L.T, the t of the current best w: does x replace it?
+VK_HD bool tie_replaces(const Lane &L, const DScene &S, uint32_t x) {
+    bool x_inclusive = VKD_KIND(x) == DK_RECT;
+    if (!S.tie_rank || L.best_prim == 0u || L.best_inst != L.cur_inst) return x_inclusive;      // x is visited after w, as in the reference
+    uint32_t ex = tie_entry(S, x), ew = tie_entry(S, L.best_prim);
+    if ((ex >> 20) == 0u || (ex >> 20) != (ew >> 20)) return x_inclusive;                      // not both in one rebuilt block: ditto
+    if (ex == ew) return false;                                                                // the same object again
+    if (ex > ew) return x_inclusive;                                                           // the reference reaches x after w
+    return VKD_KIND(L.best_prim) != DK_RECT;                                                   // ... w after x: w replaced x only if Rect
+}
+
 // ConstantMedium::hit, hittable.rs:453-493 (draws ONE number inside traversal)
 template <uint32_t F, class Mem>
 VK_HD void medium_test(Lane &L, const DScene &S, const Mem &M, uint32_t ref) {
@@ -349,22 +390,34 @@ VK_HD void process_ref(Lane &L, const DScene &S, const Mem &M, uint32_t ref) {
         float cx, cy, cz, r;
         if (is_sphere) { DSphere s = M.sphere(idx); cx = s.cx; cy = s.cy; cz = s.cz; r = s.r; }
         else { const DMoving &m = S.moving[idx]; V3 c = moving_center(m, L.time); cx = c.x; cy = c.y; cz = c.z; r = m.r; }
-        if (sphere_t(cx, cy, cz, r, L.o, L.d, L.a, T_MIN, L.T, t)) accept<F, Mem>(L, t, ref, 0.0f);
+        bool tie;
+        if (sphere_t_tie(cx, cy, cz, r, L.o, L.d, L.a, T_MIN, L.T, t, tie)) {
+            if (!tie || tie_replaces(L, S, ref)) accept<F, Mem>(L, t, ref, 0.0f);     // tie: rare, see tie_replaces
+        }
         return;
     }
     if ((F & VKF_RECT) && k == DK_RECT) {
-        if (rect_t(S.rects[idx], L.o, L.d, T_MIN, L.T, t)) accept<F, Mem>(L, t, ref, 0.0f);
+        if (rect_t(S.rects[idx], L.o, L.d, T_MIN, L.T, t)) {                          // inclusive bounds: t == L.T comes through
+            if (t != L.T || tie_replaces(L, S, ref)) accept<F, Mem>(L, t, ref, 0.0f);
+        }
         return;
     }
     if ((F & VKF_BOX) && k == DK_BOX) {
         uint32_t face = 0;
         DBox B = M.box(idx);
-        if (box_t(B, L.o, L.d, T_MIN, L.T, t, face)) accept<F, Mem>(L, t, ref, vk::bits_f32(face));
+        // the list scan is strict against the tmax it was given; nextafter(T) as tmax lets a hit AT T through for the tie rule
+        float tmax = S.tie_rank ? nextafter_up(L.T) : L.T;
+        if (box_t(B, L.o, L.d, T_MIN, tmax, t, face)) {
+            if (t < L.T || (t == L.T && tie_replaces(L, S, ref))) accept<F, Mem>(L, t, ref, vk::bits_f32(face));
+        }
         return;
     }
     if ((F & VKF_LIST) && k == DK_LIST) {
         uint32_t item;
-        if (list_t(S, M, ref, L.o, L.d, L.a, L.time, T_MIN, L.T, t, item)) accept<F, Mem>(L, t, item ^ (ref & DREF_FLIP), 0.0f);
+        float tmax = S.tie_rank ? nextafter_up(L.T) : L.T;
+        if (list_t(S, M, ref, L.o, L.d, L.a, L.time, T_MIN, tmax, t, item)) {
+            if (t < L.T || (t == L.T && tie_replaces(L, S, ref))) accept<F, Mem>(L, t, item ^ (ref & DREF_FLIP), 0.0f);
+        }
         return;
     }
     if ((F & VKF_MEDIUM) && k == DK_MEDIUM) { medium_test<F, Mem>(L, S, M, ref); return; }

@@ -24,6 +24,7 @@ VK_TEX_SOLID, VK_TEX_CHECKER, VK_TEX_IMAGE, VK_TEX_NOISE = range(4)
 VK_INTEGRATOR_PDF, VK_INTEGRATOR_SCATTER = 0, 1
 VK_BACKGROUND_SOLID, VK_BACKGROUND_SKY = 0, 1
 VK_OUTPUT_F32, VK_OUTPUT_RGB8 = 0, 1
+VK_SCENE_FAST_ACCEL = 1
 
 
 def make_ref(kind, index, flip=False):
@@ -103,6 +104,7 @@ class SceneDesc(C.Structure):
         ("n_perlins", C.c_uint32), ("perlins", C.POINTER(Perlin)),
         ("world", C.c_uint32),
         ("n_lights", C.c_uint32), ("lights", C.POINTER(C.c_uint32)),
+        ("flags", C.c_uint32),
     ]
 
 

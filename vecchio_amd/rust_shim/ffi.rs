@@ -54,6 +54,7 @@ pub struct vk_scene_desc {
     pub n_perlins: u32, pub perlins: *const vk_perlin,
     pub world: vk_ref,
     pub n_lights: u32, pub lights: *const vk_ref,
+    pub flags: u32,             // VK_SCENE_FAST_ACCEL = 1: let the library rebuild draw-free subtrees (see vecchio_amd.h); 0 = exact tree
 }
 
 #[repr(C)] #[derive(Copy, Clone)]
@@ -114,7 +115,7 @@ impl FlatBuilder {
             n_textures: self.textures.len() as u32, textures: self.textures.as_ptr(),
             n_images: self.images.len() as u32, images: self.images.as_ptr(),
             n_perlins: self.perlins.len() as u32, perlins: self.perlins.as_ptr(),
-            world: self.world, n_lights: self.lights.len() as u32, lights: self.lights.as_ptr(),
+            world: self.world, n_lights: self.lights.len() as u32, lights: self.lights.as_ptr(), flags: 0,
         }
     }
 }
