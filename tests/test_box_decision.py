@@ -31,9 +31,11 @@ def test_fast_path_equals_reference_divisions(emu):
     rng = np.random.default_rng(7)
     n = 1_500_000
     total_fb = 0
-    for scale in (1.0, 500.0):
-        boxes = make_boxes(rng, n, scale)
-        o = rng.uniform(-scale, scale, (n, 3)).astype(np.float32)
+    for scale, offset in ((1.0, 0.0), (500.0, 0.0), (1.0, 3.0e4)):
+        # offset: the whole configuration far from the world origin — o/d is huge next to the t of the box, the worst case for
+        # the fused form b*inv - o*inv (cancellation); its margin grows with |o/d| and the exact fallback takes over
+        boxes = make_boxes(rng, n, scale) + np.float32(offset)
+        o = rng.uniform(-scale, scale, (n, 3)).astype(np.float32) + np.float32(offset)
         # a third of the rays aim exactly at a point ON the box (corner, edge, face or interior point): grazing cases
         t = rng.uniform(0, 1, (n, 3)).astype(np.float32) * rng.choice([0.0, 1.0, 0.5], (n, 3)).astype(np.float32)
         target = boxes[:, 0::2] + t * (boxes[:, 1::2] - boxes[:, 0::2])
@@ -58,7 +60,7 @@ def test_fast_path_equals_reference_divisions(emu):
         assert not bad.any(), f"{int(bad.sum())} of {n} decisions differ, first: box {boxes[bad][0]} ray {rays[bad][0]}"
         total_fb += int(((dec >> 2) & 1).sum())
         assert ((dec & 1) == 1).mean() > 0.05 and ((dec & 1) == 0).mean() > 0.05      # both outcomes well covered
-    assert 0 < total_fb < 0.2 * 2 * n          # the fallback is exercised, and is the exception
+    assert 0 < total_fb < 0.2 * 3 * n          # the fallback is exercised, and is the exception
 
 
 def test_always_hit_leaf_boxes(emu):
