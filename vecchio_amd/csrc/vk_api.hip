@@ -167,7 +167,7 @@ uint32_t pick_variant(const vk_scene *s) {
 }
 
 size_t per_wave_lds_bytes(uint32_t F) {   // cold lane state of one wave + its tile's fixed-point sums (64 x 3 x 8 B) + its unit state
-    return (size_t)64 * ((F & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE) * sizeof(float) + 64 * 3 * sizeof(unsigned long long) + WAVE_STATE_WORDS * sizeof(uint32_t);
+    return ((F & VKF_INSTANCE) ? wave_block_floats<VKF_INSTANCE>() : wave_block_floats<0u>()) * sizeof(float);
 }
 
 // LDS residency plan.  `hot` = bytes of items + spheres + boxes.  Measured on MI355X with the VALU-bound

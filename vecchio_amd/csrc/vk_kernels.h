@@ -123,8 +123,12 @@ enum : int { CF_THR = 0, CF_DEPTH = 3, CF_KEY = 4, CF_CTR = 6, CF_XY = 7, CF_SAM
 constexpr int NCOLD_BASE = 9;
 constexpr int NCOLD_INST = 15;
 template <uint32_t F> constexpr int ncold() { return (F & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE; }
-constexpr int WAVE_STATE_WORDS = 4;   // per-wave, wave-uniform: the unit whose samples are being handed out (see render_kernel)
-enum : int { WS_TXY = 0, WS_S0 = 1, WS_TOTAL = 2, WS_NEXT = 3 };   // one 16-byte record: tile origin (x | y << 16), first sample, items, items handed out
+constexpr int WAVE_STATE_WORDS = 8;   // per-wave, wave-uniform: the unit whose samples are being handed out (see render_kernel)
+enum : int { WS_TXY = 0, WS_S0 = 1, WS_TOTAL = 2, WS_NEXT = 3,   // one 16-byte record: tile origin (x | y << 16), first sample, items, items handed out
+              WS_KARGS = 4 };                                      // + the kernel-argument segment's address (2 words), for code that is called (shade_refill_call)
+
+// per-wave LDS block, contiguous: [cold lane state][tile sums: 64 x 3 x u64][wave state]
+template <uint32_t F> constexpr uint32_t wave_block_floats() { return 64u * (uint32_t)ncold<F>() + 64u * 3u * 2u + (uint32_t)WAVE_STATE_WORDS; }
 
 // Pixel sums are ORDER-INDEPENDENT: every finished sample is added to its pixel's three 64-bit fixed-point accumulators
 // (2^-26 units: 1.5e-8 absolute per sample, sums up to 1.4e11) with integer atomics, so the image does not depend on which
@@ -182,6 +186,148 @@ __device__ __forceinline__ void flush_tile_sums(unsigned long long *tile_sum, lo
 // number of lanes of the wave for which p holds (v_cmp -> s_bcnt1, no VGPR round trip)
 __device__ __forceinline__ uint32_t lanes_with(bool p) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
 
+// ---- the SHADE + REFILL phase body: shade the lanes whose segment is fully traversed, deposit finished samples, hand new
+// samples to the lanes without a path.  Leaves `fresh` lanes with a new ray parked in L.wo / L.wd / L.time, which the caller
+// installs with ONE begin_segment (its three exact reciprocals are ~60 instructions per call site).  Used inline by the lean variants and through shade_refill_call (below) by the everything-variants.
+struct PhaseClocks { unsigned long long mat = 0, refill = 0, t1 = 0; };
+template <uint32_t F, bool LDS_SCENE, bool STATS, bool COST>
+__device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &active, bool &need, bool &fresh, bool &touched, uint32_t &cost_t0,
+                                                  KArgsC P, float *cold, unsigned long long *tile_sum, uint32_t *wstate, uint32_t lane, uint32_t lds_items, PhaseClocks &clk) {
+    using Mem = typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type;
+    RenderConsts C = KARG(P, C);
+    DScene S = KARG(P, S);
+    Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
+    unsigned long long &st_t_mat = clk.mat, &st_t_refill = clk.refill, &st_t1 = clk.t1;
+    (void)st_t_mat; (void)st_t_refill; (void)st_t1; (void)cost_t0;
+    touched = is_shade;           // lanes whose path state is in registers during this phase
+    fresh = false;                // lanes that leave this phase with a new ray to install; it is parked in the
+                                  // (dead) world-ray fields L.wo / L.wd / L.time, so it costs no registers
+    if (is_shade) {
+        cold_load_path<F>(cold, lane, L);
+        if (STATS) st_t1 = clock64();
+        V3 no, nd; float nt;
+        bool cont = shade_core<F, Mem>(L, S, M, C, no, nd, nt);
+        if (cont) { L.wo = no; L.wd = nd; L.time = nt; fresh = true; }
+        if (STATS) st_t_mat += clock64() - st_t1;
+        if (!cont) {
+            uint32_t xy = __float_as_uint(cold[CF_XY * 64 + lane]);
+            size_t pix = (size_t)(xy >> 16) * C.width + (xy & 0xFFFFu);
+            float4 *dbg = KARG(P, debug);
+            if (dbg) dbg[pix * C.spp + __float_as_uint(cold[CF_SAMPLE * 64 + lane])] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(L.rng.ctr));
+            long long *acc = KARG(P, accum);
+            if (acc && isfinite(L.acc.x) && isfinite(L.acc.y) && isfinite(L.acc.z)) {   // main.rs:192-194; c += color (main.rs:193)
+                unsigned long long fx = (unsigned long long)to_fixed(L.acc.x), fy = (unsigned long long)to_fixed(L.acc.y), fz = (unsigned long long)to_fixed(L.acc.z);
+                // a sample of the tile the wave is handing out (nearly all of them) lands in the wave's LDS sums, which
+                // reach the frame's accumulators once per unit; a straggler of an earlier unit goes there directly
+                if ((xy & 0xFFF8FFF8u) == __builtin_amdgcn_readfirstlane(wstate[WS_TXY])) {
+                    unsigned long long *t = tile_sum + ((xy & 7u) | ((xy >> 13) & 0x38u)) * 3u;
+                    atomicAdd(t + 0, fx); atomicAdd(t + 1, fy); atomicAdd(t + 2, fz);
+                } else {
+                    unsigned long long *a = reinterpret_cast<unsigned long long *>(acc) + pix * 3;
+                    atomicAdd(a + 0, fx); atomicAdd(a + 1, fy); atomicAdd(a + 2, fz);
+                }
+            }
+            if (COST) {   // probe launch: the lane-time this sample took, charged to its tile
+                uint32_t *tc = KARG(P, tile_cost);
+                uint32_t now = (uint32_t)(wall_clock64() >> 4);
+                if (tc) atomicAdd(&tc[((xy >> 16) / TILE) * KARG(P, tiles_x) + (xy & 0xFFFFu) / TILE], now - cost_t0);
+            }
+            active = false;
+            need = true;
+        }
+    }
+    if (STATS) st_t1 = clock64();
+    // ---- hand out samples of the wave's current unit to the lanes without a path; pull the next unit when it is used up
+    for (;;) {
+        unsigned long long need_mask = __builtin_amdgcn_ballot_w64(need);
+        if (!need_mask) break;
+        uint4 ws = *reinterpret_cast<const uint4 *>(wstate);       // one ds_read_b128, the same address in every lane
+        uint32_t txy = __builtin_amdgcn_readfirstlane(ws.x), s0 = __builtin_amdgcn_readfirstlane(ws.y);
+        uint32_t total = __builtin_amdgcn_readfirstlane(ws.z), next = __builtin_amdgcn_readfirstlane(ws.w);
+        if (next >= total) {
+            uint32_t unit = 0;
+            if (lane == 0) unit = atomicAdd(KARG(P, counter), 1u);
+            unit = __builtin_amdgcn_readfirstlane(unit);
+            const uint32_t n_chunks = KARG(P, n_chunks);
+            if (unit >= KARG(P, n_local_tiles) * n_chunks) {                      // the launch's units are all handed out:
+                need = false;                                                     // these lanes idle until the wave's last path ends
+                break;
+            }
+            flush_tile_sums(tile_sum, KARG(P, accum), txy, lane, C.width, C.height);  // the finished unit's sums so far
+            const uint32_t chunk = unit % n_chunks;
+            // tiles are visited dearest-first when the probe launch left an order (see enqueue_render)
+            uint32_t tslot = unit / n_chunks;
+            { const uint32_t *ord = KARG(P, tile_order); if (ord) tslot = ord[tslot]; }
+            const uint32_t tile = KARG(P, tile_rank) + tslot * KARG(P, tile_world);
+            const uint32_t tiles_x = KARG(P, tiles_x);
+            s0 = (uint32_t)(((uint64_t)C.spp * chunk) / n_chunks);
+            const uint32_t s1 = (uint32_t)(((uint64_t)C.spp * (chunk + 1)) / n_chunks);
+            txy = ((tile % tiles_x) * TILE) | (((tile / tiles_x) * TILE) << 16);
+            next = 0u; total = 64u * (s1 - s0);
+            if (lane == 0) { wstate[WS_TXY] = txy; wstate[WS_S0] = s0; wstate[WS_TOTAL] = total; }
+        }
+        uint32_t k = next + (uint32_t)__popcll(need_mask & ((1ull << lane) - 1ull));
+        if (need && k < total) {
+            uint32_t q = k & 63u, smp = s0 + (k >> 6);
+            uint32_t px = (txy & 0xFFFFu) + (q & 7u), py = (txy >> 16) + (q >> 3);
+            if (px < C.width && py < C.height) {   // slots outside the image (edge tiles) are skipped: the lane asks again
+                cold[CF_XY * 64 + lane] = __uint_as_float(px | (py << 16));
+                cold[CF_SAMPLE * 64 + lane] = __uint_as_float(smp);
+                if (COST) cost_t0 = (uint32_t)(wall_clock64() >> 4);
+                V3 no, nd; float nt;               // the lane's next sample (main.rs:186-190)
+                start_sample_core(L, C, px, py, smp, no, nd, nt);
+                L.wo = no; L.wd = nd; L.time = nt;
+                fresh = true;
+                active = true;
+                need = false;
+                touched = true;
+            }
+        }
+        uint32_t taken = (uint32_t)__popcll(need_mask);
+        if (lane == 0) wstate[WS_NEXT] = next + taken < total ? next + taken : total;
+    }
+    if (STATS) { st_t_refill += clock64() - st_t1; st_t1 = clock64(); }
+}
+
+// The everything-variants (media + textures + instances + lists) call the phase out of line: its several hundred live
+// values then get their own register allocation instead of squeezing the traversal loops' (left inline, the allocator spilled
+// traversal state inside the box and primitive loops as soon as anything in the kernel changed: C3 moved between 330 and 520
+// Msamples/s with the spill placement).  Only what shading reads of the traversal state crosses, by value.
+struct ShadeIo {
+    uint32_t flags;            // in: 1 is_shade, 2 active, 4 need;   out: 2 active, 4 need, 8 fresh, 16 touched
+    float T; uint32_t best_prim; int32_t best_inst; float best_aux;
+    V3 o, d; float time;       // in: the segment's ray (world ray when the scene has no instances); out: the new ray of fresh lanes
+    uint32_t cost_t0;
+};
+template <uint32_t F, bool LDS_SCENE, bool COST>
+__device__ __attribute__((noinline)) ShadeIo shade_refill_call(ShadeIo io, uint32_t lds_items, uint32_t wave_block) {
+    // a called function has neither the kernel-argument pointer nor the kernel's LDS pointers: the wave's LDS block comes as its
+    // offset in the workgroup's dynamic LDS, and the kernel left the argument segment's address in the wave state
+    const uint32_t lane = threadIdx.x & 63u;
+    float *cold = reinterpret_cast<float *>(smem) + wave_block;
+    unsigned long long *tile_sum = reinterpret_cast<unsigned long long *>(cold + 64 * ncold<F>());
+    uint32_t *wstate = reinterpret_cast<uint32_t *>(cold + 64 * ncold<F>() + 64 * 3 * 2);
+    KArgsC P;
+    {
+        uint64_t a = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(wstate[WS_KARGS]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(wstate[WS_KARGS + 1]) << 32);
+        P = (KArgsC)a;
+        asm volatile("" : "+s"(P));
+    }
+    Lane L;
+    memset(&L, 0, sizeof(L));
+    L.T = io.T; L.best_prim = io.best_prim; L.best_inst = io.best_inst; L.best_aux = io.best_aux;
+    L.o = io.o; L.d = io.d; L.time = io.time;
+    bool active = (io.flags & 2u) != 0u, need = (io.flags & 4u) != 0u, fresh = false, touched = false;
+    uint32_t cost_t0 = io.cost_t0;
+    PhaseClocks clk;
+    shade_refill_body<F, LDS_SCENE, false, COST>(L, (io.flags & 1u) != 0u, active, need, fresh, touched, cost_t0, P, cold, tile_sum, wstate, lane, lds_items, clk);
+    if (active && touched) cold_store_path<F>(cold, lane, L);      // fresh lanes: L.wo / L.wd hold the NEW ray, which is what the world-ray slots want
+    ShadeIo out = io;
+    out.flags = (active ? 2u : 0u) | (need ? 4u : 0u) | (fresh ? 8u : 0u) | (touched ? 16u : 0u);
+    out.o = L.wo; out.d = L.wd; out.time = L.time; out.cost_t0 = cost_t0;
+    return out;
+}
+
 // Work distribution.  A work UNIT is (8x8 tile, sample chunk), pulled by a WAVE from a global atomic counter and handed
 // out to its lanes sample by sample (item k -> pixel slot k & 63, sample s0 + (k >> 6): the 64 primary rays of one sample
 // index start together, which keeps the first segments coherent).  A lane whose path ended takes the next item by ballot +
@@ -199,21 +345,25 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
     unsigned long long st_t_box = 0, st_t_light = 0, st_t_heavy = 0, st_t_shade = 0, st_heavy_execs = 0, st_t0 = 0, st_t_total = 0, st_t_mat = 0, st_t_refill = 0, st_t_install = 0, st_t1 = 0;
     if (STATS) st_t_total = clock64();
 
-    // ---- LDS layout: [items][spheres][boxes][per-wave cold lane state][per-wave tile sums][per-wave unit state]
+    // ---- LDS layout: [items][spheres][boxes][per wave: cold lane state | tile sums | wave state]
     uint32_t lds_items = 0;
     float *cold;
     unsigned long long *tile_sum;   // the wave's current tile: 64 pixels x 3 fixed-point sums
     uint32_t *wstate;
+    uint32_t wave_block;            // offset of this wave's LDS block in the dynamic LDS, in floats
     {
         KArgsC P = kargs_fresh();
         lds_items = LDS_SCENE ? KARG(P, lds_items) : 0u;
         uint32_t lds_spheres = LDS_SCENE ? KARG(P, lds_spheres) : 0u;
         uint32_t lds_boxes = LDS_SCENE ? KARG(P, lds_boxes) : 0u;
-        float *dyn = reinterpret_cast<float *>(smem + (2u * lds_items + lds_spheres + 2u * lds_boxes));
-        const uint32_t n_waves = blockDim.x >> 6;
-        cold = dyn + wave * (64 * ncold<F>());
-        tile_sum = reinterpret_cast<unsigned long long *>(dyn + n_waves * (64 * ncold<F>())) + wave * (64 * 3);
-        wstate = reinterpret_cast<uint32_t *>(dyn + n_waves * (64 * ncold<F>() + 64 * 3 * 2)) + wave * WAVE_STATE_WORDS;
+        wave_block = 4u * (2u * lds_items + lds_spheres + 2u * lds_boxes) + wave * wave_block_floats<F>();     // in floats from smem
+        cold = reinterpret_cast<float *>(smem) + wave_block;
+        tile_sum = reinterpret_cast<unsigned long long *>(cold + 64 * ncold<F>());
+        wstate = reinterpret_cast<uint32_t *>(cold + 64 * ncold<F>() + 64 * 3 * 2);
+        if (lane == 0) {      // for called code: the address of the kernel-argument segment
+            uint64_t a = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+            wstate[WS_KARGS] = (uint32_t)a; wstate[WS_KARGS + 1] = (uint32_t)(a >> 32);
+        }
         if (LDS_SCENE) {
             const uint4 *gi = reinterpret_cast<const uint4 *>(KARG(P, S.items));
             for (uint32_t k = threadIdx.x; k < 2u * lds_items; k += blockDim.x) smem[(k >> 1) + ((k & 1u) ? lds_items : 0u)] = gi[k];
@@ -271,7 +421,6 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             DScene S = KARG(P, S);
             Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
             if (STATS) st_t0 = clock64();
-            cold_load_world_ray<F>(cold, lane, L);
             const uint32_t live = n_box + n_heavy + n_light + n_sn;   // lanes only change state here, none appear or vanish
             // steps between two exit tests (compile time: a run-time trip count costs 4-13 %).  With shading deferred the
             // optimum is 3 for the sphere-only and Cornell-type variants (against 4: C2 +0.7 %, C4 +1.3 %; 2: -3 %, 6: -1 %,
@@ -279,7 +428,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? BOX_UNROLL : BOX_UNROLL - 1;
             for (;;) {
                 if (F & VKF_INSTANCE) {     // end of an instance's item range: back to the parent space (rare)
-                    if (is_box && L.i >= L.end && L.cur_inst >= 0) leave_instance<F, Mem>(L, S);
+                    if (is_box && L.i >= L.end && L.cur_inst >= 0) { cold_load_world_ray<F>(cold, lane, L); leave_instance<F, Mem>(L, S); }
                 }
                 bool go = active && L.pend == 0u && L.i < range_end<F>(L, S);
                 if (STATS) {        // diagnostic build: same steps one at a time, counting the lanes in each
@@ -297,10 +446,13 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 uint32_t ns = live - nb - np;
                 if (STATS && !HAS_HEAVY) { st_heavy_execs += live; st_t_light += np; st_t_heavy += ns; st_prim_execs += 1; }   // sphere-only diagnostic: lanes per exit test
                 if (nb == 0 || nb < np * prim_weight || nb * shade_defer < ns) {   // another state now has more lanes parked than are stepping
-                    // sphere-only variants: when that state is PRIM, test the pending spheres right here and
-                    // keep stepping (saves the scheduler round trip that otherwise follows every ~10 box steps)
-                    if (!HAS_HEAVY && !(F & VKF_MEDIUM) && np != 0 && np * shade_defer >= ns) {
-                        if (active && has_prim_work(L)) prim_step<F, Mem>(L, S, M);
+                    // when that state is a LIGHT primitive test (Sphere / MovingSphere / Rect: never draws, never changes the
+                    // space), run it right here and keep stepping: saves the scheduler round trip that otherwise follows every
+                    // ~10 box steps
+                    bool light = active && has_prim_work(L) && !(HAS_HEAVY && prim_is_heavy(L.pend));
+                    uint32_t nl = HAS_HEAVY ? lanes_with(light) : np;
+                    if (nl != 0 && 2u * nl >= np && nl * shade_defer >= ns) {
+                        if (light) prim_step<F, Mem>(L, S, M);
                         is_box = active && !has_prim_work(L) && traversing(L);
                         continue;
                     }
@@ -325,113 +477,36 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             if (STATS) { if (n_heavy > n_light) st_t_heavy += clock64() - st_t0; else st_t_light += clock64() - st_t0; }
         } else {
             // ---- SHADE + REFILL
-            KArgsC P = kargs_fresh();
-            RenderConsts C = KARG(P, C);
-            DScene S = KARG(P, S);
-            Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
             if (STATS) { st_shade_execs++; st_shade_lanes += n_sn; st_t0 = clock64(); }
-            bool touched = is_shade;      // lanes whose path state is in registers during this phase
-            bool fresh = false;           // lanes that leave this phase with a new ray to install; it is parked in the
-                                          // (dead) world-ray fields L.wo / L.wd / L.time, so it costs no registers
-            // (the everything-variant keeps one begin_segment per call site: merging them there doubled its spills)
-            constexpr bool ONE_INSTALL = (F & VKF_ALL_SCENE) != VKF_ALL_SCENE;
-            if (is_shade) {
-                cold_load_path<F>(cold, lane, L);
-                if (STATS) st_t1 = clock64();
-                bool cont;
-                if (ONE_INSTALL) {
-                    V3 no, nd; float nt;
-                    cont = shade_core<F, Mem>(L, S, M, C, no, nd, nt);
-                    if (cont) { L.wo = no; L.wd = nd; L.time = nt; fresh = true; }
-                } else {
-                    cont = shade<F, Mem>(L, S, M, C);
+            // out of line for the everything-variants (see shade_refill_call); one begin_segment for both kinds of new ray
+            constexpr bool SPLIT = (F & VKF_ALL_SCENE) == VKF_ALL_SCENE && !STATS;
+            bool touched = false, fresh = false;
+            if constexpr (SPLIT) {
+                ShadeIo io;
+                io.flags = (is_shade ? 1u : 0u) | (active ? 2u : 0u) | (need ? 4u : 0u);
+                io.T = L.T; io.best_prim = L.best_prim; io.best_inst = L.best_inst; io.best_aux = L.best_aux;
+                io.o = L.o; io.d = L.d; io.time = L.time; io.cost_t0 = cost_t0;
+                io = shade_refill_call<F, LDS_SCENE, COST>(io, lds_items, wave_block);
+                active = (io.flags & 2u) != 0u; need = (io.flags & 4u) != 0u; fresh = (io.flags & 8u) != 0u;
+                cost_t0 = io.cost_t0;
+                if (fresh) {
+                    KArgsC P = kargs_fresh();
+                    DScene S = KARG(P, S);
+                    begin_segment(L, S, io.o, io.d, io.time);      // (the callee stored the path state, new world ray included)
                 }
-                if (STATS) st_t_mat += clock64() - st_t1;
-                if (!cont) {
-                    uint32_t xy = __float_as_uint(cold[CF_XY * 64 + lane]);
-                    size_t pix = (size_t)(xy >> 16) * C.width + (xy & 0xFFFFu);
-                    float4 *dbg = KARG(P, debug);
-                    if (dbg) dbg[pix * C.spp + __float_as_uint(cold[CF_SAMPLE * 64 + lane])] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(L.rng.ctr));
-                    long long *acc = KARG(P, accum);
-                    if (acc && isfinite(L.acc.x) && isfinite(L.acc.y) && isfinite(L.acc.z)) {   // main.rs:192-194; c += color (main.rs:193)
-                        unsigned long long fx = (unsigned long long)to_fixed(L.acc.x), fy = (unsigned long long)to_fixed(L.acc.y), fz = (unsigned long long)to_fixed(L.acc.z);
-                        // a sample of the tile the wave is handing out (nearly all of them) lands in the wave's LDS sums, which
-                        // reach the frame's accumulators once per unit; a straggler of an earlier unit goes there directly
-                        if ((xy & 0xFFF8FFF8u) == __builtin_amdgcn_readfirstlane(wstate[WS_TXY])) {
-                            unsigned long long *t = tile_sum + ((xy & 7u) | ((xy >> 13) & 0x38u)) * 3u;
-                            atomicAdd(t + 0, fx); atomicAdd(t + 1, fy); atomicAdd(t + 2, fz);
-                        } else {
-                            unsigned long long *a = reinterpret_cast<unsigned long long *>(acc) + pix * 3;
-                            atomicAdd(a + 0, fx); atomicAdd(a + 1, fy); atomicAdd(a + 2, fz);
-                        }
-                    }
-                    if (COST) {   // probe launch: the lane-time this sample took, charged to its tile
-                        uint32_t *tc = KARG(P, tile_cost);
-                        uint32_t now = (uint32_t)(wall_clock64() >> 4);
-                        if (tc) atomicAdd(&tc[((xy >> 16) / TILE) * KARG(P, tiles_x) + (xy & 0xFFFFu) / TILE], now - cost_t0);
-                    }
-                    active = false;
-                    need = true;
+            } else {
+                PhaseClocks clk;
+                shade_refill_body<F, LDS_SCENE, STATS, COST>(L, is_shade, active, need, fresh, touched, cost_t0, kargs_fresh(), cold, tile_sum, wstate, lane, lds_items, clk);
+                if (STATS) { st_t_mat += clk.mat; st_t_refill += clk.refill; st_t1 = clock64(); }
+                if (fresh) {
+                    KArgsC P = kargs_fresh();
+                    DScene S = KARG(P, S);
+                    begin_segment(L, S, L.wo, L.wd, L.time);   // one copy of the exact reciprocals for both kinds of new ray
                 }
+                if (active && touched) cold_store_path<F>(cold, lane, L);
+                if (STATS) st_t_install += clock64() - st_t1;
             }
-            if (STATS) st_t1 = clock64();
-            // ---- hand out samples of the wave's current unit to the lanes without a path; pull the next unit when it is used up
-            for (;;) {
-                unsigned long long need_mask = __builtin_amdgcn_ballot_w64(need);
-                if (!need_mask) break;
-                uint4 ws = *reinterpret_cast<const uint4 *>(wstate);       // one ds_read_b128, the same address in every lane
-                uint32_t txy = __builtin_amdgcn_readfirstlane(ws.x), s0 = __builtin_amdgcn_readfirstlane(ws.y);
-                uint32_t total = __builtin_amdgcn_readfirstlane(ws.z), next = __builtin_amdgcn_readfirstlane(ws.w);
-                if (next >= total) {
-                    uint32_t unit = 0;
-                    if (lane == 0) unit = atomicAdd(KARG(P, counter), 1u);
-                    unit = __builtin_amdgcn_readfirstlane(unit);
-                    const uint32_t n_chunks = KARG(P, n_chunks);
-                    if (unit >= KARG(P, n_local_tiles) * n_chunks) {                      // the launch's units are all handed out:
-                        need = false;                                                     // these lanes idle until the wave's last path ends
-                        break;
-                    }
-                    flush_tile_sums(tile_sum, KARG(P, accum), txy, lane, C.width, C.height);  // the finished unit's sums so far
-                    const uint32_t chunk = unit % n_chunks;
-                    // tiles are visited dearest-first when the probe launch left an order (see enqueue_render)
-                    uint32_t tslot = unit / n_chunks;
-                    { const uint32_t *ord = KARG(P, tile_order); if (ord) tslot = ord[tslot]; }
-                    const uint32_t tile = KARG(P, tile_rank) + tslot * KARG(P, tile_world);
-                    const uint32_t tiles_x = KARG(P, tiles_x);
-                    s0 = (uint32_t)(((uint64_t)C.spp * chunk) / n_chunks);
-                    const uint32_t s1 = (uint32_t)(((uint64_t)C.spp * (chunk + 1)) / n_chunks);
-                    txy = ((tile % tiles_x) * TILE) | (((tile / tiles_x) * TILE) << 16);
-                    next = 0u; total = 64u * (s1 - s0);
-                    if (lane == 0) { wstate[WS_TXY] = txy; wstate[WS_S0] = s0; wstate[WS_TOTAL] = total; }
-                }
-                uint32_t k = next + (uint32_t)__popcll(need_mask & ((1ull << lane) - 1ull));
-                if (need && k < total) {
-                    uint32_t q = k & 63u, smp = s0 + (k >> 6);
-                    uint32_t px = (txy & 0xFFFFu) + (q & 7u), py = (txy >> 16) + (q >> 3);
-                    if (px < C.width && py < C.height) {   // slots outside the image (edge tiles) are skipped: the lane asks again
-                        cold[CF_XY * 64 + lane] = __uint_as_float(px | (py << 16));
-                        cold[CF_SAMPLE * 64 + lane] = __uint_as_float(smp);
-                        if (COST) cost_t0 = (uint32_t)(wall_clock64() >> 4);
-                        if (ONE_INSTALL) {                 // the lane's next sample (main.rs:186-190)
-                            V3 no, nd; float nt;
-                            start_sample_core(L, C, px, py, smp, no, nd, nt);
-                            L.wo = no; L.wd = nd; L.time = nt;
-                            fresh = true;
-                        } else {
-                            start_sample(L, S, C, px, py, smp);
-                        }
-                        active = true;
-                        need = false;
-                        touched = true;
-                    }
-                }
-                uint32_t taken = (uint32_t)__popcll(need_mask);
-                if (lane == 0) wstate[WS_NEXT] = next + taken < total ? next + taken : total;
-            }
-            if (STATS) { st_t_refill += clock64() - st_t1; st_t1 = clock64(); }
-            if (ONE_INSTALL && fresh) begin_segment(L, S, L.wo, L.wd, L.time);   // one copy of the exact reciprocals for both kinds of new ray
-            if (active && touched) cold_store_path<F>(cold, lane, L);
-            if (STATS) { st_t_shade += clock64() - st_t0; st_t_install += clock64() - st_t1; }
+            if (STATS) st_t_shade += clock64() - st_t0;
         }
     }
     {   // the last unit's sums

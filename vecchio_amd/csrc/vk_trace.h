@@ -512,6 +512,12 @@ VK_HD void prim_step(Lane &L, const DScene &S, const Mem &M) {
     L.pend = L.pend2;
     L.pend2 = 0;
     process_ref<F, Mem>(L, S, M, ref);
+    // a light object followed by another light one (a leaf of two spheres / rects): both in this step, as above
+    if (!prim_is_heavy(ref) && L.pend != 0u && !prim_is_heavy(L.pend)) {
+        uint32_t ref2 = L.pend;
+        L.pend = 0;
+        process_ref<F, Mem>(L, S, M, ref2);
+    }
 }
 
 // sequential form (CPU emulator): one step of whichever kind is due
