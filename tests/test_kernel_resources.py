@@ -58,17 +58,20 @@ def test_cornell_variant_does_not_spill(built):
     for key, r in variants().items():
         if key[0] & ~F_PDF != F_CORNELL:
             continue
-        assert r["occupancy"] >= 4 and r["scratch"] == 0 and r["scratch_ops"] == 0 and r["vgprs"] <= 128, (key, r)
+        # (0 / 0 until the SHADE + REFILL phase became a function of its own: 16 B / 7 instructions, all in that phase)
+        assert r["occupancy"] >= 4 and r["scratch"] <= 16 and r["scratch_ops"] <= 8 and r["vgprs"] <= 128, (key, r)
 
 
 def test_full_variant_budget(built):
     for key, r in variants().items():
         if key[0] & ~F_PDF not in (0x17F, 0x17F & ~F_PDF):
             continue
-        assert r["occupancy"] >= 4 and r["scratch"] <= 176 and not r["dynamic_stack"], (key, r)
-        # The same scratch SIZE can be spilled in twice as many places: two extra live scalars in the work-fetch code
-        # once took this variant from 91 to 213 scratch instructions and C3 from 505 to 290 Msamples/s.
-        # (91..155 when written; the variants C3 runs are the 511 ones)
-        assert 0 <= r["scratch_ops"] <= 320, (key, r)
-        if key == (0x1FF, False, 4, False):
-            assert r["scratch_ops"] <= 130, (key, r)
+        assert r["occupancy"] >= 4 and not r["dynamic_stack"], (key, r)
+        if key[3]:
+            continue        # STATS builds keep the phase inline (diagnostics only)
+        # The everything-variants call the SHADE + REFILL phase out of line (vk_kernels.h shade_refill_call): the kernel's own code
+        # — the box and primitive loops — must stay free of spills (2 scratch instructions when written; inline, the allocator left
+        # 91..290 of them there and C3 moved between 330 and 520 Msamples/s with their placement).  ScratchSize is the callee's
+        # frame: its saved registers and its own spills (240 B when written).
+        assert 0 <= r["scratch_ops"] <= 8, (key, r)
+        assert r["scratch"] <= 288, (key, r)
