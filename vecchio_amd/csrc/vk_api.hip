@@ -71,7 +71,8 @@ struct EnvSwitches {
     int max_waves_per_cu = 0;          // VK_MAX_WAVES_PER_CU=n: lower the occupancy
     int chunk_cap = 0;                 // VK_CHUNK_CAP=n: samples per pixel per work unit
     int shade_defer = 0;               // VK_SHADE_DEFER=n
-    bool tile_order = true;            // VK_TILE_ORDER=0: raster order, no probe launch
+    bool tile_order = true;            // VK_TILE_ORDER=0: raster order, no probe launch; =1: dearest-first also for whole frames
+    bool tile_order_forced = false;
     int probe_spp = 0;                 // VK_PROBE_SPP=n
     int prim_weight = 0;               // VK_PRIM_WEIGHT=n
     int retree = -1;                   // VK_RETREE=0/1: force the SAH rebuild of draw-free subtrees off / on (default: vk_scene_desc.flags)
@@ -80,7 +81,7 @@ struct EnvSwitches {
         EnvSwitches v;
         if (const char *e = getenv("VK_FORCE_FULL_VARIANT")) v.force_full_variant = e[0] == '1';
         if (const char *e = getenv("VK_NO_LDS_SCENE")) v.no_lds_scene = e[0] == '1';
-        if (const char *e = getenv("VK_TILE_ORDER")) v.tile_order = e[0] != '0';
+        if (const char *e = getenv("VK_TILE_ORDER")) { v.tile_order = e[0] != '0'; v.tile_order_forced = e[0] == '1'; }
         if (const char *e = getenv("VK_RETREE")) v.retree = e[0] != '0' ? 1 : 0;
         v.max_waves_per_cu = int_env("VK_MAX_WAVES_PER_CU");
         v.chunk_cap = int_env("VK_CHUNK_CAP");
@@ -284,8 +285,10 @@ uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
     // unit); small enough that tiles of very different cost (fog, glass, grazing rays over 1M spheres) are spread over many
     // waves and that small images still give ~64K units for ~6K waves.  (C2: 32 / 64 / 128 spp per unit -> 5 218 / 5 235 / 5 221.)
     uint64_t tiles = (uint64_t)((p->width + TILE - 1) / TILE) * ((p->height + TILE - 1) / TILE);
-    uint64_t c = (uint64_t)p->samples_per_pixel * tiles / 65536u;
-    uint32_t cap = 64;
+    uint64_t c = (uint64_t)p->samples_per_pixel * (tiles / (p->tile_world ? p->tile_world : 1u)) / 65536u;      // ~64K units per launch
+    // One GPU: 64 (C2: 32 / 64 / 128 / 256 -> 5 218 / 5 235 / 5 221 / 4 960 Msamples/s).  One rank of N: the launch ends on the last
+    // units of the rank's dearest tiles, so smaller ones (C2's 1/8 share: 64 -> 54.2 ms, 32 -> 53.1, 16 -> 52.9, 8 -> 53.5; ideal 50.0).
+    uint32_t cap = (p->tile_world > 1u) ? 32u : 64u;
     // Scenes that exceed an XCD's L2 (C5): tile costs are skewed by orders of magnitude (rays grazing a million spheres at
     // the horizon), and the launch ends with the last units of the dearest tiles: small units spread them over more waves
     // (C5 at 256 spp: 4 -> 191, 8 -> 189, 16 -> 185, 32 -> 175 Msamples/s; at 32 spp: 4 -> 121, 8 -> 92, 16 -> 60, 32 -> 36)
@@ -348,7 +351,9 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     // (the COST build of the same kernel variant), three tiny kernels bucket-sort the tiles dearest first, and the real
     // launch takes its units in that order (longest processing time first).  The order never changes a pixel.
     // One rank's 1/8 share of C2: 78.1 -> 68.6 ms (ideal 64.9); whole frame 522 -> 519 ms including the probe.
-    bool use_order = A.n_local_tiles >= 64 && p->samples_per_pixel >= 64 && s->env.tile_order;
+    // (whole frames on one GPU gain nothing from it any more — there is no per-unit drain — and the 1 M-sphere scene loses 12 %
+    // with its dearest tiles all in flight at once; one rank's 1/8 share of C2: 59.7 ms in raster order, 53.9 dearest first, ideal 50.0)
+    bool use_order = A.n_local_tiles >= 64 && p->samples_per_pixel >= 64 && s->env.tile_order && (g.world > 1u || s->env.tile_order_forced);
     if (use_order) {
         int rc = ensure(s->tile_cost, s->tile_cost_n, (size_t)tiles * sizeof(uint32_t));
         if (rc == VK_OK) rc = ensure(s->tile_order, s->tile_order_n, (size_t)A.n_local_tiles * sizeof(uint32_t));
