@@ -1,22 +1,27 @@
-// vk_api.hip — the HIP megakernel and the C ABI of include/vecchio_amd.h (libvecchio_amd.so).
+// vk_api.hip — the C ABI of include/vecchio_amd.h (libvecchio_amd.so) around the HIP megakernel of vk_kernels.h.
 //
 // Kernel structure (gfx950 / CDNA4, wave64):
-//   * persistent workgroups (512-768 threads, sized by plan_residency); each WAVE repeatedly pulls one
-//     work unit = (8x8-pixel tile, sample chunk) from a global atomic counter;
-//   * one ray per lane.  A lane whose path ended pulls the next (pixel, sample) of the wave's unit
-//     through a ballot + prefix-popcount ("active-ray compaction": lanes never idle while the unit
-//     still has samples); the RNG is keyed (seed, pixel, sample), so the result does not depend on
-//     which lane, wave or GPU traces a sample;
+//   * persistent workgroups (512-768 threads, sized by plan_residency); each WAVE pulls work units =
+//     (8x8-pixel tile, sample chunk) from a global atomic counter and hands them to its lanes sample by
+//     sample; it pulls the next unit the moment the current one is handed out (no per-unit drain);
+//   * one ray per lane.  A lane whose path ended takes the next (pixel, sample) through a ballot +
+//     prefix-popcount ("active-ray compaction"); the RNG is keyed (seed, pixel, sample) and pixel sums are
+//     64-bit fixed point (integer atomics: LDS per tile, flushed to the frame's accumulators once per
+//     unit), so the image does not depend on which lane, wave, unit, tile partition or GPU traced a
+//     sample, nor on completion order;
 //   * a wave-level phase scheduler runs, each round, the code of the state most lanes are in: BOX
-//     (box_steps: nested steps under one shrinking EXEC mask), PRIM light / heavy, SHADE + REFILL;
-//     lane state that only shading needs (throughput, radiance, RNG, depth) is parked in LDS between
-//     SHADE phases so the traversal loops fit 80 VGPRs (6 waves/SIMD) or 128 (4 waves/SIMD);
+//     (box_steps: nested steps under one shrinking EXEC mask, light primitive tests inline), PRIM heavy,
+//     SHADE + REFILL (out of line for the everything-variants); lane state that only shading needs
+//     (throughput, RNG, depth, pixel) is parked in LDS between SHADE phases so the traversal loops fit
+//     80 VGPRs (6 waves/SIMD) or 128 (4 waves/SIMD);
 //   * traversal is the stack-free threaded walk of vk_trace.h; when the linear BVH + spheres + boxes
 //     fit next to that per-wave state WITHOUT costing occupancy, every workgroup stages them into its
 //     LDS (160 KB/CU) once and item fetches are ds_read_b128; otherwise they are L1/L2 gathers;
-//   * per-pixel sums live in LDS (one float3 per tile pixel per wave, ds_add_f32), written once per
-//     unit as a chunk partial; resolve_kernel adds the partials of a pixel in chunk order;
 //   * no MFMA: there is no dense contraction in a path tracer.
+//
+// Host side: one vk_scene per device (scene upload, per-launch scratch); vk_scene_create_multi = a group of
+// them: tiles dealt over the devices, each on its own stream, slabs moved to devices[0] by peer copies,
+// de-interleaved on device, one device-to-host copy.
 //
 // There is NO CPU fallback in this library: every entry point either runs on a gfx950
 // device or returns an error.
