@@ -1,5 +1,6 @@
-"""Host AddressSanitizer + UBSan over the oracle and the C++ host mirror (scene builders, BVHNode::new,
-flatten).  CPU only: GPU ASan / XNACK are not available on this pool."""
+"""Host AddressSanitizer + UBSan over the oracle, the C++ host mirror (scene builders, BVHNode::new, flatten) and the
+device library's lineariser + per-lane code (tests/emu), with and without re-treeing.  CPU only: GPU ASan / XNACK are
+not available on this pool."""
 import os
 import subprocess
 
@@ -9,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_oracle_and_host_under_asan_ubsan(tmp_path):
     exe = tmp_path / "asan_check"
     srcs = [os.path.join(ROOT, "oracle", "asan_check.cpp"), os.path.join(ROOT, "oracle", "oracle.cpp")] + \
-           [os.path.join(ROOT, "vecchio_amd", "host", f) for f in ("host.cpp", "scene.cpp", "host_api.cpp")]
+           [os.path.join(ROOT, "vecchio_amd", "host", f) for f in ("host.cpp", "scene.cpp", "host_api.cpp")] + \
+           [os.path.join(ROOT, "tests", "emu", "emu.cpp"), os.path.join(ROOT, "vecchio_amd", "csrc", "vk_linearize.cpp")]
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
                            "-fno-sanitize-recover=undefined", "-o", str(exe)] + srcs + ["-lpthread"])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
