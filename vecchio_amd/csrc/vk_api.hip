@@ -131,8 +131,8 @@ struct vk_scene {
     std::vector<vk_scene *> parts;
     // a part's own stream, its slab (on its device), the slab's landing buffer on devices[0] and the event that says it landed
     hipStream_t stream = nullptr;
-    void *slab = nullptr; size_t slab_bytes = 0;
-    void *landing = nullptr; size_t landing_bytes = 0; int landing_device = 0;
+    uint8_t *slab = nullptr; size_t slab_bytes = 0;
+    uint8_t *landing = nullptr; size_t landing_bytes = 0; int landing_device = 0;
     hipEvent_t ev_landed = nullptr;
     hipEvent_t ev_begin = nullptr;               // group: recorded on the caller's stream at the start of a frame
 };
@@ -478,13 +478,13 @@ int enqueue_render_multi(vk_scene *grp, const vk_camera *cam, const vk_render_pa
         if (rc != VK_OK) return rc;
         samples += sj.samples; launches += sj.kernel_launches;
         size_t bytes = (size_t)gj.n_local * 64u * slot_bytes;
-        { char *sl = reinterpret_cast<char *>(q->slab); rc = ensure(sl, q->slab_bytes, bytes); q->slab = sl; }
+        rc = ensure(q->slab, q->slab_bytes, bytes);
         if (rc != VK_OK) return rc;
         rc = u8 ? tile_move<TM_PACK_U8>(q->fb, q->slab, &pj, gj, q->stream) : tile_move<TM_PACK_F32>(q->fb, q->slab, &pj, gj, q->stream);
         if (rc != VK_OK) return rc;
         if (bytes > q->landing_bytes) {                // the landing buffer lives on devices[0]
             HIP_TRY(hipSetDevice(grp->device));
-            char *ld = reinterpret_cast<char *>(q->landing); rc = ensure(ld, q->landing_bytes, bytes); q->landing = ld;
+            rc = ensure(q->landing, q->landing_bytes, bytes);
             if (rc != VK_OK) return rc;
             HIP_TRY(hipSetDevice(q->device));
         }
@@ -524,7 +524,7 @@ void destroy_one(vk_scene *s) {
     (void)hipSetDevice(s->device);
     for (void *p : s->allocs) (void)hipFree(p);
     for (void *p : {(void *)s->counter, (void *)s->fb, (void *)s->fb8, (void *)s->accum, (void *)s->debug, (void *)s->phase_stats, (void *)s->tile_cost,
-                    (void *)s->tile_order, (void *)s->order_hist, s->slab})
+                    (void *)s->tile_order, (void *)s->order_hist, (void *)s->slab})
         if (p) (void)hipFree(p);
     if (s->landing) { (void)hipSetDevice(s->landing_device); (void)hipFree(s->landing); (void)hipSetDevice(s->device); }
     for (hipEvent_t e : {s->ev0, s->ev1, s->ev_landed, s->ev_begin})

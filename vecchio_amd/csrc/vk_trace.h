@@ -505,8 +505,18 @@ VK_HD void prim_step(Lane &L, const DScene &S, const Mem &M) {
         // left behind, accel.rs:64-70): the lane is back in the box loop after one primitive phase instead of two
         uint32_t ref2 = L.pend2;
         L.pend = 0; L.pend2 = 0;
-        process_ref<F, Mem>(L, S, M, ref);
-        if (ref2) process_ref<F, Mem>(L, S, M, ref2);
+        // both records are fetched before the first test so that their two memory (or LDS) latencies overlap
+        DSphere sa = M.sphere(VKD_INDEX(ref));
+        DSphere sb = M.sphere(VKD_INDEX(ref2 ? ref2 : ref));
+        float t; bool tie;
+        if (sphere_t_tie(sa.cx, sa.cy, sa.cz, sa.r, L.o, L.d, L.a, T_MIN, L.T, t, tie)) {
+            if (!tie || tie_replaces(L, S, ref)) accept<F, Mem>(L, t, ref, 0.0f);
+        }
+        if (ref2) {
+            if (sphere_t_tie(sb.cx, sb.cy, sb.cz, sb.r, L.o, L.d, L.a, T_MIN, L.T, t, tie)) {
+                if (!tie || tie_replaces(L, S, ref2)) accept<F, Mem>(L, t, ref2, 0.0f);
+            }
+        }
         return;
     }
     L.pend = L.pend2;
