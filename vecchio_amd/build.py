@@ -20,11 +20,31 @@ HIPFLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "
             "-Wall", "-Wno-unused-function"]
 
 
-def _newer(target, sources):
-    if not os.path.exists(target):
+def _fingerprint(sources, flags=()):
+    """content hash of the sources (and the flags they are built with): what a built file is a function of"""
+    import hashlib
+    h = hashlib.sha256(" ".join(flags).encode())
+    for s in sorted(sources):
+        h.update(os.path.basename(s).encode())
+        with open(s, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _newer(target, sources, flags=()):
+    """Is `target` stale?  By CONTENT, not by mtime: every built file has a `<file>.src` stamp beside it holding the hash of
+    the sources it was built from, so a library pushed to another machine (gpurun copies the tree; timestamps mean nothing
+    there) is rebuilt exactly when it is not the build of the sources next to it."""
+    stamp = target + ".src"
+    if not os.path.exists(target) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+    with open(stamp) as f:
+        return f.read().strip() != _fingerprint(sources, flags)
+
+
+def _stamp(target, sources, flags=()):
+    with open(target + ".src", "w") as f:
+        f.write(_fingerprint(sources, flags) + "\n")
 
 
 def _run(cmd):
@@ -56,19 +76,20 @@ def _device_deps():
 
 
 def host_is_stale():
-    return _newer(os.path.join(LIB, "libvecchio_host.so"), _host_deps()[1])
+    return _newer(os.path.join(LIB, "libvecchio_host.so"), _host_deps()[1], CXXFLAGS)
 
 
 def device_is_stale():
-    return _newer(os.path.join(LIB, "libvecchio_amd.so"), _device_deps()[1]) or not os.path.exists(kernel_resources_path())
+    return _newer(os.path.join(LIB, "libvecchio_amd.so"), _device_deps()[1], HIPFLAGS) or not os.path.exists(kernel_resources_path())
 
 
 def build_host(force=False):
     out = os.path.join(LIB, "libvecchio_host.so")
     srcs, deps = _host_deps()
-    if force or _newer(out, deps):
+    if force or _newer(out, deps, CXXFLAGS):
         os.makedirs(LIB, exist_ok=True)
         _run_atomic([CXX] + CXXFLAGS + ["-shared", "-o"], out, srcs)
+        _stamp(out, deps, CXXFLAGS)
     return out
 
 
@@ -77,8 +98,11 @@ def build_cli(force=False):
     src = os.path.join(HOST, "main.cpp")
     if not os.path.exists(src):
         return None
-    if force or _newer(out, [src, build_host()]):
+    host = build_host()
+    deps = [src, os.path.join(HOST, "host_api.h"), os.path.join(ROOT, "include", "vecchio_amd.h")]
+    if force or _newer(out, deps, CXXFLAGS) or not os.path.exists(host):
         _run([CXX] + CXXFLAGS + ["-o", out, src, "-L" + LIB, "-lvecchio_host", "-ldl", "-Wl,-rpath,$ORIGIN"])
+        _stamp(out, deps, CXXFLAGS)
     return out
 
 
@@ -86,7 +110,7 @@ def build_device(force=False):
     """hipcc cross-compiles for gfx950 without a GPU present."""
     out = os.path.join(LIB, "libvecchio_amd.so")
     srcs, deps = _device_deps()
-    if force or _newer(out, deps) or not os.path.exists(kernel_resources_path()):
+    if force or _newer(out, deps, HIPFLAGS) or not os.path.exists(kernel_resources_path()):
         os.makedirs(LIB, exist_ok=True)
         # -save-temps in a scratch directory: the gfx950 assembly is read back for the per-kernel spill counts
         import tempfile
@@ -117,6 +141,7 @@ def build_device(force=False):
         text = blocks[0] + "".join("Name: " + b.rstrip("\n") + f"\n   ScratchOps: {spills.get(b.split()[0], -1)}\n" for b in blocks[1:])
         with open(kernel_resources_path(), "w") as f:
             f.write(text)
+        _stamp(out, deps, HIPFLAGS)
     return out
 
 
@@ -139,8 +164,9 @@ def build_oracle(force=False):
     out = os.path.join(odir, "_build", "liboracle.so")
     deps = [os.path.join(odir, "oracle.cpp"), os.path.join(odir, "oracle.h"), os.path.join(CSRC, "vk_math.h"),
             os.path.join(ROOT, "include", "vecchio_amd.h")]
-    if force or _newer(out, deps):
-        _run(["make", "-C", odir])
+    if force or _newer(out, deps, ("oracle",)):
+        _run(["make", "-B", "-C", odir])
+        _stamp(out, deps, ("oracle",))
     return out
 
 
@@ -150,9 +176,10 @@ def build_emu(force=False):
     out = os.path.join(edir, "_build", "libemu.so")
     srcs = [os.path.join(edir, "emu.cpp"), os.path.join(CSRC, "vk_linearize.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("vk_trace.h", "vk_math.h", "vk_device_scene.h", "vk_linearize.h")]
-    if force or _newer(out, deps):
+    if force or _newer(out, deps, CXXFLAGS):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         _run([CXX] + CXXFLAGS + ["-shared", "-o", out] + srcs + ["-lpthread"])
+        _stamp(out, deps, CXXFLAGS)
     return out
 
 
