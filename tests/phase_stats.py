@@ -18,6 +18,7 @@ for job in jobs:
         tot = max(1, v[12])
         print(f"   per sample: box wave-steps {v[0]/ns:.3f} (fill {v[1]/max(1,v[0])/64:.3f}; lane box steps {v[1]/ns:.1f}), prim phases {v[2]/ns:.3f} (heavy {v[7]/ns:.3f}, fill {v[3]/max(1,v[2])/64:.3f}), shade phases {v[4]/ns:.3f} (fill {v[5]/max(1,v[4])/64:.3f}) rounds {v[6]/ns:.3f}")
         print(f"   wave clocks: box {v[8]/tot:.3f} light {v[9]/tot:.3f} heavy {v[10]/tot:.3f} shade {v[11]/tot:.3f} | clocks per: box step {v[8]/max(1,v[0]):.0f}, light prim {v[9]/max(1,v[2]-v[7]):.0f}, heavy prim {v[10]/max(1,v[7]):.0f}, shade phase {v[11]/max(1,v[4]):.0f}", flush=True)
-        print(f"   sphere-only builds: per exit test of the box loop: live {v[7]/max(1,v[2]):.1f} prim-pending {v[9]/max(1,v[2]):.1f} waiting-for-shade {v[10]/max(1,v[2]):.1f} (exit tests {v[2]/ns:.2f}/sample)")
+        if ds.info().features == 0:
+            print(f"   sphere-only builds: per exit test of the box loop: live {v[7]/max(1,v[2]):.1f} prim-pending {v[9]/max(1,v[2]):.1f} waiting-for-shade {v[10]/max(1,v[2]):.1f} (exit tests {v[2]/ns:.2f}/sample)")
         print(f"   shade phase split (clocks per phase): record+material {v[13]/max(1,v[4]):.0f}, refill {v[14]/max(1,v[4]):.0f}, install+cold store {v[15]/max(1,v[4]):.0f}, rest (cold load, deposit) {(v[11]-v[13]-v[14]-v[15])/max(1,v[4]):.0f}", flush=True)
     ds.close()
