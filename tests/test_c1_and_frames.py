@@ -64,3 +64,25 @@ def test_cli_harness_writes_reference_style_ppm(device, oracle, built, tmp_path)
     want = np.zeros((48, 48, 3), np.uint8)
     ffi.load_host_lib().vkh_to_color(ref.ctypes.data, 48, 48, want.ctypes.data)
     assert np.abs(got - want.astype(np.int64)).max() <= 1     # 8-bit quantisation of values equal to 1e-6
+
+
+def test_to_color_restatements_agree_on_the_cpu(built):
+    """Vec3::to_color (vec3.rs:44-61) three times over: the numpy restatement the GPU tests compare the device kernel with
+    (tests/golden_checks.py), and the C++ host mirror's writer (vkh_to_color, what vecchio_cli prints) — on NaN, negatives,
+    -0, values >= 1, +-inf, the 0.999 clamp boundary, code boundaries and random values, including the top-down row order."""
+    import golden_checks as G
+    from vecchio_amd import ffi
+    rng = np.random.default_rng(5)
+    w, h = 37, 11
+    img = rng.uniform(0, 1.3, (h, w, 3)).astype(np.float32)
+    b = np.float32(0.999) ** 2
+    special = np.array([np.nan, -1.0, -0.0, 0.0, 1.0, 2.0, np.inf, -np.inf, b, np.nextafter(b, np.float32(0)), np.nextafter(b, np.float32(2)),
+                        1e-45, 1e-38, (255.0 / 256) ** 2, (1.0 / 256) ** 2, 0.25, 1e30], np.float32)
+    img.reshape(-1)[:len(special)] = special
+    want = np.zeros((h, w, 3), np.uint8)
+    ffi.load_host_lib().vkh_to_color(img.ctypes.data, w, h, want.ctypes.data)
+    with np.errstate(invalid="ignore"):
+        mine = G.to_color(img)[::-1]
+    assert np.array_equal(mine, want)
+    q = G.to_color(np.array([[[0.0, 1.0, 100.0]]], np.float32))
+    assert q.tolist() == [[[0, 255, 255]]]
