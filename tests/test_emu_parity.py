@@ -61,3 +61,30 @@ def test_stress_scene_subset(oracle, emu, built):
     img_e, ps_e, _, info = emu.render_samples(hs.desc, cam, p)
     assert info[1] > 9000
     compare(ps_o, ps_e, img_o, img_e)
+
+
+@pytest.mark.parametrize("poison", ["direction", "origin", "inf_origin"])
+def test_non_finite_rays_in_a_sphere_only_scene(poison, oracle, emu, host_scenes):
+    """A ray with a NaN direction or origin hits every box (f32::min/max drop NaN quotients, accel.rs:21-31) and no sphere
+    (NaN discriminant, hittable.rs:66-70): the reference walks its whole tree and returns None.  In a spheres-only scene the
+    kernel skips that walk (vk_trace.h begin_segment); the outcome — miss, NaN sky colour, sample dropped by the finite
+    filter (main.rs:192-194) — and the draw count must be the oracle's."""
+    import ctypes as C
+    from vecchio_amd import ffi
+    hs, cam0 = host_scenes("random_spheres_iow")
+    cam = ffi.Camera.from_buffer_copy(cam0)
+    if poison == "direction":
+        cam.horizontal[1] = float("nan")
+    elif poison == "origin":
+        cam.origin[2] = float("nan")
+    else:
+        cam.origin[0] = float("inf")
+    p = hs.params(24, 3, 50)
+    img_o, ps_o = oracle.render_samples(hs.desc, cam, p)
+    img_e, ps_e, steps, info = emu.render_samples(hs.desc, cam, p)
+    assert np.array_equal(ps_o[:, 3].view(np.uint32), ps_e[:, 3].view(np.uint32))
+    assert np.array_equal(np.isfinite(ps_o[:, :3]).all(1), np.isfinite(ps_e[:, :3]).all(1))
+    assert np.array_equal(img_o, img_e)
+    if poison != "inf_origin":              # (an infinite origin gives direction (-inf, ..): unit(d).y = 0, a finite sky colour)
+        assert not np.isfinite(ps_o[:, :3]).all(1).any() and img_o.max() == 0.0
+    assert steps < 24 * 13 * 3 * 8          # no tree walk: the oracle's counters would say 511 box tests per sample

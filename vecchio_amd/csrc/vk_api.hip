@@ -294,10 +294,9 @@ uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
     // One GPU: 64 (C2: 32 / 64 / 128 / 256 -> 5 218 / 5 235 / 5 221 / 4 960 Msamples/s).  One rank of N: the launch ends on the last
     // units of the rank's dearest tiles, so smaller ones (C2's 1/8 share: 64 -> 54.2 ms, 32 -> 53.1, 16 -> 52.9, 8 -> 53.5; ideal 50.0).
     uint32_t cap = (p->tile_world > 1u) ? 32u : 64u;
-    // Scenes that exceed an XCD's L2 (C5): tile costs are skewed by orders of magnitude (rays grazing a million spheres at
-    // the horizon), and the launch ends with the last units of the dearest tiles: small units spread them over more waves
-    // (C5 at 256 spp: 4 -> 191, 8 -> 189, 16 -> 185, 32 -> 175 Msamples/s; at 32 spp: 4 -> 121, 8 -> 92, 16 -> 60, 32 -> 36)
-    if (s->hot_bytes > (4u << 20)) cap = p->samples_per_pixel >= 128u ? 8u : 4u;     // bigger than one XCD's L2
+    // (Round 1 and the first half of round 2 cut the units of scenes bigger than an XCD's L2 down to 8 spp "because tile costs are
+    // skewed by orders of magnitude": the skew was NaN rays walking the whole million-item tree — see begin_segment in vk_trace.h.
+    // Without them C5 prefers the common setting: 4 / 8 / 16 / 32 / 64 spp per unit -> 564 / 574 / 579 / 583 / 585 Msamples/s.)
     if (s->env.chunk_cap >= 1) cap = (uint32_t)s->env.chunk_cap;   // diagnostics
     uint32_t lo = cap < 32 ? cap : 32;
     uint32_t chunk_spp = (uint32_t)(c > cap ? cap : (c < lo ? lo : c));
@@ -324,9 +323,11 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     A.n_local_tiles = g.n_local;
     A.n_chunks = choose_chunks(s, p);
     A.counter = s->counter;
-    A.shade_defer = s->hot_bytes > (4u << 20) ? 1u : SHADE_DEFER;
+    A.shade_defer = SHADE_DEFER;          // (C5: 1 / 2 / 4 / 8 -> 573 / 588 / 593 / 603-at-pw-2)
     if (s->env.shade_defer >= 1 && s->env.shade_defer <= 64) A.shade_defer = (uint32_t)s->env.shade_defer;   // diagnostics
-    A.prim_weight = 1u;
+    // scenes beyond an XCD's L2 (C5: a leaf every 6 box steps, every gather a possible L2 miss): pending sphere tests are served
+    // sooner — when 3x their lanes outnumber the stepping ones (1 / 2 / 3 -> 606 / 623 / 631 Msamples/s); L2-resident scenes: 1
+    A.prim_weight = s->hot_bytes > (4u << 20) ? 3u : 1u;
     if (s->env.prim_weight >= 1 && s->env.prim_weight <= 64) A.prim_weight = (uint32_t)s->env.prim_weight;   // diagnostics
     size_t n_pixels = (size_t)p->width * p->height;
     if (stats) {

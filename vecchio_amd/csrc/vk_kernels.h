@@ -25,9 +25,8 @@ constexpr int TILE = 8;   // 8x8 pixels = one wave
 // times over: a shading phase costs ~700 issue slots against ~42 of a box step, so it pays to keep traversing with
 // thinning waves until nearly every lane waits for shading and then shade them all at once.  C2 / C4, Msamples/s:
 // 1 (plain plurality): 4 070 / 3 435; 1.5: 4 270 / 3 645; 2: 4 430 / 3 725; 3: 4 580 / 3 815; 4: 4 630 / 3 820;
-// 8: 4 600 / 3 765.  (Deferring only against BOX, not PRIM: 4 150.)  Scenes that miss L2 (C5) are bound by the
-// latency of the item gathers, not by issue slots: there every parked lane is a gather less in flight, and plain
-// plurality is better (C5: 69 against 58 Msamples/s), so the factor is a launch parameter.
+// 8: 4 600 / 3 765 (round 1).  (Deferring only against BOX, not PRIM: 4 150.)  It is a launch parameter (VK_SHADE_DEFER);
+// the 1 M-sphere scene prefers the same 4 once its NaN rays no longer walk the whole tree (1 / 2 / 4 -> 573 / 588 / 593).
 #ifndef VK_SHADE_DEFER
 #define VK_SHADE_DEFER 4
 #endif

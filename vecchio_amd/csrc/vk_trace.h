@@ -283,6 +283,16 @@ VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time) {
     set_space(L, o, d);
     L.i = 0; L.end = S.n_world_items; L.pend = 0; L.pend2 = 0; L.cur_inst = -1;
     L.T = INFINITY; L.best_prim = 0; L.best_inst = -1; L.best_aux = 0.0f;
+    // A ray with a NaN (or infinite) direction or origin hits EVERY box — f32::min/max drop the NaN quotients, accel.rs:21-31 —
+    // and no sphere: Sphere::hit's discriminant is NaN (hittable.rs:66-70).  The reference walks its whole tree for such a ray
+    // and returns None; in a scene of spheres only (nothing draws during traversal) the walk has no other effect, so it is
+    // skipped.  They come from Dielectric::scatter's refract() just past the critical angle (sqrt of a rounding-negative
+    // number, util.rs:18-23), about one sample in 10^7 — each cost a full 1 M-item walk on the stress scene: a 1.7 s tail on
+    // EVERY frame, whatever its length.
+    if (S.features == 0u) {
+        bool dead = !(L.a < INFINITY) || !(fabsf(o.x) + fabsf(o.y) + fabsf(o.z) < INFINITY);
+        if (dead) L.i = L.end;
+    }
 }
 
 template <uint32_t F, class Mem>
