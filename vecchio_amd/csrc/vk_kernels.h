@@ -331,8 +331,7 @@ __device__ __attribute__((noinline)) ShadeIo shade_refill_call(ShadeIo io, uint3
 // out to its lanes sample by sample (item k -> pixel slot k & 63, sample s0 + (k >> 6): the 64 primary rays of one sample
 // index start together, which keeps the first segments coherent).  A lane whose path ended takes the next item by ballot +
 // prefix popcount (active-ray compaction), and the wave pulls the NEXT unit the moment the current one is handed out:
-// nobody waits for the slowest path of a unit (the "drain" cost 5 % on C2 and most of the lanes on C5, whose tile costs
-// are heavy tailed).  That is possible because pixel sums are order independent (to_fixed above).
+// nobody waits for the slowest path of a unit (the "drain" cost 5 % on C2 and most of the lanes on C5).  That is possible because pixel sums are order independent (to_fixed above).
 template <uint32_t F, bool LDS_SCENE, int MINW, bool STATS, bool COST = false>
 __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ? 768 : 1024))), MINW) void render_kernel(KArgs A_byval) {
     (void)A_byval;
