@@ -36,13 +36,16 @@ def test_resource_file_lists_every_variant(built):
     assert {0, F_PDF, F_CORNELL | F_PDF, 0x17F, 0x17F | F_PDF} <= feats, sorted(feats)
     for f in feats:
         assert (f, True, 6 if f in (0, F_PDF) else 4, False) in v       # LDS-resident scene
-        assert (f, False, 6 if f in (0, F_PDF) else 4, False) in v      # global-memory scene
+        assert (f, False, 8 if f in (0, F_PDF) else 4, False) in v      # global-memory scene (sphere-only: 8 waves/SIMD, shading out of line)
 
 
 def test_sphere_only_variant_keeps_six_waves_per_simd(built):
     for key, r in variants().items():
         f, lds, minw, stats = key
         if f not in (0, F_PDF):
+            continue
+        if minw == 8:      # global-memory build: 64 VGPRs, the shading phase is a function of its own (vk_kernels.h shade_refill_call)
+            assert not lds and r["occupancy"] >= 8 and r["vgprs"] <= 64 and r["scratch_ops"] <= 40 and not r["dynamic_stack"], (key, r)
             continue
         assert minw == 6 and r["occupancy"] >= 6, (key, r)
         assert r["vgprs"] <= 80 and r["agprs"] == 0, (key, r)

@@ -200,7 +200,7 @@ void plan_residency(vk_scene *s, size_t hot) {
     if (best_waves >= cap && !s->env.no_lds_scene) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = best_wg * 64; s->wgs_per_cu = best_n;
     } else {
-        s->lds_bytes = 0; s->wg_threads = 512; s->wgs_per_cu = cap / 8;   // 24 (sphere-only) or 16 waves per CU
+        s->lds_bytes = 0; s->wg_threads = 512; s->wgs_per_cu = spheres_only ? 4 : cap / 8;   // 32 (sphere-only, 8 waves/SIMD) or 16 waves per CU
     }
 }
 
@@ -208,17 +208,18 @@ template <uint32_t F, int MINW_SPHERES = 6>
 int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st, bool cost) {
     // register budget: the sphere-only kernels fit 80 VGPRs (6 waves per SIMD, 24 per CU), the others are held to 128 (4 per SIMD)
     constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? MINW_SPHERES : 4;
-    // (global-memory traversal — C5, 33 MB of items — was also tried at 8 waves per SIMD / 64 VGPRs: 8 % slower.
-    // It is bound by the L2-miss path: every box step gathers a 32-byte item but moves a 128-byte line,
-    // ~3.5 TB/s of lines from the Infinity Cache at 21 Msamples/s; more waves in flight do not help.)
+    // Sphere-only scenes traversed from GLOBAL memory (C5, 49 MB of items and spheres) run at 8 waves per SIMD / 64 VGPRs with the
+    // shading phase out of line: every box step is a dependent gather there, and once no NaN ray walks the whole tree any more
+    // (vk_trace.h begin_segment) more waves in flight are worth 9 % (629 -> 685 Msamples/s; with the NaN walks it was -5 %).
+    constexpr int MINW_G = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? 8 : MINW;
     auto go = [&](auto kernel) -> int {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(kernel, grid, dim3(s->wg_threads), shmem, st, A);
         return VK_OK;
     };
     int rc;
-    if (cost) rc = lds ? go(&render_kernel<F, true, MINW, false, true>) : go(&render_kernel<F, false, MINW, false, true>);
-    else rc = lds ? go(&render_kernel<F, true, MINW, false, false>) : go(&render_kernel<F, false, MINW, false, false>);
+    if (cost) rc = lds ? go(&render_kernel<F, true, MINW, false, true>) : go(&render_kernel<F, false, MINW_G, false, true>);
+    else rc = lds ? go(&render_kernel<F, true, MINW, false, false>) : go(&render_kernel<F, false, MINW_G, false, false>);
     if (rc != VK_OK) return rc;
     HIP_TRY(hipGetLastError());
     return VK_OK;

@@ -477,7 +477,9 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             // ---- SHADE + REFILL
             if (STATS) { st_shade_execs++; st_shade_lanes += n_sn; st_t0 = clock64(); }
             // out of line for the everything-variants (see shade_refill_call); one begin_segment for both kinds of new ray
-            constexpr bool SPLIT = (F & VKF_ALL_SCENE) == VKF_ALL_SCENE && !STATS;
+            // ... and for the 8-waves-per-SIMD build of the sphere-only variants (scenes traversed from global memory: every box step a
+            // dependent gather, so more waves in flight pay — C5 629 -> 685 Msamples/s — and 64 VGPRs hold the traversal loops but not shading)
+            constexpr bool SPLIT = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE || MINW == 8) && !STATS;
             bool touched = false, fresh = false;
             if constexpr (SPLIT) {
                 ShadeIo io;
