@@ -43,10 +43,15 @@ WORKLOADS = {
 }
 
 
-def algorithmic_bytes_per_sample(c, spp):
-    """SURVEY §8(d) / BASELINE.md §4 with the canonical record sizes."""
+def algorithmic_bytes_per_sample(c, spp, walked_only=False):
+    """SURVEY §8(d) / BASELINE.md §4 with the canonical record sizes.  `walked_only` leaves out the visits of segments whose
+    ray is NaN / infinite: the reference walks the whole tree for such a ray (every box passes, every sphere fails) and
+    the device skips that walk in sphere-only scenes, where its outcome is known (vk_trace.h begin_segment)."""
     n = float(c["samples"])
-    return (32.0 * c["n_aabb"] + 16.0 * c["n_sphere"] + 36.0 * c["n_moving"] + 24.0 * c["n_rect"] + 32.0 * c["n_xform"] +
+    aabb, sph = c["n_aabb"], c["n_sphere"]
+    if walked_only:
+        aabb, sph = aabb - c["n_aabb_nonfinite"], sph - c["n_sphere_nonfinite"]
+    return (32.0 * aabb + 16.0 * sph + 36.0 * c["n_moving"] + 24.0 * c["n_rect"] + 32.0 * c["n_xform"] +
             8.0 * c["n_medium"] + 16.0 * c["n_closest"] + 3.0 * c["n_texel"] + 8.0 * 24.0 * c["n_perlin"]) / n + 12.0 / spp
 
 
@@ -222,6 +227,8 @@ def main():
                                  f"{tc:.1f} s, oracle (recursive CPU restatement) on {cores} threads"}
             c = cnt.as_dict()
             bps = algorithmic_bytes_per_sample(c, spp)
+            sphere_only = info.features == 0       # the sphere-only kernel variant: the one that skips those walks
+            bps_walked = algorithmic_bytes_per_sample(c, spp, walked_only=sphere_only)
             k_ms = float(np.mean(kernel_ms)) if kernel_ms else None
             # measured HBM traffic and instruction counts per launch: PMC counters cannot be collected from inside this
             # process, so they come from the committed rocprofv3 passes of this same command (profiles/, tests/prof_r02.sh):
@@ -250,6 +257,10 @@ def main():
                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                         "traffic_note": f"HBM bytes per launch from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command ({prof_path}), not re-measured in this run",
                         "algorithmic_bytes_per_sample": round(bps, 1), "kernel_ms": round(k_ms, 3),
+                        "algorithmic_bytes_per_sample_walked": round(bps_walked, 1),
+                        "frac_walked": round(achieved * bps_walked / bps / HBM_PEAK_GBPS, 4),
+                        "walked_note": "the same, without the whole-tree walks of NaN / infinite rays that the reference performs and the device "
+                                       "skips in sphere-only scenes (their outcome is a miss); equal to frac for every other scene",
                         "note": "algorithmic bytes (SURVEY 8d record sizes x oracle visit counts); the scene is LDS/L2 resident, so this is not "
                                 "a physical bound (it can exceed 1): the physical one is `issue`",
                         "issue": issue}

@@ -36,6 +36,7 @@ namespace {
 thread_local std::string g_err;
 thread_local vk::Rng *g_rng = nullptr;          // the "thread_rng()" of the current sample
 thread_local oracle_counters g_cnt;             // per-thread visit counters
+thread_local uint64_t g_nonfinite_segment = 0;  // 1 while the segment's ray has a NaN / infinite direction or origin (counters only)
 thread_local bool g_panic = false;              // a reference panic!/unwrap was reached
 
 inline vk::Rng &thread_rng() { return *g_rng; }
@@ -172,6 +173,7 @@ struct AxisBB {
     Vec3 min, max;
     bool hit(const Ray &r, float tmin, float tmax) const {  // accel.rs:16-35
         g_cnt.n_aabb++;
+        g_cnt.n_aabb_nonfinite += g_nonfinite_segment;
         float tmin_local = tmin;
         float tmax_local = tmax;
         for (int a = 0; a < 3; a++) {
@@ -511,6 +513,7 @@ struct Sphere : Hittable {  // hittable.rs:46-121
     Vec3 center; float radius; const Material *material; uint32_t mi;
     bool hit(const Ray &r, float tmin, float tmax, HitRec &ret) const override {  // hittable.rs:65-95
         g_cnt.n_sphere++;
+        g_cnt.n_sphere_nonfinite += g_nonfinite_segment;
         Vec3 oc = r.origin - center;
         float a = r.direction.length2();
         float half_b = oc.dot(r.direction);
@@ -1005,10 +1008,18 @@ inline Vec3 background_of(const RenderCtx &c, const Ray &r) {
     return c.background_color;  // main.rs:124
 }
 
+// (counters only) does the ray have a NaN / infinite direction or origin?  Dielectric::scatter's refract() produces such
+// directions just past the critical angle (sqrt of a rounding-negative number, util.rs:18-23)
+static inline bool nonfinite_ray(const Ray &r) {
+    float s = std::fabs(r.origin.x) + std::fabs(r.origin.y) + std::fabs(r.origin.z);
+    return !(r.direction.length2() < INFINITY) || !(s < INFINITY);
+}
+
 // main.rs:123-153
 Vec3 ray_color(const RenderCtx &ctx, Ray r, uint32_t depth) {
     if (depth > ctx.max_depth) return Vec3::new_const(0.0f);  // main.rs:126-128
     g_cnt.segments++;
+    g_nonfinite_segment = nonfinite_ray(r) ? 1u : 0u;   // counters only: such a ray passes every AxisBB::hit and fails every Sphere::hit
     HitRec c;
     if (ctx.scene->world->hit(r, 0.001f, INFINITY, c)) {  // main.rs:130
         g_cnt.n_closest++;
@@ -1036,6 +1047,7 @@ Vec3 ray_color(const RenderCtx &ctx, Ray r, uint32_t depth) {
 Vec3 ray_color_scatter(const RenderCtx &ctx, Ray r, uint32_t depth) {
     if (depth > ctx.max_depth) return Vec3::new_const(0.0f);
     g_cnt.segments++;
+    g_nonfinite_segment = nonfinite_ray(r) ? 1u : 0u;   // counters only: such a ray passes every AxisBB::hit and fails every Sphere::hit
     HitRec c;
     if (ctx.scene->world->hit(r, 0.001f, INFINITY, c)) {
         g_cnt.n_closest++;

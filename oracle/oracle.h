@@ -34,6 +34,8 @@ typedef struct oracle_counters {
     uint64_t n_perlin;       /* Perlin::noise calls = octaves (material.rs:392-413)    */
     uint64_t n_draws;        /* u32 draws consumed                                     */
     uint64_t n_dropped;      /* samples dropped by the finite filter (main.rs:192-194) */
+    uint64_t n_aabb_nonfinite;   /* of n_aabb: tests for segments whose ray is NaN / infinite (it passes every box)   */
+    uint64_t n_sphere_nonfinite; /* of n_sphere: likewise (it fails every sphere)                                      */
 } oracle_counters;
 
 /* Render the whole image (or this call's tile partition) on n_threads host threads

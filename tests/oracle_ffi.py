@@ -15,7 +15,7 @@ ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "samples", "segments", "n_aabb", "n_sphere", "n_moving", "n_rect", "n_xform", "n_medium",
-        "n_closest", "n_texel", "n_perlin", "n_draws", "n_dropped")]
+        "n_closest", "n_texel", "n_perlin", "n_draws", "n_dropped", "n_aabb_nonfinite", "n_sphere_nonfinite")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
