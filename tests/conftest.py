@@ -56,6 +56,10 @@ def host_scenes(built):
 def device(built):
     """The HIP library on a real GPU; fails loudly (never falls back) when it is unusable."""
     from vecchio_amd import ffi
+    # torch first: its wheel carries its own HIP runtime, which finds no GPU when it is initialised after the system one
+    # that libvecchio_amd.so links (tests that hand torch tensors to vk_render_device would then depend on test order)
+    import torch
+    torch.cuda.init()
     lib = ffi.load_device_lib()
     n = lib.vk_device_count()
     assert n >= 1, "no gfx950 device visible: -m gpu tests need the MI355X box"

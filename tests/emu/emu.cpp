@@ -28,7 +28,7 @@ static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string
 template <uint32_t F>
 static void trace_one(const DScene &S, const GlobalMem &M, const RenderConsts &C, uint32_t pixel, uint32_t sample, V3 &rgb, uint32_t &draws, uint64_t *steps) {
     Lane L;
-    start_sample(L, S, C, pixel % C.width, pixel / C.width, sample);
+    start_sample<F>(L, S, C, pixel % C.width, pixel / C.width, sample);
     for (;;) {
         while (traversing(L)) { traverse_step<F, GlobalMem>(L, S, M); if (steps) (*steps)++; }
         if (!shade<F, GlobalMem>(L, S, M, C)) break;
@@ -46,13 +46,58 @@ static RenderConsts make_consts(const vk_camera *cam, const vk_render_params *p)
     return C;
 }
 
+// AxisBB::hit property test: the kernel's box step (fast path + margin, exact fallback) against the reference's division
+// sequence alone, for n (box, ray, tmax) triples.  fused = 0: the (b - o) * (1/d) form of the general variants; 1: the
+// fma(b, 1/d, -o/d) form of the sphere-only variants.  decisions[i] bit0 = kernel's answer, bit1 = slab_exact's answer,
+// bit2 = the kernel took the exact fallback.
+template <uint32_t F>
+static void box_decisions(const float *boxes, const float *rays, size_t n, uint8_t *decisions) {
+    for (size_t k = 0; k < n; k++) {
+        DItem it;
+        it.mnx = boxes[k * 6 + 0]; it.mxx = boxes[k * 6 + 1]; it.mny = boxes[k * 6 + 2]; it.mxy = boxes[k * 6 + 3];
+        it.mnz = boxes[k * 6 + 4]; it.mxz = boxes[k * 6 + 5];
+        it.w0 = ((uint32_t)DK_SPHERE << 28) | 1u; it.w1 = 0;      // a leaf: pend != 0 afterwards <=> box hit
+        Lane L;
+        memset(&L, 0, sizeof(L));
+        V3 o = v3(rays[k * 7 + 0], rays[k * 7 + 1], rays[k * 7 + 2]), d = v3(rays[k * 7 + 3], rays[k * 7 + 4], rays[k * 7 + 5]);
+        set_space<fused_box<F>()>(L, o, d);
+        L.T = rays[k * 7 + 6];
+        L.i = 0; L.end = 1; L.pend = 0;
+        GlobalMem M{&it, nullptr, nullptr, nullptr};
+        box_step_core<F, GlobalMem>(L, M);
+        bool fast = L.pend != 0;
+        bool exact = slab_exact(it, o, d, T_MIN, rays[k * 7 + 6]);
+        // was the fallback taken?  the margin test exactly as box_step_core writes it
+        float x0, x1, y0, y1, z0, z1;
+        if (fused_box<F>()) {
+            x0 = __builtin_fmaf(it.mnx, L.inv.x, -L.oi.x); x1 = __builtin_fmaf(it.mxx, L.inv.x, -L.oi.x);
+            y0 = __builtin_fmaf(it.mny, L.inv.y, -L.oi.y); y1 = __builtin_fmaf(it.mxy, L.inv.y, -L.oi.y);
+            z0 = __builtin_fmaf(it.mnz, L.inv.z, -L.oi.z); z1 = __builtin_fmaf(it.mxz, L.inv.z, -L.oi.z);
+        } else {
+            x0 = (it.mnx - o.x) * L.inv.x; x1 = (it.mxx - o.x) * L.inv.x;
+            y0 = (it.mny - o.y) * L.inv.y; y1 = (it.mxy - o.y) * L.inv.y;
+            z0 = (it.mnz - o.z) * L.inv.z; z1 = (it.mxz - o.z) * L.inv.z;
+        }
+        float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));
+        float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), rays[k * 7 + 6]));
+        float dlt = hi - lo;
+        bool fb = !(fabsf(dlt) >= __builtin_fmaf(hi, 2.0e-6f, L.xnan));
+        decisions[k] = (uint8_t)((fast ? 1 : 0) | (exact ? 2 : 0) | (fb ? 4 : 0));
+    }
+}
 extern "C" {
 
 const char *emu_last_error(void) { return g_err.c_str(); }
 
-// full-feature variant only (the GPU picks leaner variants; logic is the same code)
+// the full-feature variants, and for scenes of spheres only the sphere-only ones (as the device library picks them: they
+// run the fused box test, vk_trace.h set_space); the Cornell-type variants in between are the same code as the full ones
 static const uint32_t FALL = VKF_ALL_SCENE;
 static const uint32_t FPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
+static void trace_any(const DScene &S, const GlobalMem &M, const RenderConsts &C, uint32_t integrator, uint32_t pixel, uint32_t sample, V3 &rgb, uint32_t &draws, uint64_t *steps) {
+    bool lean = S.features == 0u && !getenv("VK_FORCE_FULL_VARIANT");
+    if (integrator == VK_INTEGRATOR_PDF) { if (lean) trace_one<VKF_INTEG_PDF>(S, M, C, pixel, sample, rgb, draws, steps); else trace_one<FPDF>(S, M, C, pixel, sample, rgb, draws, steps); }
+    else { if (lean) trace_one<0u>(S, M, C, pixel, sample, rgb, draws, steps); else trace_one<FALL>(S, M, C, pixel, sample, rgb, draws, steps); }
+}
 
 int emu_sample(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *p, uint32_t pixel, uint32_t sample,
                float rgb[3], uint32_t *draws) {
@@ -63,8 +108,7 @@ int emu_sample(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
     GlobalMem M{S.items, S.spheres, S.sphere_mat, S.boxes};
     RenderConsts C = make_consts(cam, p);
     V3 c; uint32_t dr;
-    if (p->integrator == VK_INTEGRATOR_PDF) trace_one<FPDF>(S, M, C, pixel, sample, c, dr, nullptr);
-    else trace_one<FALL>(S, M, C, pixel, sample, c, dr, nullptr);
+    trace_any(S, M, C, p->integrator, pixel, sample, c, dr, nullptr);
     rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
     if (draws) *draws = dr;
     return VK_OK;
@@ -79,7 +123,7 @@ int emu_first_hit(const vk_scene_desc *desc, const vk_camera *cam, const vk_rend
     GlobalMem M{S.items, S.spheres, S.sphere_mat, S.boxes};
     RenderConsts C = make_consts(cam, p);
     Lane L;
-    start_sample(L, S, C, pixel % C.width, pixel / C.width, sample);
+    start_sample<FALL>(L, S, C, pixel % C.width, pixel / C.width, sample);
     out[0] = L.o.x; out[1] = L.o.y; out[2] = L.o.z; out[3] = L.d.x; out[4] = L.d.y; out[5] = L.d.z;
     while (traversing(L)) traverse_step<FALL, GlobalMem>(L, S, M);
     out[6] = L.T; memcpy(&out[7], &L.best_prim, 4);
@@ -110,8 +154,7 @@ int emu_render(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
                 V3 sum = v3s(0.0f);
                 for (uint32_t s = 0; s < p->samples_per_pixel; s++) {
                     V3 c; uint32_t dr;
-                    if (p->integrator == VK_INTEGRATOR_PDF) trace_one<FPDF>(S, M, C, pix, s, c, dr, &steps);
-                    else trace_one<FALL>(S, M, C, pix, s, c, dr, &steps);
+                    trace_any(S, M, C, p->integrator, pix, s, c, dr, &steps);
                     if (per_sample_out) {
                         float *o = per_sample_out + ((size_t)pix * p->samples_per_pixel + s) * 4;
                         o[0] = c.x; o[1] = c.y; o[2] = c.z; memcpy(&o[3], &dr, 4);
@@ -132,35 +175,9 @@ int emu_render(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
     return VK_OK;
 }
 
-// AxisBB::hit property test: the kernel's box step (reciprocal multiplies + margin, exact fallback) against the
-// reference's division sequence alone, for n (box, ray, tmax) triples.  decisions[i] bit0 = kernel's answer,
-// bit1 = slab_exact's answer, bit2 = the kernel took the exact fallback.
-void emu_box_decisions(const float *boxes, const float *rays, size_t n, uint8_t *decisions) {
-    for (size_t k = 0; k < n; k++) {
-        DItem it;
-        it.mnx = boxes[k * 6 + 0]; it.mxx = boxes[k * 6 + 1]; it.mny = boxes[k * 6 + 2]; it.mxy = boxes[k * 6 + 3];
-        it.mnz = boxes[k * 6 + 4]; it.mxz = boxes[k * 6 + 5];
-        it.w0 = ((uint32_t)DK_SPHERE << 28) | 1u; it.w1 = 0;      // a leaf: pend != 0 afterwards <=> box hit
-        Lane L;
-        memset(&L, 0, sizeof(L));
-        V3 o = v3(rays[k * 7 + 0], rays[k * 7 + 1], rays[k * 7 + 2]), d = v3(rays[k * 7 + 3], rays[k * 7 + 4], rays[k * 7 + 5]);
-        set_space(L, o, d);
-        L.T = rays[k * 7 + 6];
-        L.i = 0; L.end = 1; L.pend = 0;
-        GlobalMem M{&it, nullptr, nullptr, nullptr};
-        box_step_core<VKF_ALL_SCENE, GlobalMem>(L, M);
-        bool fast = L.pend != 0;
-        bool exact = slab_exact(it, o, d, T_MIN, rays[k * 7 + 6]);
-        // was the fallback taken?  the margin test exactly as box_step_core writes it
-        float x0 = (it.mnx - o.x) * L.inv.x, x1 = (it.mxx - o.x) * L.inv.x;
-        float y0 = (it.mny - o.y) * L.inv.y, y1 = (it.mxy - o.y) * L.inv.y;
-        float z0 = (it.mnz - o.z) * L.inv.z, z1 = (it.mxz - o.z) * L.inv.z;
-        float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));
-        float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), rays[k * 7 + 6]));
-        float dlt = hi - lo;
-        bool fb = !(fabsf(dlt) >= __builtin_fmaf(hi, 2.0e-6f, L.xnan));
-        decisions[k] = (uint8_t)((fast ? 1 : 0) | (exact ? 2 : 0) | (fb ? 4 : 0));
-    }
+void emu_box_decisions(const float *boxes, const float *rays, size_t n, uint8_t *decisions, int fused) {
+    if (fused) box_decisions<0u>(boxes, rays, n, decisions);
+    else box_decisions<VKF_ALL_SCENE>(boxes, rays, n, decisions);
 }
 
 }  // extern "C"

@@ -6,15 +6,16 @@ box_step_core (tests/emu) against slab_exact alone."""
 import ctypes as C
 
 import numpy as np
+import pytest
 
 
-def decide(emu, boxes, rays):
+def decide(emu, boxes, rays, fused):
     lib = emu.load()
-    lib.emu_box_decisions.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.emu_box_decisions.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
     boxes = np.ascontiguousarray(boxes, np.float32)
     rays = np.ascontiguousarray(rays, np.float32)
     out = np.zeros(len(boxes), np.uint8)
-    lib.emu_box_decisions(boxes.ctypes.data, rays.ctypes.data, len(boxes), out.ctypes.data)
+    lib.emu_box_decisions(boxes.ctypes.data, rays.ctypes.data, len(boxes), out.ctypes.data, int(fused))
     return out
 
 
@@ -27,9 +28,11 @@ def make_boxes(rng, n, scale):
     return b
 
 
-def test_fast_path_equals_reference_divisions(emu):
-    rng = np.random.default_rng(7)
-    n = 1_500_000
+@pytest.mark.parametrize("fused", [0, 1], ids=["sub_mul", "fused"])
+def test_fast_path_equals_reference_divisions(emu, fused):
+    """fused = 1: the fma(b, 1/d, -o/d) form of the sphere-only kernel variants (margin with an |o/d| term)"""
+    rng = np.random.default_rng(7 + fused)
+    n = 1_000_000
     total_fb = 0
     for scale, offset in ((1.0, 0.0), (500.0, 0.0), (1.0, 3.0e4)):
         # offset: the whole configuration far from the world origin — o/d is huge next to the t of the box, the worst case for
@@ -55,7 +58,7 @@ def test_fast_path_equals_reference_divisions(emu):
             tt = (np.linalg.norm(target - o, axis=1) / np.linalg.norm(d, axis=1)).astype(np.float32)
         tmax[near & np.isfinite(tt)] = tt[near & np.isfinite(tt)]
         rays = np.concatenate([o, d, tmax[:, None]], 1)
-        dec = decide(emu, boxes, rays)
+        dec = decide(emu, boxes, rays, fused)
         bad = ((dec & 1) != ((dec >> 1) & 1))
         assert not bad.any(), f"{int(bad.sum())} of {n} decisions differ, first: box {boxes[bad][0]} ray {rays[bad][0]}"
         total_fb += int(((dec >> 2) & 1).sum())
@@ -63,7 +66,8 @@ def test_fast_path_equals_reference_divisions(emu):
     assert 0 < total_fb < 0.2 * 3 * n          # the fallback is exercised, and is the exception
 
 
-def test_always_hit_leaf_boxes(emu):
+@pytest.mark.parametrize("fused", [0, 1], ids=["sub_mul", "fused"])
+def test_always_hit_leaf_boxes(emu, fused):
     """objects that sit beside a BVH child are leaves with a +-3e38 box: hit for every ray the reference could form"""
     rng = np.random.default_rng(8)
     n = 200_000
@@ -71,6 +75,6 @@ def test_always_hit_leaf_boxes(emu):
     o = rng.uniform(-1e4, 1e4, (n, 3)).astype(np.float32)
     d = rng.normal(size=(n, 3)).astype(np.float32) * rng.choice(np.array([1.0, 1e-6, 1e6], np.float32), (n, 1))
     tmax = rng.choice(np.array([np.inf, 10.0, 0.002], np.float32), n)
-    dec = decide(emu, boxes, np.concatenate([o, d, tmax[:, None]], 1))
+    dec = decide(emu, boxes, np.concatenate([o, d, tmax[:, None]], 1), fused)
     assert ((dec & 1) == ((dec >> 1) & 1)).all()
     assert (dec & 1).all()

@@ -16,7 +16,10 @@ LIB = os.path.join(ROOT, "vecchio_amd", "lib")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXX = os.environ.get("CXX", "g++")
 CXXFLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-Wall", "-Wextra"]
-HIPFLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+# -fno-slp-vectorize: left alone, LLVM packs adjacent scalar f32 adds/multiplies of the sphere test and the shading code into
+# v_pk_add_f32 / v_pk_mul_f32 behind v_mov shuffles and s_nops; on gfx950 those do not issue faster than the scalar pair and cost
+# registers (measured: C2 +2.3 %, C4 +2.4 %, C3 +7.8 %, C5 +2.3 % without them; the sphere-only kernel 78 -> 74 VGPRs)
+HIPFLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC",
             "-Wall", "-Wno-unused-function"]
 
 

@@ -68,8 +68,12 @@ struct LdsMem {
         o.mat = b.z; o._p = 0;
         return o;
     }
-    __device__ __forceinline__ DItem item(uint32_t i) const {
-        uint4 a = items[i], b = items_hi[i];
+    // the traversal cursor counts BYTES of these two arrays (16 per item; see GlobalMem::ISHIFT): the skip links of the staged
+    // items are scaled to match when a workgroup copies them in (render_kernel)
+    static constexpr uint32_t ISHIFT = 4;
+    __device__ __forceinline__ DItem item(uint32_t off) const {
+        uint4 a = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(items) + off);
+        uint4 b = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(items_hi) + off);
         DItem n;
         n.mnx = __uint_as_float(a.x); n.mxx = __uint_as_float(a.y); n.mny = __uint_as_float(a.z); n.mxy = __uint_as_float(a.w);
         n.mnz = __uint_as_float(b.x); n.mxz = __uint_as_float(b.y);
@@ -313,7 +317,7 @@ __device__ __attribute__((noinline)) ShadeIo shade_refill_call(ShadeIo io, uint3
         asm volatile("" : "+s"(P));
     }
     Lane L;
-    memset(&L, 0, sizeof(L));
+    __builtin_memset(&L, 0, sizeof(L));     // (the intrinsic: HIP's device memset() is a loop, which keeps a Lane this large in scratch)
     L.T = io.T; L.best_prim = io.best_prim; L.best_inst = io.best_inst; L.best_aux = io.best_aux;
     L.o = io.o; L.d = io.d; L.time = io.time;
     bool active = (io.flags & 2u) != 0u, need = (io.flags & 4u) != 0u, fresh = false, touched = false;
@@ -364,7 +368,11 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
         }
         if (LDS_SCENE) {
             const uint4 *gi = reinterpret_cast<const uint4 *>(KARG(P, S.items));
-            for (uint32_t k = threadIdx.x; k < 2u * lds_items; k += blockDim.x) smem[(k >> 1) + ((k & 1u) ? lds_items : 0u)] = gi[k];
+            for (uint32_t k = threadIdx.x; k < 2u * lds_items; k += blockDim.x) {
+                uint4 h = gi[k];
+                if ((k & 1u) && (h.z >> 28) == 0u) h.z <<= LdsMem::ISHIFT;      // an inner item's skip link, in cursor units
+                smem[(k >> 1) + ((k & 1u) ? lds_items : 0u)] = h;
+            }
             const uint4 *gs = reinterpret_cast<const uint4 *>(KARG(P, S.spheres));
             for (uint32_t k = threadIdx.x; k < lds_spheres; k += blockDim.x) smem[2u * lds_items + k] = gs[k];
             const uint4 *gb = reinterpret_cast<const uint4 *>(KARG(P, S.boxes));
@@ -377,7 +385,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
     if (lane == 0) { wstate[WS_TXY] = 0xFFFFFFFFu; wstate[WS_NEXT] = 0u; wstate[WS_TOTAL] = 0u; }
 
     Lane L;
-    memset(&L, 0, sizeof(L));
+    __builtin_memset(&L, 0, sizeof(L));     // (the intrinsic: HIP's device memset() is a loop, which keeps a Lane this large in scratch)
     uint32_t cost_t0 = 0;      // probe (COST) build only: when this lane's current sample started
     (void)cost_t0;
     bool need = true;          // lane has no path and wants a sample (false once the launch's units are all handed out)
@@ -428,12 +436,12 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 if (F & VKF_INSTANCE) {     // end of an instance's item range: back to the parent space (rare)
                     if (is_box && L.i >= L.end && L.cur_inst >= 0) { cold_load_world_ray<F>(cold, lane, L); leave_instance<F, Mem>(L, S); }
                 }
-                bool go = active && L.pend == 0u && L.i < range_end<F>(L, S);
+                bool go = active && L.pend == 0u && L.i < range_end<F, Mem>(L, S);
                 if (STATS) {        // diagnostic build: same steps one at a time, counting the lanes in each
                     for (int u = 0; u < UNROLL; u++) {
                         st_box_steps += 1; st_box_lanes += lanes_with(go);
                         box_steps<F, Mem, 1>(L, S, M, go);
-                        go = active && L.pend == 0u && L.i < range_end<F>(L, S);
+                        go = active && L.pend == 0u && L.i < range_end<F, Mem>(L, S);
                     }
                 } else {
                     box_steps<F, Mem, UNROLL>(L, S, M, go);
@@ -492,7 +500,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 if (fresh) {
                     KArgsC P = kargs_fresh();
                     DScene S = KARG(P, S);
-                    begin_segment(L, S, io.o, io.d, io.time);      // (the callee stored the path state, new world ray included)
+                    begin_segment<Mem::ISHIFT, fused_box<F>()>(L, S, io.o, io.d, io.time);      // (the callee stored the path state, new world ray included)
                 }
             } else {
                 PhaseClocks clk;
@@ -501,7 +509,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 if (fresh) {
                     KArgsC P = kargs_fresh();
                     DScene S = KARG(P, S);
-                    begin_segment(L, S, L.wo, L.wd, L.time);   // one copy of the exact reciprocals for both kinds of new ray
+                    begin_segment<Mem::ISHIFT, fused_box<F>()>(L, S, L.wo, L.wd, L.time);   // one copy of the exact reciprocals for both kinds of new ray
                 }
                 if (active && touched) cold_store_path<F>(cold, lane, L);
                 if (STATS) st_t_install += clock64() - st_t1;

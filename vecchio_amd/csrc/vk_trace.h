@@ -55,6 +55,10 @@ struct RenderConsts {   // per-launch constants (camera + params)
 // Hot records (items, spheres) come either from HBM/L2 (GlobalMem) or from the workgroup's
 // LDS copy of the scene (LdsMem, set up by the kernel).
 struct GlobalMem {
+    // The traversal cursor (Lane::i, Lane::end, the skip links) counts in units of 1 << ISHIFT: plain item indices here; the
+    // LDS-resident scene (vk_kernels.h LdsMem) counts in BYTES of its 16-byte-stride arrays, so that a box step needs no shift
+    // to form its two ds_read addresses (the skip links are scaled once, when a workgroup stages the items).
+    static constexpr uint32_t ISHIFT = 0;
     const DItem *items; const DSphere *spheres; const uint32_t *sphere_mat; const DBox *boxes;
     VK_HD DBox box(uint32_t i) const { return boxes[i]; }
     VK_HD DItem item(uint32_t i) const { return items[i]; }
@@ -66,7 +70,8 @@ struct GlobalMem {
 struct Lane {
     // current-space ray (object space while inside an instance)
     V3 o, d; float time;
-    V3 inv; float a; float xnan;   // xnan: 0, or NaN when the reciprocal-multiply box test must not be trusted
+    V3 inv; float a; float xnan;   // xnan: the additive part of the box test's margin (0 unfused), or NaN when its fast path must not be trusted
+    V3 oi;                     // o * (1/d): fused box test only (set_space)
     V3 wo, wd;                 // world-space ray of this segment
     // traversal cursor
     uint32_t i, end, pend, pend2; int32_t cur_inst;
@@ -81,14 +86,33 @@ struct Lane {
 // the next f32 above a positive finite t (+inf stays +inf)
 VK_HD float nextafter_up(float t) { return (t > 0.0f && t < INFINITY) ? vk::bits_f32(vk::f32_bits(t) + 1u) : t; }
 
+// The sphere-only kernel variants run the FUSED box test (box_step_core): one fma per bound, t~ = fma(b, 1/d, -o/d), against
+// the other variants' (b - o) * (1/d).  Both are decided against the reference's fl(fl(b - o) / d) with a margin and fall
+// back to the reference's own division sequence inside it; the fused form needs three more registers per lane (o/d), which
+// only the sphere-only variants have to spare, and its margin carries a term in |o/d| (cancellation when b*(1/d) ~ o/d).
+template <uint32_t F> constexpr bool fused_box() { return (F & ~(uint32_t)VKF_INTEG_PDF) == 0u; }
+
+template <bool FUSED = false>
 VK_HD void set_space(Lane &L, V3 o, V3 d) {
     L.o = o; L.d = d;
     L.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     L.a = length2(d);
     float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    // reciprocal-multiply slab test is only trusted when 1/d is a full-precision normal number
-    bool ok = ax > 1e-30f && ax < 1e30f && ay > 1e-30f && ay < 1e30f && az > 1e-30f && az < 1e30f;
-    L.xnan = ok ? 0.0f : vk::bits_f32(0x7FC00000u);
+    if (FUSED) {
+        // With u = 2^-24, r = fl(1/d), c = fl(o*r): fma(b, r, -c) = (1/d)(1+e2)(1+e4)(b - o - o*e3), the reference's value is
+        // ((b - o)/d)(1+e0)(1+e1), all |e| <= u, so the two differ by at most 4u|t| + u|o/d| (+ second order).  As in the
+        // unfused case (box_step_core) the decision hi > lo is then the reference's whenever |hi - lo| >= (8u*hi + 2u*max|o/d|)/(1 - 4u):
+        // the test there uses 2e-6*hi + 2^-21*max|c|, four times that.  Rays whose 1/d or o/d leave the range where these
+        // bounds hold without overflow go through the exact test every time (xnan = NaN).
+        L.oi = v3(o.x * L.inv.x, o.y * L.inv.y, o.z * L.inv.z);
+        float c = fmaxf(fmaxf(fabsf(L.oi.x), fabsf(L.oi.y)), fabsf(L.oi.z));
+        bool ok = ax > 1e-18f && ax < 1e18f && ay > 1e-18f && ay < 1e18f && az > 1e-18f && az < 1e18f && c < 1e18f;
+        L.xnan = ok ? c * 4.76837158203125e-7f : vk::bits_f32(0x7FC00000u);      // 2^-21
+    } else {
+        // reciprocal-multiply slab test is only trusted when 1/d is a full-precision normal number
+        bool ok = ax > 1e-30f && ax < 1e30f && ay > 1e-30f && ay < 1e30f && az > 1e-30f && az < 1e30f;
+        L.xnan = ok ? 0.0f : vk::bits_f32(0x7FC00000u);
+    }
 }
 
 // ------------------------------------------------------------------ instance transforms (hittable.rs:507-524,579-624,676-713,765-802)
@@ -278,10 +302,11 @@ VK_HD bool slab_exact(const DItem &n, V3 o, V3 d, float tmin, float tmax) {
     return true;
 }
 // ------------------------------------------------------------------ traversal
+template <uint32_t ISHIFT = 0, bool FUSED = false>
 VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time) {
     L.wo = o; L.wd = d; L.time = time;
-    set_space(L, o, d);
-    L.i = 0; L.end = S.n_world_items; L.pend = 0; L.pend2 = 0; L.cur_inst = -1;
+    set_space<FUSED>(L, o, d);
+    L.i = 0; L.end = S.n_world_items << ISHIFT; L.pend = 0; L.pend2 = 0; L.cur_inst = -1;
     L.T = INFINITY; L.best_prim = 0; L.best_inst = -1; L.best_aux = 0.0f;
     // A ray with a NaN (or infinite) direction or origin hits EVERY box — f32::min/max drop the NaN quotients, accel.rs:21-31 —
     // and no sphere: Sphere::hit's discriminant is NaN (hittable.rs:66-70).  The reference walks its whole tree for such a ray
@@ -373,22 +398,22 @@ VK_HD void enter_instance(Lane &L, const DScene &S, uint32_t ref) {
     const DInstance &I = S.instances[idx];
     V3 o = L.o, d = L.d;
     for (uint32_t k = 0; k < I.n_ops; k++) apply_op(I.ops[k], o, d);
-    set_space(L, o, d);
+    set_space<fused_box<F>()>(L, o, d);
     L.cur_inst = idx;
     L.pend2 = 0;   // the home leaf's right object is restored from home_pend on leave
-    if (I.child_end > I.child_begin) { L.i = I.child_begin; L.end = I.child_end; L.pend = 0; }
+    if (I.child_end > I.child_begin) { L.i = I.child_begin << Mem::ISHIFT; L.end = I.child_end << Mem::ISHIFT; L.pend = 0; }
     else { L.i = 0; L.end = 0; L.pend = I.child_ref; }
 }
 template <uint32_t F, class Mem>
 VK_HD void leave_instance(Lane &L, const DScene &S) {
     const DInstance &I = S.instances[L.cur_inst];
     int32_t P = I.parent;
-    L.i = I.home_next; L.pend = I.home_pend; L.pend2 = 0;
-    L.end = P < 0 ? S.n_world_items : S.instances[P].child_end;
+    L.i = I.home_next << Mem::ISHIFT; L.pend = I.home_pend; L.pend2 = 0;
+    L.end = (P < 0 ? S.n_world_items : S.instances[P].child_end) << Mem::ISHIFT;
     L.cur_inst = P;
     V3 o, d;
     ray_in_instance(S, P, L.wo, L.wd, o, d);
-    set_space(L, o, d);
+    set_space<fused_box<F>()>(L, o, d);
 }
 
 template <uint32_t F, class Mem>
@@ -463,9 +488,16 @@ VK_HD bool box_step_core(Lane &L, const Mem &M) {      // returns: a leaf's box 
     // (scalar on purpose: v_pk_add_f32/v_pk_mul_f32 on the (min,max) pair of each axis was measured SLOWER twice —
     // -5 % as compiler vectors (the broadcast operands get materialised as register pairs), -14 % as inline asm
     // with op_sel broadcasts of (o.x,o.y)/(inv.x,inv.y)/(o.z,inv.z): the packed ops do not issue at twice the rate here)
-    float x0 = (n.mnx - L.o.x) * L.inv.x, x1 = (n.mxx - L.o.x) * L.inv.x;
-    float y0 = (n.mny - L.o.y) * L.inv.y, y1 = (n.mxy - L.o.y) * L.inv.y;
-    float z0 = (n.mnz - L.o.z) * L.inv.z, z1 = (n.mxz - L.o.z) * L.inv.z;
+    float x0, x1, y0, y1, z0, z1;
+    if constexpr (fused_box<F>()) {     // one fma per bound (set_space<true> explains the margin)
+        x0 = __builtin_fmaf(n.mnx, L.inv.x, -L.oi.x); x1 = __builtin_fmaf(n.mxx, L.inv.x, -L.oi.x);
+        y0 = __builtin_fmaf(n.mny, L.inv.y, -L.oi.y); y1 = __builtin_fmaf(n.mxy, L.inv.y, -L.oi.y);
+        z0 = __builtin_fmaf(n.mnz, L.inv.z, -L.oi.z); z1 = __builtin_fmaf(n.mxz, L.inv.z, -L.oi.z);
+    } else {
+        x0 = (n.mnx - L.o.x) * L.inv.x; x1 = (n.mxx - L.o.x) * L.inv.x;
+        y0 = (n.mny - L.o.y) * L.inv.y; y1 = (n.mxy - L.o.y) * L.inv.y;
+        z0 = (n.mnz - L.o.z) * L.inv.z; z1 = (n.mxz - L.o.z) * L.inv.z;
+    }
     float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));   // >= T_MIN > 0, never NaN
     float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), L.T));    // <= T, never NaN
     // lo >= T_MIN > 0, so with e = 3*2^-24 the sign of the exact (hi - lo) equals the sign of this one whenever
@@ -478,22 +510,22 @@ VK_HD bool box_step_core(Lane &L, const Mem &M) {      // returns: a leaf's box 
         h = slab_exact(n, L.o, L.d, T_MIN, L.T);         // within rounding distance: the reference's divisions
     bool inner = (n.w0 >> 28) == 0u;
     bool leaf_hit = h && !inner;
-    L.i = (inner && !h) ? n.w0 : L.i + 1u;               // inner: hit -> left subtree, miss -> skip link
+    L.i = (inner && !h) ? n.w0 : L.i + (1u << Mem::ISHIFT);   // inner: hit -> left subtree, miss -> skip link (in cursor units)
     L.pend = leaf_hit ? n.w0 : 0u;                       // leaf: left object first, then the right one
     L.pend2 = n.w1;                                      // only read after pend, i.e. after a leaf hit
     return leaf_hit;
 }
 
 // range end of the lane's current item range: wave-uniform when the scene has no instances
-template <uint32_t F>
-VK_HD uint32_t range_end(const Lane &L, const DScene &S) { return (F & VKF_INSTANCE) ? L.end : S.n_world_items; }
+template <uint32_t F, class Mem>
+VK_HD uint32_t range_end(const Lane &L, const DScene &S) { return (F & VKF_INSTANCE) ? L.end : (S.n_world_items << Mem::ISHIFT); }
 
 // N box steps, each run by the lanes that still have box work: nested ifs, i.e. one shrinking EXEC mask
 template <uint32_t F, class Mem, int N>
 VK_HD void box_steps(Lane &L, const DScene &S, const Mem &M, bool go) {
     if (go) {
         bool queued = box_step_core<F, Mem>(L, M);      // (the mask is at hand: cheaper than comparing pend with 0 again)
-        if (N > 1) box_steps<F, Mem, (N > 1 ? N - 1 : 1)>(L, S, M, !queued && L.i < range_end<F>(L, S));
+        if (N > 1) box_steps<F, Mem, (N > 1 ? N - 1 : 1)>(L, S, M, !queued && L.i < range_end<F, Mem>(L, S));
     }
 }
 
@@ -885,10 +917,11 @@ VK_HD void start_sample_core(Lane &L, const RenderConsts &C, uint32_t x, uint32_
     time = vk::gen_range(L.rng, C.cam.time0, C.cam.time1);
     L.thr = v3s(1.0f); L.acc = v3s(0.0f); L.depth = 1;
 }
+template <uint32_t F = VKF_ALL_SCENE>
 VK_HD void start_sample(Lane &L, const DScene &S, const RenderConsts &C, uint32_t x, uint32_t y, uint32_t sample) {
     V3 o, d; float time;
     start_sample_core(L, C, x, y, sample, o, d, time);
-    begin_segment(L, S, o, d, time);
+    begin_segment<0, fused_box<F>()>(L, S, o, d, time);
 }
 
 VK_HD V3 background_of(const RenderConsts &C, V3 ud) {       // ud = unit(ray direction), only read for the sky
@@ -1038,7 +1071,7 @@ template <uint32_t F, class Mem>
 VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) {
     V3 o, d; float time;
     if (!shade_core<F, Mem>(L, S, M, C, o, d, time)) return false;
-    begin_segment(L, S, o, d, time);
+    begin_segment<Mem::ISHIFT, fused_box<F>()>(L, S, o, d, time);
     return true;
 }
 
