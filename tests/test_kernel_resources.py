@@ -24,7 +24,7 @@ def variants():
         get = lambda k: int(re.search(re.escape(k) + r": (\d+)", blk).group(1))
         out[(int(m.group(1)), m.group(2) == "1", int(m.group(3)), m.group(4) == "1")] = dict(
             vgprs=get("VGPRs"), agprs=get("AGPRs"), scratch=get("ScratchSize [bytes/lane]"),
-            occupancy=get("Occupancy [waves/SIMD]"), dynamic_stack="Dynamic Stack: True" in blk,
+            occupancy=get("Occupancy [waves/SIMD]"), dynamic_stack="Dynamic Stack: True" in blk, static_lds=get("LDS Size [bytes/block]"),
             scratch_ops=int(re.search(r"ScratchOps: (-?\d+)", blk).group(1)))
     return out
 
@@ -80,3 +80,9 @@ def test_full_variant_budget(built):
         # frame: its saved registers and its own spills (240 B when written).
         assert 0 <= r["scratch_ops"] <= 8, (key, r)
         assert r["scratch"] <= 288, (key, r)
+
+
+def test_no_static_lds(built):
+    """LdsMem::item reads the staged items at ABSOLUTE LDS addresses (cursor = address): the dynamic LDS array must start at 0"""
+    for key, r in variants().items():
+        assert r["static_lds"] == 0, (key, r)

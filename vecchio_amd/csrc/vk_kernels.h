@@ -71,9 +71,15 @@ struct LdsMem {
     // the traversal cursor counts BYTES of these two arrays (16 per item; see GlobalMem::ISHIFT): the skip links of the staged
     // items are scaled to match when a workgroup copies them in (render_kernel)
     static constexpr uint32_t ISHIFT = 4;
+    uint32_t items_hi_off;   // byte offset of items_hi in the workgroup's LDS
     __device__ __forceinline__ DItem item(uint32_t off) const {
-        uint4 a = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(items) + off);
-        uint4 b = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(items_hi) + off);
+        // Absolute LDS addresses: the staged scene starts at LDS address 0 (the kernels have no static LDS: pinned by
+        // tests/test_kernel_resources.py), so the cursor IS the address of the first half.  Through `smem` the compiler adds
+        // the array's link-time address (0) with a VALU instruction per read.
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef const u32x4 __attribute__((address_space(3))) *lds_u4;
+        u32x4 a = *(lds_u4)(uintptr_t)off;
+        u32x4 b = *(lds_u4)(uintptr_t)(off + items_hi_off);
         DItem n;
         n.mnx = __uint_as_float(a.x); n.mxx = __uint_as_float(a.y); n.mny = __uint_as_float(a.z); n.mxy = __uint_as_float(a.w);
         n.mnz = __uint_as_float(b.x); n.mxz = __uint_as_float(b.y);
@@ -109,7 +115,7 @@ template <uint32_t F, bool LDS_SCENE>
 __device__ __forceinline__ typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type make_mem(const DScene &S, uint32_t lds_items) {
     typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type M;
     if constexpr (LDS_SCENE) {
-        M.items = smem; M.items_hi = smem + lds_items; M.spheres = reinterpret_cast<const float4 *>(smem + 2u * lds_items);
+        M.items = smem; M.items_hi = smem + lds_items; M.items_hi_off = lds_items << 4; M.spheres = reinterpret_cast<const float4 *>(smem + 2u * lds_items);
         M.boxes = smem + 2u * lds_items + S.n_spheres; M.sphere_mat = S.sphere_mat;
     } else {
         M.items = S.items; M.spheres = S.spheres; M.sphere_mat = S.sphere_mat; M.boxes = S.boxes;

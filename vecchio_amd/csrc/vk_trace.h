@@ -478,6 +478,18 @@ VK_HD bool prim_is_heavy(uint32_t ref) { uint32_t k = VKD_KIND(ref); return k >=
 // objects or reaches the end of its range drops out of the mask and costs nothing more, and the
 // bookkeeping is a handful of VALU selects (a fully predicated version that kept all 64 lanes in
 // EXEC and re-did item 0 on idle lanes spent 14 of its 45 VALU instructions on selects).
+// fminf(a, t) for the loop-carried tmax: fminf() makes the compiler re-quiet `t` with a v_max_f32 t, t in every box step (it cannot
+// see through the loop that t is never a signalling NaN); v_min_f32 itself returns the same value for every a and every non-NaN t
+VK_HD float min_with_tmax(float a, float t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(t));
+    return r;
+#else
+    return fminf(a, t);
+#endif
+}
+
 template <uint32_t F, class Mem>
 VK_HD bool box_step_core(Lane &L, const Mem &M) {      // returns: a leaf's box was hit (objects queued in pend)
     DItem n = M.item(L.i);
@@ -499,7 +511,7 @@ VK_HD bool box_step_core(Lane &L, const Mem &M) {      // returns: a leaf's box 
         z0 = (n.mnz - L.o.z) * L.inv.z; z1 = (n.mxz - L.o.z) * L.inv.z;
     }
     float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));   // >= T_MIN > 0, never NaN
-    float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), L.T));    // <= T, never NaN
+    float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), min_with_tmax(fmaxf(z0, z1), L.T));    // <= T, never NaN
     // lo >= T_MIN > 0, so with e = 3*2^-24 the sign of the exact (hi - lo) equals the sign of this one whenever
     // |hi - lo| > 2e*hi/(1-e) ~ 3.6e-7*hi (also for hi <= 0: a certain miss).  The test below asks for 2e-6*hi,
     // and is false (-> exact fallback) when xnan is NaN, i.e. for rays whose 1/d is not a full-precision normal
