@@ -8,6 +8,7 @@
 #include <thread>
 #include <atomic>
 #include <vector>
+#include <type_traits>
 
 #include "../../vecchio_amd/csrc/vk_linearize.h"
 #include "../../vecchio_amd/csrc/vk_trace.h"
@@ -25,13 +26,17 @@ static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string
     return linearize(desc, LS, err, opt);
 }
 
-template <uint32_t F>
-static void trace_one(const DScene &S, const GlobalMem &M, const RenderConsts &C, uint32_t pixel, uint32_t sample, V3 &rgb, uint32_t &draws, uint64_t *steps) {
+// the same records as GlobalMem, with the fused box test the device runs on LDS-resident scenes (vk_trace.h set_space)
+struct FusedMem : GlobalMem { static constexpr bool FUSED_BOX = true; };
+
+template <uint32_t F, class Mem = GlobalMem>
+static void trace_one(const DScene &S, const GlobalMem &M0, const RenderConsts &C, uint32_t pixel, uint32_t sample, V3 &rgb, uint32_t &draws, uint64_t *steps) {
+    Mem M; static_cast<GlobalMem &>(M) = M0;
     Lane L;
-    start_sample<F>(L, S, C, pixel % C.width, pixel / C.width, sample);
+    start_sample<F, Mem>(L, S, C, pixel % C.width, pixel / C.width, sample);
     for (;;) {
-        while (traversing(L)) { traverse_step<F, GlobalMem>(L, S, M); if (steps) (*steps)++; }
-        if (!shade<F, GlobalMem>(L, S, M, C)) break;
+        while (traversing(L)) { traverse_step<F, Mem>(L, S, M); if (steps) (*steps)++; }
+        if (!shade<F, Mem>(L, S, M, C)) break;
     }
     rgb = L.acc;
     draws = L.rng.ctr;
@@ -50,7 +55,7 @@ static RenderConsts make_consts(const vk_camera *cam, const vk_render_params *p)
 // sequence alone, for n (box, ray, tmax) triples.  fused = 0: the (b - o) * (1/d) form of the general variants; 1: the
 // fma(b, 1/d, -o/d) form of the sphere-only variants.  decisions[i] bit0 = kernel's answer, bit1 = slab_exact's answer,
 // bit2 = the kernel took the exact fallback.
-template <uint32_t F>
+template <uint32_t F, bool FUSED>
 static void box_decisions(const float *boxes, const float *rays, size_t n, uint8_t *decisions) {
     for (size_t k = 0; k < n; k++) {
         DItem it;
@@ -60,16 +65,17 @@ static void box_decisions(const float *boxes, const float *rays, size_t n, uint8
         Lane L;
         memset(&L, 0, sizeof(L));
         V3 o = v3(rays[k * 7 + 0], rays[k * 7 + 1], rays[k * 7 + 2]), d = v3(rays[k * 7 + 3], rays[k * 7 + 4], rays[k * 7 + 5]);
-        set_space<fused_box<F>()>(L, o, d);
+        set_space<FUSED>(L, o, d);
         L.T = rays[k * 7 + 6];
         L.i = 0; L.end = 1; L.pend = 0;
-        GlobalMem M{&it, nullptr, nullptr, nullptr};
-        box_step_core<F, GlobalMem>(L, M);
+        typename std::conditional<FUSED, FusedMem, GlobalMem>::type M;
+        M.items = &it; M.spheres = nullptr; M.sphere_mat = nullptr; M.boxes = nullptr;
+        box_step_core<F, decltype(M)>(L, M);
         bool fast = L.pend != 0;
         bool exact = slab_exact(it, o, d, T_MIN, rays[k * 7 + 6]);
         // was the fallback taken?  the margin test exactly as box_step_core writes it
         float x0, x1, y0, y1, z0, z1;
-        if (fused_box<F>()) {
+        if (FUSED) {
             x0 = __builtin_fmaf(it.mnx, L.inv.x, -L.oi.x); x1 = __builtin_fmaf(it.mxx, L.inv.x, -L.oi.x);
             y0 = __builtin_fmaf(it.mny, L.inv.y, -L.oi.y); y1 = __builtin_fmaf(it.mxy, L.inv.y, -L.oi.y);
             z0 = __builtin_fmaf(it.mnz, L.inv.z, -L.oi.z); z1 = __builtin_fmaf(it.mxz, L.inv.z, -L.oi.z);
@@ -95,8 +101,8 @@ static const uint32_t FALL = VKF_ALL_SCENE;
 static const uint32_t FPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
 static void trace_any(const DScene &S, const GlobalMem &M, const RenderConsts &C, uint32_t integrator, uint32_t pixel, uint32_t sample, V3 &rgb, uint32_t &draws, uint64_t *steps) {
     bool lean = S.features == 0u && !getenv("VK_FORCE_FULL_VARIANT");
-    if (integrator == VK_INTEGRATOR_PDF) { if (lean) trace_one<VKF_INTEG_PDF>(S, M, C, pixel, sample, rgb, draws, steps); else trace_one<FPDF>(S, M, C, pixel, sample, rgb, draws, steps); }
-    else { if (lean) trace_one<0u>(S, M, C, pixel, sample, rgb, draws, steps); else trace_one<FALL>(S, M, C, pixel, sample, rgb, draws, steps); }
+    if (integrator == VK_INTEGRATOR_PDF) { if (lean) trace_one<VKF_INTEG_PDF, FusedMem>(S, M, C, pixel, sample, rgb, draws, steps); else trace_one<FPDF>(S, M, C, pixel, sample, rgb, draws, steps); }
+    else { if (lean) trace_one<0u, FusedMem>(S, M, C, pixel, sample, rgb, draws, steps); else trace_one<FALL>(S, M, C, pixel, sample, rgb, draws, steps); }
 }
 
 int emu_sample(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *p, uint32_t pixel, uint32_t sample,
@@ -176,8 +182,8 @@ int emu_render(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
 }
 
 void emu_box_decisions(const float *boxes, const float *rays, size_t n, uint8_t *decisions, int fused) {
-    if (fused) box_decisions<0u>(boxes, rays, n, decisions);
-    else box_decisions<VKF_ALL_SCENE>(boxes, rays, n, decisions);
+    if (fused) box_decisions<0u, true>(boxes, rays, n, decisions);
+    else box_decisions<VKF_ALL_SCENE, false>(boxes, rays, n, decisions);
 }
 
 }  // extern "C"

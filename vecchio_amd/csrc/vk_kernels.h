@@ -71,6 +71,7 @@ struct LdsMem {
     // the traversal cursor counts BYTES of these two arrays (16 per item; see GlobalMem::ISHIFT): the skip links of the staged
     // items are scaled to match when a workgroup copies them in (render_kernel)
     static constexpr uint32_t ISHIFT = 4;
+    static constexpr bool FUSED_BOX = true;      // see GlobalMem
     uint32_t items_hi_off;   // byte offset of items_hi in the workgroup's LDS
     __device__ __forceinline__ DItem item(uint32_t off) const {
         // Absolute LDS addresses: the staged scene starts at LDS address 0 (the kernels have no static LDS: pinned by
@@ -506,7 +507,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 if (fresh) {
                     KArgsC P = kargs_fresh();
                     DScene S = KARG(P, S);
-                    begin_segment<Mem::ISHIFT, fused_box<F>()>(L, S, io.o, io.d, io.time);      // (the callee stored the path state, new world ray included)
+                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, io.o, io.d, io.time);      // (the callee stored the path state, new world ray included)
                 }
             } else {
                 PhaseClocks clk;
@@ -515,7 +516,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 if (fresh) {
                     KArgsC P = kargs_fresh();
                     DScene S = KARG(P, S);
-                    begin_segment<Mem::ISHIFT, fused_box<F>()>(L, S, L.wo, L.wd, L.time);   // one copy of the exact reciprocals for both kinds of new ray
+                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, L.wo, L.wd, L.time);   // one copy of the exact reciprocals for both kinds of new ray
                 }
                 if (active && touched) cold_store_path<F>(cold, lane, L);
                 if (STATS) st_t_install += clock64() - st_t1;

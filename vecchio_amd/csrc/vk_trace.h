@@ -59,6 +59,9 @@ struct GlobalMem {
     // LDS-resident scene (vk_kernels.h LdsMem) counts in BYTES of its 16-byte-stride arrays, so that a box step needs no shift
     // to form its two ds_read addresses (the skip links are scaled once, when a workgroup stages the items).
     static constexpr uint32_t ISHIFT = 0;
+    // the fused box test (set_space) is for scenes traversed from LDS: from global memory a box step waits for its gather, not
+    // for the VALU, and the three extra registers are spills at the 64 VGPRs of the 8-waves-per-SIMD build
+    static constexpr bool FUSED_BOX = false;
     const DItem *items; const DSphere *spheres; const uint32_t *sphere_mat; const DBox *boxes;
     VK_HD DBox box(uint32_t i) const { return boxes[i]; }
     VK_HD DItem item(uint32_t i) const { return items[i]; }
@@ -90,7 +93,7 @@ VK_HD float nextafter_up(float t) { return (t > 0.0f && t < INFINITY) ? vk::bits
 // the other variants' (b - o) * (1/d).  Both are decided against the reference's fl(fl(b - o) / d) with a margin and fall
 // back to the reference's own division sequence inside it; the fused form needs three more registers per lane (o/d), which
 // only the sphere-only variants have to spare, and its margin carries a term in |o/d| (cancellation when b*(1/d) ~ o/d).
-template <uint32_t F> constexpr bool fused_box() { return (F & ~(uint32_t)VKF_INTEG_PDF) == 0u; }
+template <uint32_t F, class Mem> constexpr bool fused_box() { return (F & ~(uint32_t)VKF_INTEG_PDF) == 0u && Mem::FUSED_BOX; }
 
 template <bool FUSED = false>
 VK_HD void set_space(Lane &L, V3 o, V3 d) {
@@ -398,7 +401,7 @@ VK_HD void enter_instance(Lane &L, const DScene &S, uint32_t ref) {
     const DInstance &I = S.instances[idx];
     V3 o = L.o, d = L.d;
     for (uint32_t k = 0; k < I.n_ops; k++) apply_op(I.ops[k], o, d);
-    set_space<fused_box<F>()>(L, o, d);
+    set_space<fused_box<F, Mem>()>(L, o, d);
     L.cur_inst = idx;
     L.pend2 = 0;   // the home leaf's right object is restored from home_pend on leave
     if (I.child_end > I.child_begin) { L.i = I.child_begin << Mem::ISHIFT; L.end = I.child_end << Mem::ISHIFT; L.pend = 0; }
@@ -413,7 +416,7 @@ VK_HD void leave_instance(Lane &L, const DScene &S) {
     L.cur_inst = P;
     V3 o, d;
     ray_in_instance(S, P, L.wo, L.wd, o, d);
-    set_space<fused_box<F>()>(L, o, d);
+    set_space<fused_box<F, Mem>()>(L, o, d);
 }
 
 template <uint32_t F, class Mem>
@@ -501,7 +504,7 @@ VK_HD bool box_step_core(Lane &L, const Mem &M) {      // returns: a leaf's box 
     // -5 % as compiler vectors (the broadcast operands get materialised as register pairs), -14 % as inline asm
     // with op_sel broadcasts of (o.x,o.y)/(inv.x,inv.y)/(o.z,inv.z): the packed ops do not issue at twice the rate here)
     float x0, x1, y0, y1, z0, z1;
-    if constexpr (fused_box<F>()) {     // one fma per bound (set_space<true> explains the margin)
+    if constexpr (fused_box<F, Mem>()) {     // one fma per bound (set_space<true> explains the margin)
         x0 = __builtin_fmaf(n.mnx, L.inv.x, -L.oi.x); x1 = __builtin_fmaf(n.mxx, L.inv.x, -L.oi.x);
         y0 = __builtin_fmaf(n.mny, L.inv.y, -L.oi.y); y1 = __builtin_fmaf(n.mxy, L.inv.y, -L.oi.y);
         z0 = __builtin_fmaf(n.mnz, L.inv.z, -L.oi.z); z1 = __builtin_fmaf(n.mxz, L.inv.z, -L.oi.z);
@@ -537,7 +540,7 @@ template <uint32_t F, class Mem, int N>
 VK_HD void box_steps(Lane &L, const DScene &S, const Mem &M, bool go) {
     if (go) {
         bool queued = box_step_core<F, Mem>(L, M);      // (the mask is at hand: cheaper than comparing pend with 0 again)
-        if (N > 1) box_steps<F, Mem, (N > 1 ? N - 1 : 1)>(L, S, M, !queued && L.i < range_end<F, Mem>(L, S));
+        if (N > 1) box_steps<F, Mem, (N > 1 ? N - 1 : 1)>(L, S, M, (!queued) & (L.i < range_end<F, Mem>(L, S)));   // (&: one mask, one branch)
     }
 }
 
@@ -929,11 +932,11 @@ VK_HD void start_sample_core(Lane &L, const RenderConsts &C, uint32_t x, uint32_
     time = vk::gen_range(L.rng, C.cam.time0, C.cam.time1);
     L.thr = v3s(1.0f); L.acc = v3s(0.0f); L.depth = 1;
 }
-template <uint32_t F = VKF_ALL_SCENE>
+template <uint32_t F = VKF_ALL_SCENE, class Mem = GlobalMem>
 VK_HD void start_sample(Lane &L, const DScene &S, const RenderConsts &C, uint32_t x, uint32_t y, uint32_t sample) {
     V3 o, d; float time;
     start_sample_core(L, C, x, y, sample, o, d, time);
-    begin_segment<0, fused_box<F>()>(L, S, o, d, time);
+    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, o, d, time);
 }
 
 VK_HD V3 background_of(const RenderConsts &C, V3 ud) {       // ud = unit(ray direction), only read for the sky
@@ -1083,7 +1086,7 @@ template <uint32_t F, class Mem>
 VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) {
     V3 o, d; float time;
     if (!shade_core<F, Mem>(L, S, M, C, o, d, time)) return false;
-    begin_segment<Mem::ISHIFT, fused_box<F>()>(L, S, o, d, time);
+    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, o, d, time);
     return true;
 }
 
