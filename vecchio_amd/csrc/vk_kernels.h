@@ -435,13 +435,14 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
             if (STATS) st_t0 = clock64();
             const uint32_t live = n_box + n_heavy + n_light + n_sn;   // lanes only change state here, none appear or vanish
+            const unsigned long long m_act = __builtin_amdgcn_ballot_w64(active);
             // steps between two exit tests (compile time: a run-time trip count costs 4-13 %).  With shading deferred the
             // optimum is 3 for the sphere-only and Cornell-type variants (against 4: C2 +0.7 %, C4 +1.3 %; 2: -3 %, 6: -1 %,
             // 8: -6 %) and 4 for the everything-variants (C3: 3 -> -2 %)
             constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? BOX_UNROLL : BOX_UNROLL - 1;
             for (;;) {
                 if (F & VKF_INSTANCE) {     // end of an instance's item range: back to the parent space (rare)
-                    if (is_box && L.i >= L.end && L.cur_inst >= 0) { cold_load_world_ray<F>(cold, lane, L); leave_instance<F, Mem>(L, S); }
+                    if (active && !has_prim_work(L) && L.i >= L.end && L.cur_inst >= 0) { cold_load_world_ray<F>(cold, lane, L); leave_instance<F, Mem>(L, S); }
                 }
                 bool go = active && L.pend == 0u && L.i < range_end<F, Mem>(L, S);
                 if (STATS) {        // diagnostic build: same steps one at a time, counting the lanes in each
@@ -453,10 +454,15 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 } else {
                     box_steps<F, Mem, UNROLL>(L, S, M, go);
                 }
-                is_box = active && !has_prim_work(L) && traversing(L);
-                uint32_t nb = lanes_with(is_box);
-                uint32_t np = lanes_with(active && has_prim_work(L));
-                uint32_t ns = live - nb - np;
+                // exit test on wave-uniform counts.  The lane masks come straight out of the compares (uicmp = v_cmp into an SGPR
+                // pair) and are combined with scalar instructions: a ballot of a compound boolean goes through a VGPR (v_cndmask 0/1 +
+                // v_cmp_ne) for every term
+                const unsigned long long m_pend = __builtin_amdgcn_uicmp(L.pend, 0u, 33 /* ne */);
+                unsigned long long m_trav = __builtin_amdgcn_uicmp(L.i, range_end<F, Mem>(L, S), 36 /* ult */);
+                if (F & VKF_INSTANCE) m_trav |= __builtin_amdgcn_sicmp(L.cur_inst, 0, 39 /* sge */);
+                const unsigned long long m_prim = m_pend & m_act, m_box = m_trav & ~m_pend & m_act;
+                const uint32_t nb = (uint32_t)__builtin_popcountll(m_box), np = (uint32_t)__builtin_popcountll(m_prim);
+                const uint32_t ns = live - nb - np;
                 if (STATS && !HAS_HEAVY) { st_heavy_execs += live; st_t_light += np; st_t_heavy += ns; st_prim_execs += 1; }   // sphere-only diagnostic: lanes per exit test
                 if (nb == 0 || nb < np * prim_weight || nb * shade_defer < ns) {   // another state now has more lanes parked than are stepping
                     // when that state is a LIGHT primitive test (Sphere / MovingSphere / Rect: never draws, never changes the
@@ -466,7 +472,6 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     uint32_t nl = HAS_HEAVY ? lanes_with(light) : np;
                     if (nl != 0 && 2u * nl >= np && nl * shade_defer >= ns) {
                         if (light) prim_step<F, Mem>(L, S, M);
-                        is_box = active && !has_prim_work(L) && traversing(L);
                         continue;
                     }
                     break;
