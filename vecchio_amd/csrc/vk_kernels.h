@@ -436,10 +436,12 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             if (STATS) st_t0 = clock64();
             const uint32_t live = n_box + n_heavy + n_light + n_sn;   // lanes only change state here, none appear or vanish
             const unsigned long long m_act = __builtin_amdgcn_ballot_w64(active);
-            // steps between two exit tests (compile time: a run-time trip count costs 4-13 %).  With shading deferred the
-            // optimum is 3 for the sphere-only and Cornell-type variants (against 4: C2 +0.7 %, C4 +1.3 %; 2: -3 %, 6: -1 %,
-            // 8: -6 %) and 4 for the everything-variants (C3: 3 -> -2 %)
-            constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? BOX_UNROLL : BOX_UNROLL - 1;
+            // steps between two exit tests (compile time: a run-time trip count costs 4-13 %).  With shading deferred the optimum is 3
+            // for scenes traversed from LDS (C2: 2 -> -4 %, 4 -> -0.5 %; C4 the same), 4 for sphere-only scenes traversed from global
+            // memory (C5: 3 / 4 / 5 / 7 -> 706 / 724 / 722 / 703 Msamples/s) and 5 for the everything-variants (C3: 4 / 5 / 6 / 8 ->
+            // 617 / 627 / 622 / 616): the longer a step waits for its item, the less an exit test per step group is worth
+            constexpr bool SPHERES = (F & ~(uint32_t)VKF_INTEG_PDF) == 0u;
+            constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? BOX_UNROLL + 1 : ((SPHERES && !LDS_SCENE) ? BOX_UNROLL : BOX_UNROLL - 1);
             for (;;) {
                 if (F & VKF_INSTANCE) {     // end of an instance's item range: back to the parent space (rare)
                     if (active && !has_prim_work(L) && L.i >= L.end && L.cur_inst >= 0) { cold_load_world_ray<F>(cold, lane, L); leave_instance<F, Mem>(L, S); }
@@ -469,7 +471,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     // space), run it right here and keep stepping: saves the scheduler round trip that otherwise follows every
                     // ~10 box steps
                     bool light = active && has_prim_work(L) && !(HAS_HEAVY && prim_is_heavy(L.pend));
-                    uint32_t nl = HAS_HEAVY ? lanes_with(light) : np;
+                    uint32_t nl = HAS_HEAVY ? (uint32_t)__builtin_popcountll(m_prim & ~__builtin_amdgcn_uicmp(L.pend, (uint32_t)DK_LIST << 28, 35 /* uge: prim_is_heavy */)) : np;
                     if (nl != 0 && 2u * nl >= np && nl * shade_defer >= ns) {
                         if (light) prim_step<F, Mem>(L, S, M);
                         continue;
