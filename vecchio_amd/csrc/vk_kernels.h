@@ -466,13 +466,16 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 const uint32_t nb = (uint32_t)__builtin_popcountll(m_box), np = (uint32_t)__builtin_popcountll(m_prim);
                 const uint32_t ns = live - nb - np;
                 if (STATS && !HAS_HEAVY) { st_heavy_execs += live; st_t_light += np; st_t_heavy += ns; st_prim_execs += 1; }   // sphere-only diagnostic: lanes per exit test
-                if (nb == 0 || nb < np * prim_weight || nb * shade_defer < ns) {   // another state now has more lanes parked than are stepping
+                // keep stepping while nb != 0, nb >= np * prim_weight and nb * shade_defer >= ns: as sign tests of differences (the
+                // counts are < 2^7), which is a third of the scalar instructions of three compares or-ed together
+                const int keep1 = (int)nb - (int)(np * prim_weight > 1u ? np * prim_weight : 1u), keep2 = (int)(nb * shade_defer) - (int)ns;
+                if ((keep1 | keep2) < 0) {   // another state now has more lanes parked than are stepping
                     // when that state is a LIGHT primitive test (Sphere / MovingSphere / Rect: never draws, never changes the
                     // space), run it right here and keep stepping: saves the scheduler round trip that otherwise follows every
                     // ~10 box steps
                     bool light = active && has_prim_work(L) && !(HAS_HEAVY && prim_is_heavy(L.pend));
                     uint32_t nl = HAS_HEAVY ? (uint32_t)__builtin_popcountll(m_prim & ~__builtin_amdgcn_uicmp(L.pend, (uint32_t)DK_LIST << 28, 35 /* uge: prim_is_heavy */)) : np;
-                    if (nl != 0 && 2u * nl >= np && nl * shade_defer >= ns) {
+                    if ((((int)nl - 1) | ((int)(2u * nl) - (int)np) | ((int)(nl * shade_defer) - (int)ns)) >= 0) {   // nl != 0, 2 nl >= np, nl * shade_defer >= ns
                         if (light) prim_step<F, Mem>(L, S, M);
                         continue;
                     }
