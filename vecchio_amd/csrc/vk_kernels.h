@@ -442,11 +442,17 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             // 617 / 627 / 622 / 616): the longer a step waits for its item, the less an exit test per step group is worth
             constexpr bool SPHERES = (F & ~(uint32_t)VKF_INTEG_PDF) == 0u;
             constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? BOX_UNROLL + 1 : ((SPHERES && !LDS_SCENE) ? BOX_UNROLL : BOX_UNROLL - 1);
+            // scenes without instances: the stepping lanes are the box lanes of the last exit test, whose mask is at hand in SGPRs
+            // (inverse ballot = the lane predicate of a mask, free); with instances a lane may first have to leave its instance
+            constexpr bool MASK_GO = (F & VKF_INSTANCE) == 0u && !STATS;
+            unsigned long long m_go = MASK_GO ? (m_act & ~__builtin_amdgcn_uicmp(L.pend, 0u, 33) & __builtin_amdgcn_uicmp(L.i, range_end<F, Mem>(L, S), 36)) : 0ull;
             for (;;) {
                 if (F & VKF_INSTANCE) {     // end of an instance's item range: back to the parent space (rare)
                     if (active && !has_prim_work(L) && L.i >= L.end && L.cur_inst >= 0) { cold_load_world_ray<F>(cold, lane, L); leave_instance<F, Mem>(L, S); }
                 }
-                bool go = active && L.pend == 0u && L.i < range_end<F, Mem>(L, S);
+                bool go;
+                if constexpr (MASK_GO) go = __builtin_amdgcn_inverse_ballot_w64(m_go);
+                else go = active && L.pend == 0u && L.i < range_end<F, Mem>(L, S);
                 if (STATS) {        // diagnostic build: same steps one at a time, counting the lanes in each
                     for (int u = 0; u < UNROLL; u++) {
                         st_box_steps += 1; st_box_lanes += lanes_with(go);
@@ -465,6 +471,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 const unsigned long long m_prim = m_pend & m_act, m_box = m_trav & ~m_pend & m_act;
                 const uint32_t nb = (uint32_t)__builtin_popcountll(m_box), np = (uint32_t)__builtin_popcountll(m_prim);
                 const uint32_t ns = live - nb - np;
+                if (MASK_GO) m_go = m_box;
                 if (STATS && !HAS_HEAVY) { st_heavy_execs += live; st_t_light += np; st_t_heavy += ns; st_prim_execs += 1; }   // sphere-only diagnostic: lanes per exit test
                 // keep stepping while nb != 0, nb >= np * prim_weight and nb * shade_defer >= ns: as sign tests of differences (the
                 // counts are < 2^7), which is a third of the scalar instructions of three compares or-ed together
@@ -473,10 +480,13 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     // when that state is a LIGHT primitive test (Sphere / MovingSphere / Rect: never draws, never changes the
                     // space), run it right here and keep stepping: saves the scheduler round trip that otherwise follows every
                     // ~10 box steps
-                    bool light = active && has_prim_work(L) && !(HAS_HEAVY && prim_is_heavy(L.pend));
+                    bool light;
+                    if constexpr (!HAS_HEAVY) light = __builtin_amdgcn_inverse_ballot_w64(m_prim);
+                    else light = active && has_prim_work(L) && !prim_is_heavy(L.pend);
                     uint32_t nl = HAS_HEAVY ? (uint32_t)__builtin_popcountll(m_prim & ~__builtin_amdgcn_uicmp(L.pend, (uint32_t)DK_LIST << 28, 35 /* uge: prim_is_heavy */)) : np;
                     if ((((int)nl - 1) | ((int)(2u * nl) - (int)np) | ((int)(nl * shade_defer) - (int)ns)) >= 0) {   // nl != 0, 2 nl >= np, nl * shade_defer >= ns
                         if (light) prim_step<F, Mem>(L, S, M);
+                        if (MASK_GO) m_go = m_act & ~__builtin_amdgcn_uicmp(L.pend, 0u, 33) & __builtin_amdgcn_uicmp(L.i, range_end<F, Mem>(L, S), 36);
                         continue;
                     }
                     break;
