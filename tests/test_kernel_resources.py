@@ -64,7 +64,7 @@ def test_cornell_variant_does_not_spill(built):
             continue
         # (0 / 0 until the SHADE + REFILL phase became a function of its own: 16 B / 7 instructions, all in that phase)
         # 96 VGPRs = five waves per SIMD (20 per CU)
-        assert key[2] == 5 and r["occupancy"] >= 5 and r["scratch"] <= 16 and r["scratch_ops"] <= 8 and r["vgprs"] <= 96, (key, r)
+        assert key[2] == 5 and r["occupancy"] >= 5 and r["scratch"] <= 16 and r["scratch_ops"] <= 12 and r["vgprs"] <= 96, (key, r)
 
 
 def test_full_variant_budget(built):

@@ -442,17 +442,26 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             // 617 / 627 / 622 / 616): the longer a step waits for its item, the less an exit test per step group is worth
             constexpr bool SPHERES = (F & ~(uint32_t)VKF_INTEG_PDF) == 0u;
             constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? BOX_UNROLL + 1 : ((SPHERES && !LDS_SCENE) ? BOX_UNROLL : BOX_UNROLL - 1);
-            // scenes without instances: the stepping lanes are the box lanes of the last exit test, whose mask is at hand in SGPRs
-            // (inverse ballot = the lane predicate of a mask, free); with instances a lane may first have to leave its instance
-            constexpr bool MASK_GO = (F & VKF_INSTANCE) == 0u && !STATS;
-            unsigned long long m_go = MASK_GO ? (m_act & ~__builtin_amdgcn_uicmp(L.pend, 0u, 33) & __builtin_amdgcn_uicmp(L.i, range_end<F, Mem>(L, S), 36)) : 0ull;
+            // The lane masks of the states come straight out of compares (uicmp = v_cmp into an SGPR pair) and are combined and
+            // counted with scalar instructions; a ballot of a compound lane boolean goes through a VGPR (v_cndmask 0/1 + v_cmp_ne)
+            // for every term.  The lanes that step are the box lanes of the last exit test: their mask is at hand in SGPRs and
+            // the inverse ballot — the lane predicate of a mask — is free.
+            unsigned long long m_pend, m_lt, m_inst = 0ull;
+            auto masks = [&]() {
+                m_pend = __builtin_amdgcn_uicmp(L.pend, 0u, 33 /* ne */);
+                m_lt = __builtin_amdgcn_uicmp(L.i, range_end<F, Mem>(L, S), 36 /* ult */);
+                if (F & VKF_INSTANCE) m_inst = __builtin_amdgcn_sicmp(L.cur_inst, 0, 39 /* sge */);
+            };
+            masks();
             for (;;) {
                 if (F & VKF_INSTANCE) {     // end of an instance's item range: back to the parent space (rare)
-                    if (active && !has_prim_work(L) && L.i >= L.end && L.cur_inst >= 0) { cold_load_world_ray<F>(cold, lane, L); leave_instance<F, Mem>(L, S); }
+                    const unsigned long long m_leave = m_act & ~m_pend & ~m_lt & m_inst;
+                    if (m_leave != 0ull) {
+                        if (__builtin_amdgcn_inverse_ballot_w64(m_leave)) { cold_load_world_ray<F>(cold, lane, L); leave_instance<F, Mem>(L, S); }
+                        masks();
+                    }
                 }
-                bool go;
-                if constexpr (MASK_GO) go = __builtin_amdgcn_inverse_ballot_w64(m_go);
-                else go = active && L.pend == 0u && L.i < range_end<F, Mem>(L, S);
+                bool go = __builtin_amdgcn_inverse_ballot_w64(m_act & ~m_pend & m_lt);
                 if (STATS) {        // diagnostic build: same steps one at a time, counting the lanes in each
                     for (int u = 0; u < UNROLL; u++) {
                         st_box_steps += 1; st_box_lanes += lanes_with(go);
@@ -462,16 +471,11 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 } else {
                     box_steps<F, Mem, UNROLL>(L, S, M, go);
                 }
-                // exit test on wave-uniform counts.  The lane masks come straight out of the compares (uicmp = v_cmp into an SGPR
-                // pair) and are combined with scalar instructions: a ballot of a compound boolean goes through a VGPR (v_cndmask 0/1 +
-                // v_cmp_ne) for every term
-                const unsigned long long m_pend = __builtin_amdgcn_uicmp(L.pend, 0u, 33 /* ne */);
-                unsigned long long m_trav = __builtin_amdgcn_uicmp(L.i, range_end<F, Mem>(L, S), 36 /* ult */);
-                if (F & VKF_INSTANCE) m_trav |= __builtin_amdgcn_sicmp(L.cur_inst, 0, 39 /* sge */);
-                const unsigned long long m_prim = m_pend & m_act, m_box = m_trav & ~m_pend & m_act;
+                // exit test on wave-uniform counts
+                masks();
+                const unsigned long long m_prim = m_pend & m_act, m_box = (m_lt | m_inst) & ~m_pend & m_act;
                 const uint32_t nb = (uint32_t)__builtin_popcountll(m_box), np = (uint32_t)__builtin_popcountll(m_prim);
                 const uint32_t ns = live - nb - np;
-                if (MASK_GO) m_go = m_box;
                 if (STATS && !HAS_HEAVY) { st_heavy_execs += live; st_t_light += np; st_t_heavy += ns; st_prim_execs += 1; }   // sphere-only diagnostic: lanes per exit test
                 // keep stepping while nb != 0, nb >= np * prim_weight and nb * shade_defer >= ns: as sign tests of differences (the
                 // counts are < 2^7), which is a third of the scalar instructions of three compares or-ed together
@@ -480,13 +484,11 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     // when that state is a LIGHT primitive test (Sphere / MovingSphere / Rect: never draws, never changes the
                     // space), run it right here and keep stepping: saves the scheduler round trip that otherwise follows every
                     // ~10 box steps
-                    bool light;
-                    if constexpr (!HAS_HEAVY) light = __builtin_amdgcn_inverse_ballot_w64(m_prim);
-                    else light = active && has_prim_work(L) && !prim_is_heavy(L.pend);
-                    uint32_t nl = HAS_HEAVY ? (uint32_t)__builtin_popcountll(m_prim & ~__builtin_amdgcn_uicmp(L.pend, (uint32_t)DK_LIST << 28, 35 /* uge: prim_is_heavy */)) : np;
+                    const unsigned long long m_light = HAS_HEAVY ? (m_prim & ~__builtin_amdgcn_uicmp(L.pend, (uint32_t)DK_LIST << 28, 35 /* uge: prim_is_heavy */)) : m_prim;
+                    const uint32_t nl = (uint32_t)__builtin_popcountll(m_light);
                     if ((((int)nl - 1) | ((int)(2u * nl) - (int)np) | ((int)(nl * shade_defer) - (int)ns)) >= 0) {   // nl != 0, 2 nl >= np, nl * shade_defer >= ns
-                        if (light) prim_step<F, Mem>(L, S, M);
-                        if (MASK_GO) m_go = m_act & ~__builtin_amdgcn_uicmp(L.pend, 0u, 33) & __builtin_amdgcn_uicmp(L.i, range_end<F, Mem>(L, S), 36);
+                        if (__builtin_amdgcn_inverse_ballot_w64(m_light)) prim_step<F, Mem>(L, S, M);
+                        masks();
                         continue;
                     }
                     break;
