@@ -412,20 +412,23 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
     // C5: no gain there, -1.7 % on C2, and the two extra live scalars doubled the everything-variant's spills)
     uint32_t shade_defer, prim_weight;
     { KArgsC U = kargs_fresh(); shade_defer = KARG(U, shade_defer); prim_weight = KARG(U, prim_weight); }
+    // lanes holding a path / wanting a sample, as wave masks: both only change in the SHADE + REFILL phase
+    unsigned long long m_act = 0ull, m_need = ~0ull;
     for (;;) {
-        bool is_prim = active && has_prim_work(L);
-        bool is_box = active && !is_prim && traversing(L);
-        bool is_shade = active && !is_prim && !is_box;
+        // the lane masks of the four states from compares, combined and counted with scalar instructions (see the BOX loop)
         // primitives come in two weights (sphere/rect ~50 instructions; Boxy, list, medium, instance
         // entry several times that): scheduled separately so cheap tests never pay for heavy ones
         const bool HAS_HEAVY = (F & (VKF_LIST | VKF_MEDIUM | VKF_INSTANCE | VKF_BOX)) != 0;
-        bool is_heavy = HAS_HEAVY && is_prim && prim_is_heavy(L.pend);
-        uint32_t n_box = lanes_with(is_box);
-        uint32_t n_heavy = HAS_HEAVY ? lanes_with(is_heavy) : 0u;
-        uint32_t n_light = lanes_with(is_prim && !is_heavy);
-        if (n_heavy > n_light) { is_prim = is_heavy; } else { is_prim = is_prim && !is_heavy; }
-        uint32_t n_prim = n_heavy > n_light ? n_heavy : n_light;
-        uint32_t n_sn = lanes_with(is_shade || need);
+        const unsigned long long m_pend0 = __builtin_amdgcn_uicmp(L.pend, 0u, 33 /* ne */) & m_act;
+        unsigned long long m_trav = __builtin_amdgcn_uicmp(L.i, L.end, 36 /* ult */);
+        if (F & VKF_INSTANCE) m_trav |= __builtin_amdgcn_sicmp(L.cur_inst, 0, 39 /* sge */);
+        const unsigned long long m_heavy = HAS_HEAVY ? (__builtin_amdgcn_uicmp(L.pend, (uint32_t)DK_LIST << 28, 35 /* uge: prim_is_heavy */) & m_pend0) : 0ull;
+        const unsigned long long m_light = m_pend0 & ~m_heavy;
+        const unsigned long long m_shade = m_act & ~m_pend0 & ~m_trav;
+        const uint32_t n_box = (uint32_t)__builtin_popcountll(m_act & ~m_pend0 & m_trav);
+        const uint32_t n_heavy = (uint32_t)__builtin_popcountll(m_heavy), n_light = (uint32_t)__builtin_popcountll(m_light);
+        const uint32_t n_prim = n_heavy > n_light ? n_heavy : n_light;
+        const uint32_t n_sn = (uint32_t)__builtin_popcountll(m_shade | m_need);
         if ((n_box | n_prim | n_sn) == 0) break;
         if (STATS) st_sched++;
         if (n_box >= n_prim * prim_weight && n_box * shade_defer >= n_sn) {
@@ -435,7 +438,6 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
             if (STATS) st_t0 = clock64();
             const uint32_t live = n_box + n_heavy + n_light + n_sn;   // lanes only change state here, none appear or vanish
-            const unsigned long long m_act = __builtin_amdgcn_ballot_w64(active);
             // steps between two exit tests (compile time: a run-time trip count costs 4-13 %).  With shading deferred the optimum is 3
             // for scenes traversed from LDS (C2: 2 -> -4 %, 4 -> -0.5 %; C4 the same), 4 for sphere-only scenes traversed from global
             // memory (C5: 3 / 4 / 5 / 7 -> 706 / 724 / 722 / 703 Msamples/s) and 5 for the everything-variants (C3: 4 / 5 / 6 / 8 ->
@@ -501,7 +503,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             DScene S = KARG(P, S);
             Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
             if (STATS) { st_prim_execs++; st_prim_lanes += n_prim; st_t0 = clock64(); if (n_heavy > n_light) st_heavy_execs++; }
-            if (is_prim) {
+            if (__builtin_amdgcn_inverse_ballot_w64(n_heavy > n_light ? m_heavy : m_light)) {
                 if (F & VKF_MEDIUM) {    // ConstantMedium::hit draws inside traversal (hittable.rs:473)
                     L.rng.key = (uint64_t)__float_as_uint(cold[CF_KEY * 64 + lane]) | ((uint64_t)__float_as_uint(cold[(CF_KEY + 1) * 64 + lane]) << 32);
                     L.rng.ctr = __float_as_uint(cold[CF_CTR * 64 + lane]);
@@ -517,6 +519,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             // ... and for the 8-waves-per-SIMD build of the sphere-only variants (scenes traversed from global memory: every box step a
             // dependent gather, so more waves in flight pay — C5 629 -> 685 Msamples/s — and 64 VGPRs hold the traversal loops but not shading)
             constexpr bool SPLIT = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE || MINW == 8) && !STATS;
+            const bool is_shade = __builtin_amdgcn_inverse_ballot_w64(m_shade);
             bool touched = false, fresh = false;
             if constexpr (SPLIT) {
                 ShadeIo io;
@@ -543,6 +546,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 if (active && touched) cold_store_path<F>(cold, lane, L);
                 if (STATS) st_t_install += clock64() - st_t1;
             }
+            m_act = __builtin_amdgcn_ballot_w64(active); m_need = __builtin_amdgcn_ballot_w64(need);
             if (STATS) st_t_shade += clock64() - st_t0;
         }
     }
