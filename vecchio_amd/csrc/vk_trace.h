@@ -481,16 +481,14 @@ VK_HD bool prim_is_heavy(uint32_t ref) { uint32_t k = VKD_KIND(ref); return k >=
 // objects or reaches the end of its range drops out of the mask and costs nothing more, and the
 // bookkeeping is a handful of VALU selects (a fully predicated version that kept all 64 lanes in
 // EXEC and re-did item 0 on idle lanes spent 14 of its 45 VALU instructions on selects).
-// fminf(a, t) for the loop-carried tmax: fminf() makes the compiler re-quiet `t` with a v_max_f32 t, t in every box step (it cannot
-// see through the loop that t is never a signalling NaN); v_min_f32 itself returns the same value for every a and every non-NaN t
+// fminf(a, t) for the loop-carried tmax t (positive, possibly +inf, never NaN), as a SIGNED INTEGER minimum of the bit patterns:
+// fminf() makes the compiler re-quiet `t` with a v_max_f32 t, t in every box step (it cannot see through the loop that t is
+// never a signalling NaN).  For t > 0 the integer order is the float order whenever a >= 0; a negative a (sign bit set) is
+// the smaller one in both orders; a = +NaN (> +inf as an integer) yields t like fminf.  (a = -NaN would come through, where
+// fminf gives t: then both bounds of the axis were NaN and the step takes the exact path whatever this returns.)
 VK_HD float min_with_tmax(float a, float t) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(t));
-    return r;
-#else
-    return fminf(a, t);
-#endif
+    int32_t ia = (int32_t)vk::f32_bits(a), it = (int32_t)vk::f32_bits(t);
+    return vk::bits_f32((uint32_t)(ia < it ? ia : it));
 }
 
 template <uint32_t F, class Mem>
