@@ -181,6 +181,10 @@ int emu_render(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
     return VK_OK;
 }
 
+// the box step's clamp against the loop-carried tmax (vk_trace.h min_with_tmax): out[i] = min_with_tmax(a[i], t[i])
+void emu_min_with_tmax(const float *a, const float *t, size_t n, float *out) {
+    for (size_t k = 0; k < n; k++) out[k] = min_with_tmax(a[k], t[k]);
+}
 void emu_box_decisions(const float *boxes, const float *rays, size_t n, uint8_t *decisions, int fused) {
     if (fused) box_decisions<0u, true>(boxes, rays, n, decisions);
     else box_decisions<VKF_ALL_SCENE, false>(boxes, rays, n, decisions);

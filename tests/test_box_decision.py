@@ -78,3 +78,25 @@ def test_always_hit_leaf_boxes(emu, fused):
     dec = decide(emu, boxes, np.concatenate([o, d, tmax[:, None]], 1), fused)
     assert ((dec & 1) == ((dec >> 1) & 1)).all()
     assert (dec & 1).all()
+
+
+def test_tmax_clamp_is_fminf_for_every_tmax_the_walk_can_hold(emu):
+    """min_with_tmax (a signed-integer minimum of the bit patterns) against fminf, for tmax > 0 or +inf (never NaN: it starts at
+    +inf and only ever takes accepted hit distances) and every kind of a: +-0, +-inf, denormals, negative, +NaN.  (-NaN is the one
+    documented difference: it only arises when both bounds of an axis are NaN, i.e. on rays that take the exact test anyway.)"""
+    lib = emu.load()
+    lib.emu_min_with_tmax.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    rng = np.random.default_rng(11)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, 1e-45, -1e-45, 1e-38, -1e-38, 3.4e38, -3.4e38, 0.001, 1.0, np.nan], np.float32)
+    a = np.concatenate([special.repeat(64), rng.normal(size=200_000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 200_000).astype(np.float32),
+                        rng.integers(0, 2**32, 200_000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    keep = ~(np.isnan(a) & (a.view(np.uint32) >> 31 == 1))          # drop -NaN bit patterns
+    a = np.ascontiguousarray(a[keep])
+    t = np.abs(rng.normal(size=len(a)).astype(np.float32)) * np.float32(10.0) ** rng.integers(-20, 20, len(a)).astype(np.float32)
+    t[rng.uniform(size=len(a)) < 0.2] = np.inf
+    t[t == 0] = np.float32(0.001)
+    t = np.ascontiguousarray(t, np.float32)
+    out = np.empty_like(a)
+    lib.emu_min_with_tmax(a.ctypes.data, t.ctypes.data, len(a), out.ctypes.data)
+    want = np.fmin(a, t)                                            # fminf: NaN operands are dropped
+    assert (out.view(np.uint32) == want.view(np.uint32)).all()

@@ -443,7 +443,10 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             // memory (C5: 3 / 4 / 5 / 7 -> 706 / 724 / 722 / 703 Msamples/s) and 5 for the everything-variants (C3: 4 / 5 / 6 / 8 ->
             // 617 / 627 / 622 / 616): the longer a step waits for its item, the less an exit test per step group is worth
             constexpr bool SPHERES = (F & ~(uint32_t)VKF_INTEG_PDF) == 0u;
-            constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? BOX_UNROLL + 1 : ((SPHERES && !LDS_SCENE) ? BOX_UNROLL : BOX_UNROLL - 1);
+#ifndef VK_CORNELL_UNROLL
+#define VK_CORNELL_UNROLL 3
+#endif
+            constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? BOX_UNROLL + 1 : (SPHERES ? (LDS_SCENE ? BOX_UNROLL - 1 : BOX_UNROLL) : VK_CORNELL_UNROLL);
             // The lane masks of the states come straight out of compares (uicmp = v_cmp into an SGPR pair) and are combined and
             // counted with scalar instructions; a ballot of a compound lane boolean goes through a VGPR (v_cndmask 0/1 + v_cmp_ne)
             // for every term.  The lanes that step are the box lanes of the last exit test: their mask is at hand in SGPRs and
