@@ -315,7 +315,7 @@ VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time) {
     // and no sphere: Sphere::hit's discriminant is NaN (hittable.rs:66-70).  The reference walks its whole tree for such a ray
     // and returns None; in a scene of spheres only (nothing draws during traversal) the walk has no other effect, so it is
     // skipped.  They come from Dielectric::scatter's refract() just past the critical angle (sqrt of a rounding-negative
-    // number, util.rs:18-23), about one sample in 10^7 — each cost a full 1 M-item walk on the stress scene: a 1.7 s tail on
+    // number, util.rs:18-23), 3 samples in 10^4 on the stress scene — each cost a full 1 M-item walk on the stress scene: a 1.7 s tail on
     // EVERY frame, whatever its length.
     if (S.features == 0u) {
         bool dead = !(L.a < INFINITY) || !(fabsf(o.x) + fabsf(o.y) + fabsf(o.z) < INFINITY);
