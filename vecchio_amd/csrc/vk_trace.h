@@ -202,12 +202,14 @@ VK_HD V3 moving_center(const DMoving &m, float time) {  // hittable.rs:147-150
 VK_HD bool rect_t(const DRect &q, V3 o, V3 d, float tmin, float tmax, float &t_out) {
     uint32_t a0 = q.axes & 3u, a1 = (q.axes >> 2) & 3u, a2 = (q.axes >> 4) & 3u;
     float t = (q.k - comp(o, a2)) / comp(d, a2);
-    if (t < tmin || t > tmax) return false;
     float a = comp(o, a0) + t * comp(d, a0);
     float b = comp(o, a1) + t * comp(d, a1);
-    if (a < q.c0 || a > q.c1 || b < q.d0 || b > q.d1) return false;
-    t_out = t;
-    return true;
+    // one predicate instead of two early returns (the same comparisons, NaN behaviour included: a NaN fails none of the
+    // reference's `<` / `>` rejections): on a wave some lane passes the first test nearly always, so the early return saved
+    // nothing but cost an EXEC region each
+    bool ok = !(t < tmin) & !(t > tmax) & !(a < q.c0) & !(a > q.c1) & !(b < q.d0) & !(b > q.d1);
+    if (ok) t_out = t;
+    return ok;
 }
 // Sphere / MovingSphere / Rect by dref
 template <class Mem>
@@ -240,11 +242,11 @@ VK_HD bool list_t(const DScene &S, const Mem &M, uint32_t list_ref, V3 o, V3 d, 
 template <int A0, int A1, int A2>
 VK_HD void box_face(float k, float c0, float c1, float d0, float d1, V3 o, V3 d, float tmin, float &closest, uint32_t f, uint32_t &face, bool &found) {
     float t = (k - comp(o, A2)) / comp(d, A2);
-    if (t < tmin || t > closest) return;
     float a = comp(o, A0) + t * comp(d, A0);
     float b = comp(o, A1) + t * comp(d, A1);
-    if (a < c0 || a > c1 || b < d0 || b > d1) return;
-    if (t < closest) { closest = t; face = f; found = true; }
+    // Rect::hit's rejections and the list's strict `rec.t < closest` as one predicate (see rect_t)
+    bool ok = !(t < tmin) & !(t > closest) & !(a < c0) & !(a > c1) & !(b < d0) & !(b > d1) & (t < closest);
+    closest = ok ? t : closest; face = ok ? f : face; found = found | ok;
 }
 VK_HD bool box_t(const DBox &B, V3 o, V3 d, float tmin, float tmax, float &t, uint32_t &face) {
     float closest = tmax;
