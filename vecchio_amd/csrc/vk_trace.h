@@ -521,8 +521,19 @@ VK_HD bool box_step_core(Lane &L, const Mem &M) {      // returns: a leaf's box 
     // number.  `>=` so that hi = +inf (always-hit leaves while T is still infinite) stays on the fast path.
     float dlt = hi - lo;
     bool h = dlt > 0.0f;
-    if (!(fabsf(dlt) >= __builtin_fmaf(hi, 2.0e-6f, L.xnan)))
+    const float margin = __builtin_fmaf(hi, 2.0e-6f, L.xnan);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // One lane in a hundred thousand gets here: the wave asks first whether ANY of its lanes does (the compare's lane mask,
+    // one scalar branch) and only then opens an EXEC region — which otherwise costs three scalar instructions in every step.
+    // (The empty asm keeps the compiler from folding the two tests back into one region.)
+    if (__builtin_amdgcn_fcmpf(fabsf(dlt), margin, 12 /* unordered or less than: !(a >= b) */) != 0ull) {
+        asm volatile("");
+        if (!(fabsf(dlt) >= margin)) h = slab_exact(n, L.o, L.d, T_MIN, L.T);
+    }
+#else
+    if (!(fabsf(dlt) >= margin))
         h = slab_exact(n, L.o, L.d, T_MIN, L.T);         // within rounding distance: the reference's divisions
+#endif
     bool inner = (n.w0 >> 28) == 0u;
     bool leaf_hit = h && !inner;
     L.i = (inner && !h) ? n.w0 : L.i + (1u << Mem::ISHIFT);   // inner: hit -> left subtree, miss -> skip link (in cursor units)
