@@ -35,7 +35,7 @@ def test_resource_file_lists_every_variant(built):
     feats = {k[0] for k in v}
     assert {0, F_PDF, F_CORNELL | F_PDF, 0x17F, 0x17F | F_PDF} <= feats, sorted(feats)
     for f in feats:
-        minw = 6 if f in (0, F_PDF) else (5 if f & ~F_PDF == F_CORNELL else 4)
+        minw = 5 if f & ~F_PDF == F_CORNELL else 6
         assert (f, True, minw, False) in v                               # LDS-resident scene
         assert (f, False, 8 if f in (0, F_PDF) else minw, False) in v    # global-memory scene (sphere-only: 8 waves/SIMD, shading out of line)
 
@@ -71,15 +71,17 @@ def test_full_variant_budget(built):
     for key, r in variants().items():
         if key[0] & ~F_PDF not in (0x17F, 0x17F & ~F_PDF):
             continue
-        assert r["occupancy"] >= 4 and not r["dynamic_stack"], (key, r)
+        assert not r["dynamic_stack"], (key, r)
         if key[3]:
-            continue        # STATS builds keep the phase inline (diagnostics only)
-        # The everything-variants call the SHADE + REFILL phase out of line (vk_kernels.h shade_refill_call): the kernel's own code
-        # — the box and primitive loops — must stay free of spills (2 scratch instructions when written; inline, the allocator left
-        # 91..290 of them there and C3 moved between 330 and 520 Msamples/s with their placement).  ScratchSize is the callee's
-        # frame: its saved registers and its own spills (240 B when written).
-        assert 0 <= r["scratch_ops"] <= 8, (key, r)
-        assert r["scratch"] <= 288, (key, r)
+            assert r["occupancy"] >= 4, (key, r)
+            continue        # STATS builds keep the phase inline and 128 VGPRs (diagnostics only)
+        # The everything-variants call the SHADE + REFILL phase out of line (vk_kernels.h shade_refill_call) and are held to 80
+        # VGPRs = six waves per SIMD: they wait for memory, so occupancy is worth more than the 13 registers that spill (C3: 4 / 5
+        # / 6 / 7 waves per SIMD -> 642 / 695 / 726 / 695 Msamples/s; 25 scratch instructions in the kernel's own code when written,
+        # 154 at seven).  ScratchSize is mostly the callee's frame: its saved registers and its own spills.
+        assert key[2] == 6 and r["occupancy"] >= 6 and r["vgprs"] <= 80, (key, r)
+        assert 0 <= r["scratch_ops"] <= 40, (key, r)
+        assert r["scratch"] <= 320, (key, r)
 
 
 def test_no_static_lds(built):

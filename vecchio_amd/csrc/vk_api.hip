@@ -183,14 +183,14 @@ size_t per_wave_lds_bytes(uint32_t F) {   // cold lane state of one wave + its t
 // 4.06 vs 3.77 Gsamples/s at 24 waves/CU; C4: no difference), while occupancy is worth much more (C3: the
 // 118 KB scene in LDS leaves 11 waves/CU = 371 Msamples/s; from L2 at 16 waves/CU = 503).  So the scene is
 // staged in LDS only when that costs no waves: choose the workgroup size (waves share one LDS copy) and
-// workgroups per CU that reach the variant's full occupancy (24 waves/CU at 80 VGPRs, 16 at 128) with the
+// workgroups per CU that reach the variant's full occupancy (24 waves/CU at 80 VGPRs, 20 at 96) with the
 // scene resident, else traverse from global memory at full occupancy.
 void plan_residency(vk_scene *s, size_t hot) {
     const size_t pw = per_wave_lds_bytes(pick_variant(s));
     uint32_t best_waves = 0, best_wg = 0, best_n = 0;
     const bool spheres_only = pick_variant(s) == 0u;
     const bool cornell = pick_variant(s) == (VKF_RECT | VKF_LIST | VKF_INSTANCE | VKF_BOX);
-    const uint32_t per_simd = spheres_only ? s->sphere_waves : 5u;   // = MINW of launch_variant
+    const uint32_t per_simd = spheres_only ? s->sphere_waves : (cornell ? 5u : 6u);   // = MINW of launch_variant
     uint32_t cap = 4 * per_simd;                                             // waves per CU the variant's register budget admits
     // (five per SIMD only come about with workgroups of 4 waves, one per SIMD: two 10-wave workgroups land 3+3+2+2 and the second
     // one does not fit beside the first)
@@ -206,15 +206,18 @@ void plan_residency(vk_scene *s, size_t hot) {
     if (best_waves >= cap && !s->env.no_lds_scene) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = best_wg * 64; s->wgs_per_cu = best_n;
     } else {
-        s->lds_bytes = 0; s->wg_threads = spheres_only ? 512 : 256; s->wgs_per_cu = spheres_only ? 4 : 5;   // 32 (sphere-only, 8 waves/SIMD), 20 or 16 waves per CU
+        s->lds_bytes = 0; s->wg_threads = spheres_only ? 512 : 256; s->wgs_per_cu = spheres_only ? 4 : (cornell ? 5 : 6);   // 32 (sphere-only, 8 waves/SIMD), 20 or 24 waves per CU
     }
 }
 
 template <uint32_t F, int MINW_SPHERES = 6>
 int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st, bool cost) {
-    // register budget: the sphere-only kernels fit 80 VGPRs (6 waves per SIMD, 24 per CU), the others are held to 128 (4 per SIMD)
-    // the Cornell-type variants (Rect / list / Boxy / instance) fit 96 VGPRs: 5 per SIMD
-    constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? MINW_SPHERES : 5;
+    // register budget: the sphere-only kernels fit 80 VGPRs (6 waves per SIMD, 24 per CU); the Cornell-type variants (Rect / list /
+    // Boxy / instance) fit 96: 5 per SIMD.  The everything-variants need 120 to be free of spills, but they wait for memory 44 % of
+    // the time (C3's 118 KB hot set is read through L1/L2): held to 96 they spill 4 registers and C3 gains 8 %, held to 80 = 6 per
+    // SIMD 13 registers (25 scratch instructions, outside the box loop) and C3 gains 13 % (642 -> 695 -> 726 Msamples/s; at 72 = 7
+    // per SIMD, 27 registers and 154 scratch instructions, it is back to 695)
+    constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? MINW_SPHERES : (((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? 6 : 5);
     // Sphere-only scenes traversed from GLOBAL memory (C5, 49 MB of items and spheres) run at 8 waves per SIMD / 64 VGPRs with the
     // shading phase out of line: every box step is a dependent gather there, and once no NaN ray walks the whole tree any more
     // (vk_trace.h begin_segment) more waves in flight are worth 9 % (629 -> 685 Msamples/s; with the NaN walks it was -5 %).
