@@ -35,7 +35,7 @@ def test_resource_file_lists_every_variant(built):
     feats = {k[0] for k in v}
     assert {0, F_PDF, F_CORNELL | F_PDF, 0x17F, 0x17F | F_PDF} <= feats, sorted(feats)
     for f in feats:
-        minw = 5 if f & ~F_PDF == F_CORNELL else 6
+        minw = 6
         assert (f, True, minw, False) in v                               # LDS-resident scene
         assert (f, False, 8 if f in (0, F_PDF) else minw, False) in v    # global-memory scene (sphere-only: 8 waves/SIMD, shading out of line)
 
@@ -58,13 +58,14 @@ def test_sphere_only_variant_keeps_six_waves_per_simd(built):
         assert not r["dynamic_stack"], (key, r)
 
 
-def test_cornell_variant_does_not_spill(built):
+def test_cornell_variant_budget(built):
     for key, r in variants().items():
         if key[0] & ~F_PDF != F_CORNELL:
             continue
-        # (0 / 0 until the SHADE + REFILL phase became a function of its own: 16 B / 7 instructions, all in that phase)
-        # 96 VGPRs = five waves per SIMD (20 per CU)
-        assert key[2] == 5 and r["occupancy"] >= 5 and r["scratch"] <= 16 and r["scratch_ops"] <= 12 and r["vgprs"] <= 96, (key, r)
+        # free of spills at 96 VGPRs; held to 80 = six waves per SIMD it spills 45 registers (79 scratch instructions when written,
+        # shading inline) and is still faster: C4 5 240 -> 5 425 Msamples/s (vk_api.hip launch_variant)
+        assert key[2] == 6 and r["occupancy"] >= 6 and r["vgprs"] <= 80 and not r["dynamic_stack"], (key, r)
+        assert r["scratch"] <= 128 and r["scratch_ops"] <= 100, (key, r)
 
 
 def test_full_variant_budget(built):

@@ -183,20 +183,19 @@ size_t per_wave_lds_bytes(uint32_t F) {   // cold lane state of one wave + its t
 // 4.06 vs 3.77 Gsamples/s at 24 waves/CU; C4: no difference), while occupancy is worth much more (C3: the
 // 118 KB scene in LDS leaves 11 waves/CU = 371 Msamples/s; from L2 at 16 waves/CU = 503).  So the scene is
 // staged in LDS only when that costs no waves: choose the workgroup size (waves share one LDS copy) and
-// workgroups per CU that reach the variant's full occupancy (24 waves/CU at 80 VGPRs, 20 at 96) with the
+// workgroups per CU that reach the variant's full occupancy (24 waves/CU at 80 VGPRs) with the
 // scene resident, else traverse from global memory at full occupancy.
 void plan_residency(vk_scene *s, size_t hot) {
     const size_t pw = per_wave_lds_bytes(pick_variant(s));
     uint32_t best_waves = 0, best_wg = 0, best_n = 0;
     const bool spheres_only = pick_variant(s) == 0u;
-    const bool cornell = pick_variant(s) == (VKF_RECT | VKF_LIST | VKF_INSTANCE | VKF_BOX);
-    const uint32_t per_simd = spheres_only ? s->sphere_waves : (cornell ? 5u : 6u);   // = MINW of launch_variant
+    const uint32_t per_simd = spheres_only ? s->sphere_waves : 6u;          // = MINW of launch_variant
     uint32_t cap = 4 * per_simd;                                             // waves per CU the variant's register budget admits
-    // (five per SIMD only come about with workgroups of 4 waves, one per SIMD: two 10-wave workgroups land 3+3+2+2 and the second
-    // one does not fit beside the first)
-    const uint32_t max_wg_waves = per_simd == 6 ? 12 : (per_simd == 5 ? 4 : 16);      // <= the variant's __launch_bounds__ thread limit / 64
+    // Workgroups hold a multiple of 4 waves that divides evenly over the CU's four SIMDs: the dispatcher deals a workgroup's waves
+    // round-robin, so e.g. two 10-wave workgroups land 3+3+2+2 twice and the second one does not fit beside the first at 5 per SIMD
+    const uint32_t max_wg_waves = 12;                                        // <= the variants' __launch_bounds__ thread limit / 64
     { int v = s->env.max_waves_per_cu; if (v >= 4 && (uint32_t)v < cap) cap = (uint32_t)v; }   // diagnostics: lower the occupancy
-    for (uint32_t n_wg = 1; n_wg <= 5; n_wg++) {
+    for (uint32_t n_wg = 1; n_wg <= 6; n_wg++) {
         size_t budget = LDS_PER_CU / n_wg;
         if (hot + 4 * pw > budget) break;
         uint32_t w = (uint32_t)std::min<size_t>(std::min<uint32_t>(max_wg_waves, cap / n_wg), (budget - hot) / pw);
@@ -206,18 +205,18 @@ void plan_residency(vk_scene *s, size_t hot) {
     if (best_waves >= cap && !s->env.no_lds_scene) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = best_wg * 64; s->wgs_per_cu = best_n;
     } else {
-        s->lds_bytes = 0; s->wg_threads = spheres_only ? 512 : 256; s->wgs_per_cu = spheres_only ? 4 : (cornell ? 5 : 6);   // 32 (sphere-only, 8 waves/SIMD), 20 or 24 waves per CU
+        s->lds_bytes = 0; s->wg_threads = spheres_only ? 512 : 256; s->wgs_per_cu = spheres_only ? 4 : 6;   // 32 (sphere-only, 8 waves/SIMD) or 24 waves per CU
     }
 }
 
 template <uint32_t F, int MINW_SPHERES = 6>
 int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st, bool cost) {
-    // register budget: the sphere-only kernels fit 80 VGPRs (6 waves per SIMD, 24 per CU); the Cornell-type variants (Rect / list /
-    // Boxy / instance) fit 96: 5 per SIMD.  The everything-variants need 120 to be free of spills, but they wait for memory 44 % of
-    // the time (C3's 118 KB hot set is read through L1/L2): held to 96 they spill 4 registers and C3 gains 8 %, held to 80 = 6 per
-    // SIMD 13 registers (25 scratch instructions, outside the box loop) and C3 gains 13 % (642 -> 695 -> 726 Msamples/s; at 72 = 7
-    // per SIMD, 27 registers and 154 scratch instructions, it is back to 695)
-    constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? MINW_SPHERES : (((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? 6 : 5);
+    // Register budget: every variant is held to 80 VGPRs = 6 waves per SIMD, 24 per CU.  The sphere-only kernels fit (76).  The
+    // Cornell-type variants (Rect / list / Boxy / instance) need 96 and the everything-variants 120 to be free of spills, but both
+    // gain more from the waves than they lose to the spills: C4 at 4 / 5 / 6 per SIMD 4 430 / 5 240 / 5 425 Msamples/s (45 spilled
+    // registers at 6, shading inline; out of line 5 340); C3, which waits for memory 44 % of the time, 642 / 695 / 726 at 4 / 5 / 6
+    // (13 spilled registers, 25 scratch instructions outside the box loop, shading out of line) and 695 at 7 (27 registers, 154).
+    constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? MINW_SPHERES : 6;
     // Sphere-only scenes traversed from GLOBAL memory (C5, 49 MB of items and spheres) run at 8 waves per SIMD / 64 VGPRs with the
     // shading phase out of line: every box step is a dependent gather there, and once no NaN ray walks the whole tree any more
     // (vk_trace.h begin_segment) more waves in flight are worth 9 % (629 -> 685 Msamples/s; with the NaN walks it was -5 %).
