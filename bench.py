@@ -13,6 +13,8 @@ Also reported in the same JSON line:
                the full spp) with the oracle's render of the same pixels: pixels checked, max |dRGB|
   roofline     algorithmic bytes per launch (SURVEY §8d formula, visit counts from the oracle's counters on a
                bounded sample of the same scene/seed) / HIP-event time of the launch; plus `issue`: the
+               `traffic` = the HBM bytes of one launch, measured in this run by two one-step child runs under rocprofv3 --pmc
+               (FETCH_SIZE, WRITE_SIZE; --no-traffic or a profiler that cannot run: the committed profile's figure); `issue` = the
                physical bound of this kernel — VALU issue slots (wave-instructions per sample from the committed
                rocprofv3 PMC pass of this command, 2 cycles each on a SIMD-32, 1024 SIMDs x 2.4 GHz)
   cpu_baseline the oracle (restated CPU path, "port") timed on this box's host cores on a bounded sample of the
@@ -67,6 +69,48 @@ def pmc_summary(workload):
     return None, None
 
 
+def measure_traffic_live(workload, timeout_s=150):
+    """HBM bytes of ONE launch of this workload's production kernel, measured now: two child runs of this script (one step each)
+    under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes as MI355X_MICROARCH.md prescribes (kernel trace only, the
+    program directly after `--`).  FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 FETCH_SIZE counts half the bytes of wide reads, so
+    the read figure is given as the x2 upper bound.  Returns (bytes, detail) or (None, reason): the caller then falls back to the
+    committed profile."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None, "this run is itself being profiled"
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="vk_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+               "--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu", "--no-verify", "--no-also", "--no-traffic"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            vals = []
+            for f in glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "render_kernel" in r["Kernel_Name"] and ", true>(" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"no {counter} row for the render kernel"
+            got[counter] = sum(vals) / len(vals)
+        except Exception as e:      # a profiler that cannot run here must not take the benchmark down
+            return None, f"{counter} pass failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    read_ub, written = 2.0 * got["FETCH_SIZE"] * 1024.0, got["WRITE_SIZE"] * 1024.0
+    return read_ub + written, {"read_bytes_upper_bound": read_ub, "written_bytes": written}
+
+
 def verify_against_oracle(O, hs, cam, img, width, spp, depth, budget_samples=1.5e6):
     """Compares a sparse subset of 8x8 tiles of `img` (numpy, (h, w, 3), y up) with the oracle's render of exactly
     those pixels at the same seed and the FULL spp.  Every k-th tile (k prime, so the subset wanders over the
@@ -104,6 +148,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run check of the timed framebuffer against the oracle")
     ap.add_argument("--no-also", action="store_true", help="skip the single steps of the other BASELINE configs")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure the HBM traffic of a launch now (two one-step child runs under rocprofv3 --pmc); "
+                         "roofline.traffic then comes from the committed profile")
     ap.add_argument("--fast-accel", action="store_true",
                     help="set VK_SCENE_FAST_ACCEL in the scene description: the library rebuilds draw-free subtrees with its SAH builder "
                          "(opt-in; not the headline: see include/vecchio_amd.h)")
@@ -149,7 +196,7 @@ def main():
     import oracle_ffi as O
     cores = os.cpu_count() or 1
 
-    def run_workload(name, steps, warmup, spp_override=0, want_cpu=False, bvh="reference", fast_accel=False):
+    def run_workload(name, steps, warmup, spp_override=0, want_cpu=False, bvh="reference", fast_accel=False, live_traffic=False):
         scene_name, width, spp, depth, label = WORKLOADS[name]
         if spp_override:
             spp = spp_override
@@ -250,12 +297,23 @@ def main():
                                  "frac": round(rate / VALU_WAVE_INSTR_PER_S, 4), "lane_fill": round(d.get("valu_lane_utilisation", 0.0), 4),
                                  "note": "instruction count per sample from the committed PMC pass (a property of the build), rate from THIS run's "
                                          "kernel time; frac x lane_fill = share of the 78.6 T lane-instr/s the kernel's useful lanes occupy"}
+            traffic_note = (f"HBM bytes per launch from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command ({prof_path}), "
+                            "not re-measured in this run")
+            if live_traffic and not spp_override and bvh == "reference" and not fast_accel:
+                live, detail = measure_traffic_live(name)
+                if live is not None:
+                    traffic_note = ("HBM bytes of one launch MEASURED IN THIS RUN: two one-step child runs of this script under rocprofv3 --pmc "
+                                    f"(FETCH_SIZE x 2 as the gfx950 upper bound: {detail['read_bytes_upper_bound']:.0f} B read, WRITE_SIZE: "
+                                    f"{detail['written_bytes']:.0f} B written); committed profile ({prof_path}): {traffic}")
+                    traffic = live
+                else:
+                    traffic_note += f" (a live measurement was tried and failed: {detail})"
             roof = None
             if k_ms:
                 achieved = bps * local_samples / (k_ms * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                        "traffic_note": f"HBM bytes per launch from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command ({prof_path}), not re-measured in this run",
+                        "traffic_note": traffic_note,
                         "algorithmic_bytes_per_sample": round(bps, 1), "kernel_ms": round(k_ms, 3),
                         "algorithmic_bytes_per_sample_walked": round(bps_walked, 1),
                         "frac_walked": round(achieved * bps_walked / bps / HBM_PEAK_GBPS, 4),
@@ -279,7 +337,7 @@ def main():
         return res
 
     main_res = run_workload(args.workload, args.steps, args.warmup, args.spp, want_cpu=(n_gpus == 1 and not args.no_cpu), bvh=args.bvh,
-                            fast_accel=args.fast_accel)
+                            fast_accel=args.fast_accel, live_traffic=(n_gpus == 1 and world == 1 and not args.no_traffic and not rehearsal))
     also = []
     if n_gpus == 1 and not args.no_also and args.workload == "C2" and not args.spp:
         for name, spp_o, fa in (("C4", 0, False), ("C3", 0, False), ("C5", 0, False), ("C2", 0, True)):

@@ -10,7 +10,7 @@ STEPS=${STEPS:-2}
 WARMUP=${WARMUP:-1}
 TMO=${TMO:-300}
 mkdir -p gpurun_out; rm -rf $OUT; mkdir -p $OUT
-ARGS="bench.py --steps $STEPS --warmup $WARMUP --no-cpu --no-verify $WL"
+ARGS="bench.py --steps $STEPS --warmup $WARMUP --no-cpu --no-verify --no-traffic $WL"
 echo "$ARGS" > $OUT/command.txt
 timeout -k 10 $TMO rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || exit 1
 pass() { # name counters...
