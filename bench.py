@@ -13,9 +13,9 @@ Also reported in the same JSON line:
                the full spp) with the oracle's render of the same pixels: pixels checked, max |dRGB|
   roofline     algorithmic bytes per launch (SURVEY §8d formula, visit counts from the oracle's counters on a
                bounded sample of the same scene/seed) / HIP-event time of the launch; plus `issue`: the
-               `traffic` = the HBM bytes of one launch, measured in this run by two one-step child runs under rocprofv3 --pmc
-               (FETCH_SIZE, WRITE_SIZE; --no-traffic or a profiler that cannot run: the committed profile's figure); `issue` = the
-               physical bound of this kernel — VALU issue slots (wave-instructions per sample from the committed
+               `traffic` = the HBM bytes of one launch and the instruction counts of `issue`, measured in this run by three
+               one-step child runs under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE, SQ counters; --no-traffic or a profiler that
+               cannot run: the committed profile's figures); `issue` = the physical bound of this kernel — VALU issue slots (wave-instructions per sample from the committed
                rocprofv3 PMC pass of this command, 2 cycles each on a SIMD-32, 1024 SIMDs x 2.4 GHz)
   cpu_baseline the oracle (restated CPU path, "port") timed on this box's host cores on a bounded sample of the
                same workload (N = 1 only)
@@ -69,12 +69,12 @@ def pmc_summary(workload):
     return None, None
 
 
-def measure_traffic_live(workload, timeout_s=150):
-    """HBM bytes of ONE launch of this workload's production kernel, measured now: two child runs of this script (one step each)
-    under rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in separate passes as MI355X_MICROARCH.md prescribes (kernel trace only, the
-    program directly after `--`).  FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 FETCH_SIZE counts half the bytes of wide reads, so
-    the read figure is given as the x2 upper bound.  Returns (bytes, detail) or (None, reason): the caller then falls back to the
-    committed profile."""
+def measure_counters_live(workload, timeout_s=150):
+    """Hardware counters of ONE launch of this workload's production kernel, measured now: child runs of this script (one step each)
+    under rocprofv3 --pmc, one pass per counter group as MI355X_MICROARCH.md prescribes (kernel trace only, the program directly
+    after `--`): FETCH_SIZE, WRITE_SIZE (KiB; on gfx950 FETCH_SIZE counts half the bytes of wide reads, so the read figure is given
+    as the x2 upper bound) and the SQ instruction counters behind `roofline.issue`.  Returns (dict, None) or (None, reason): the
+    caller then falls back to the committed profile."""
     import csv
     import glob
     import shutil
@@ -86,29 +86,30 @@ def measure_traffic_live(workload, timeout_s=150):
     if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
         return None, "this run is itself being profiled"
     got = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for group in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU")):
         tmp = tempfile.mkdtemp(prefix="vk_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+        cmd = [exe, "--pmc", *group, "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.join(ROOT, "bench.py"),
                "--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu", "--no-verify", "--no-also", "--no-traffic"]
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-            vals = []
+            vals = {c: [] for c in group}
             for f in glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if "render_kernel" in r["Kernel_Name"] and ", true>(" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                        vals.append(float(r["Counter_Value"]))
-            if not vals:
-                return None, f"no {counter} row for the render kernel"
-            got[counter] = sum(vals) / len(vals)
+                    if "render_kernel" in r["Kernel_Name"] and ", true>(" not in r["Kernel_Name"] and r["Counter_Name"] in vals:
+                        vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            for c in group:
+                if not vals[c]:
+                    return None, f"no {c} row for the render kernel"
+                got[c] = sum(vals[c]) / len(vals[c])
         except Exception as e:      # a profiler that cannot run here must not take the benchmark down
-            return None, f"{counter} pass failed: {type(e).__name__}"
+            return None, f"{group[0]} pass failed: {type(e).__name__}"
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    read_ub, written = 2.0 * got["FETCH_SIZE"] * 1024.0, got["WRITE_SIZE"] * 1024.0
-    return read_ub + written, {"read_bytes_upper_bound": read_ub, "written_bytes": written}
+    got["read_bytes_upper_bound"], got["written_bytes"] = 2.0 * got["FETCH_SIZE"] * 1024.0, got["WRITE_SIZE"] * 1024.0
+    return got, None
 
 
 def verify_against_oracle(O, hs, cam, img, width, spp, depth, budget_samples=1.5e6):
@@ -300,14 +301,23 @@ def main():
             traffic_note = (f"HBM bytes per launch from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command ({prof_path}), "
                             "not re-measured in this run")
             if live_traffic and not spp_override and bvh == "reference" and not fast_accel:
-                live, detail = measure_traffic_live(name)
+                live, why = measure_counters_live(name)
                 if live is not None:
-                    traffic_note = ("HBM bytes of one launch MEASURED IN THIS RUN: two one-step child runs of this script under rocprofv3 --pmc "
-                                    f"(FETCH_SIZE x 2 as the gfx950 upper bound: {detail['read_bytes_upper_bound']:.0f} B read, WRITE_SIZE: "
-                                    f"{detail['written_bytes']:.0f} B written); committed profile ({prof_path}): {traffic}")
-                    traffic = live
+                    traffic_note = ("HBM bytes of one launch MEASURED IN THIS RUN: one-step child runs of this script under rocprofv3 --pmc "
+                                    f"(FETCH_SIZE x 2 as the gfx950 upper bound: {live['read_bytes_upper_bound']:.0f} B read, WRITE_SIZE: "
+                                    f"{live['written_bytes']:.0f} B written); committed profile ({prof_path}): {traffic}")
+                    traffic = live["read_bytes_upper_bound"] + live["written_bytes"]
+                    if k_ms:
+                        vi = live["SQ_INSTS_VALU"] / local_samples
+                        rate = live["SQ_INSTS_VALU"] / (k_ms * 1e-3)
+                        issue = {"bound": "valu_issue", "valu_wave_instr_per_sample": round(vi, 1), "salu_wave_instr_per_sample": round(live["SQ_INSTS_SALU"] / local_samples, 1),
+                                 "cycles_per_wave_instr": 2, "peak_wave_instr_per_s": VALU_WAVE_INSTR_PER_S, "achieved_wave_instr_per_s": round(rate, 1),
+                                 "frac": round(rate / VALU_WAVE_INSTR_PER_S, 4),
+                                 "lane_fill": round(live["SQ_THREAD_CYCLES_VALU"] / (64.0 * live["SQ_ACTIVE_INST_VALU"]), 4),
+                                 "note": "instruction counts of one launch MEASURED IN THIS RUN (rocprofv3 --pmc child run), rate from this run's kernel "
+                                         "time; frac x lane_fill = share of the 78.6 T lane-instr/s the kernel's useful lanes occupy"}
                 else:
-                    traffic_note += f" (a live measurement was tried and failed: {detail})"
+                    traffic_note += f" (a live measurement was tried and failed: {why})"
             roof = None
             if k_ms:
                 achieved = bps * local_samples / (k_ms * 1e-3) / 1e9
