@@ -13,7 +13,7 @@
 //     (box_steps: nested steps under one shrinking EXEC mask, light primitive tests inline), PRIM heavy,
 //     SHADE + REFILL (out of line for the everything-variants); lane state that only shading needs
 //     (throughput, RNG, depth, pixel) is parked in LDS between SHADE phases so the traversal loops fit
-//     80 VGPRs (6 waves/SIMD) or 128 (4 waves/SIMD);
+//     80 VGPRs (6 waves/SIMD; 64 = 8 waves/SIMD for sphere-only scenes traversed from global memory);
 //   * traversal is the stack-free threaded walk of vk_trace.h; when the linear BVH + spheres + boxes
 //     fit next to that per-wave state WITHOUT costing occupancy, every workgroup stages them into its
 //     LDS (160 KB/CU) once and item fetches are ds_read_b128; otherwise they are L1/L2 gathers;
