@@ -69,7 +69,7 @@ def pmc_summary(workload):
     return None, None
 
 
-def measure_counters_live(workload, timeout_s=150):
+def measure_counters_live(workload, timeout_s=75):
     """Hardware counters of ONE launch of this workload's production kernel, measured now: child runs of this script (one step each)
     under rocprofv3 --pmc, one pass per counter group as MI355X_MICROARCH.md prescribes (kernel trace only, the program directly
     after `--`): FETCH_SIZE, WRITE_SIZE (KiB; on gfx950 FETCH_SIZE counts half the bytes of wide reads, so the read figure is given
