@@ -194,6 +194,12 @@ __device__ __forceinline__ void flush_tile_sums(unsigned long long *tile_sum, lo
 }
 
 // number of lanes of the wave for which p holds (v_cmp -> s_bcnt1, no VGPR round trip)
+// lane mask of prim_is_heavy<F>(ref), straight from the compare
+template <uint32_t F>
+__device__ __forceinline__ unsigned long long heavy_mask(uint32_t ref) {
+    if constexpr ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) return __builtin_amdgcn_uicmp(ref - ((uint32_t)DK_LIST << 28), 3u << 28, 36 /* ult */);
+    else return __builtin_amdgcn_uicmp(ref, (uint32_t)DK_LIST << 28, 35 /* uge */);
+}
 __device__ __forceinline__ uint32_t lanes_with(bool p) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
 
 // ---- the SHADE + REFILL phase body: shade the lanes whose segment is fully traversed, deposit finished samples, hand new
@@ -422,7 +428,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
         const unsigned long long m_pend0 = __builtin_amdgcn_uicmp(L.pend, 0u, 33 /* ne */) & m_act;
         unsigned long long m_trav = __builtin_amdgcn_uicmp(L.i, L.end, 36 /* ult */);
         if (F & VKF_INSTANCE) m_trav |= __builtin_amdgcn_sicmp(L.cur_inst, 0, 39 /* sge */);
-        const unsigned long long m_heavy = HAS_HEAVY ? (__builtin_amdgcn_uicmp(L.pend, (uint32_t)DK_LIST << 28, 35 /* uge: prim_is_heavy */) & m_pend0) : 0ull;
+        const unsigned long long m_heavy = HAS_HEAVY ? (heavy_mask<F>(L.pend) & m_pend0) : 0ull;
         const unsigned long long m_light = m_pend0 & ~m_heavy;
         const unsigned long long m_shade = m_act & ~m_pend0 & ~m_trav;
         const uint32_t n_box = (uint32_t)__builtin_popcountll(m_act & ~m_pend0 & m_trav);
@@ -489,7 +495,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     // when that state is a LIGHT primitive test (Sphere / MovingSphere / Rect: never draws, never changes the
                     // space), run it right here and keep stepping: saves the scheduler round trip that otherwise follows every
                     // ~10 box steps
-                    const unsigned long long m_light = HAS_HEAVY ? (m_prim & ~__builtin_amdgcn_uicmp(L.pend, (uint32_t)DK_LIST << 28, 35 /* uge: prim_is_heavy */)) : m_prim;
+                    const unsigned long long m_light = HAS_HEAVY ? (m_prim & ~heavy_mask<F>(L.pend)) : m_prim;
                     const uint32_t nl = (uint32_t)__builtin_popcountll(m_light);
                     if ((((int)nl - 1) | ((int)(2u * nl) - (int)np) | ((int)(nl * shade_defer) - (int)ns)) >= 0) {   // nl != 0, 2 nl >= np, nl * shade_defer >= ns
                         if (__builtin_amdgcn_inverse_ballot_w64(m_light)) prim_step<F, Mem>(L, S, M);

@@ -476,7 +476,14 @@ VK_HD void process_ref(Lane &L, const DScene &S, const Mem &M, uint32_t ref) {
 VK_HD bool traversing(const Lane &L) { return L.i < L.end || L.pend != 0 || L.cur_inst >= 0; }
 VK_HD bool has_prim_work(const Lane &L) { return L.pend != 0; }
 // Sphere / MovingSphere / Rect tests are ~50 instructions; Boxy, lists, media and instance entry cost several times that
-VK_HD bool prim_is_heavy(uint32_t ref) { uint32_t k = VKD_KIND(ref); return k >= DK_LIST; }
+// In the everything-variants a Boxy (kind 7: six rect tests, no draw, no change of space) counts as light and is served inside the
+// box loop like a sphere or a rect: C3's 400 ground boxes then stop competing with the media and the instance entries for the
+// heavy phase (C3 727 -> 766 Msamples/s).  The Cornell-type variants keep it heavy (C4 -2.9 % otherwise: its two boxes sit
+// inside instances, i.e. behind a heavy step anyway).  A scheduling class only: results do not depend on it.
+template <uint32_t F>
+VK_HD bool prim_is_heavy(uint32_t ref) {
+    return ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? (ref - ((uint32_t)DK_LIST << 28) < (3u << 28)) : (VKD_KIND(ref) >= DK_LIST);
+}
 
 // One box step of a lane that HAS box work and is inside its range (pend == 0, i < end).
 // The wave runs it under the EXEC mask of exactly those lanes (box_steps below): a lane that queues
@@ -591,7 +598,7 @@ VK_HD void prim_step(Lane &L, const DScene &S, const Mem &M) {
     L.pend2 = 0;
     process_ref<F, Mem>(L, S, M, ref);
     // a light object followed by another light one (a leaf of two spheres / rects): both in this step, as above
-    if (!prim_is_heavy(ref) && L.pend != 0u && !prim_is_heavy(L.pend)) {
+    if (!prim_is_heavy<F>(ref) && L.pend != 0u && !prim_is_heavy<F>(L.pend)) {
         uint32_t ref2 = L.pend;
         L.pend = 0;
         process_ref<F, Mem>(L, S, M, ref2);
