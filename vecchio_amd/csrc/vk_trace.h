@@ -597,8 +597,12 @@ VK_HD void prim_step(Lane &L, const DScene &S, const Mem &M) {
     L.pend = L.pend2;
     L.pend2 = 0;
     process_ref<F, Mem>(L, S, M, ref);
-    // a light object followed by another light one (a leaf of two spheres / rects): both in this step, as above
-    if (!prim_is_heavy<F>(ref) && L.pend != 0u && !prim_is_heavy<F>(L.pend)) {
+    // a light object followed by another light one (a leaf of two spheres / rects): both in this step, as above; and an
+    // instance that holds ONE object (a rotated, translated Boxy: enter_instance queued it in pend): entered and tested in one
+    // step instead of two heavy phases
+    const bool chain_light = !prim_is_heavy<F>(ref) && L.pend != 0u && !prim_is_heavy<F>(L.pend);
+    const bool chain_inst = (F & VKF_INSTANCE) != 0u && VKD_KIND(ref) == DK_INSTANCE && L.pend != 0u;
+    if (chain_light || chain_inst) {
         uint32_t ref2 = L.pend;
         L.pend = 0;
         process_ref<F, Mem>(L, S, M, ref2);
