@@ -213,8 +213,8 @@ template <uint32_t F, int MINW_SPHERES = 6>
 int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st, bool cost) {
     // Register budget: every variant is held to 80 VGPRs = 6 waves per SIMD, 24 per CU.  The sphere-only kernels fit (76).  The
     // Cornell-type variants (Rect / list / Boxy / instance) need 96 and the everything-variants 120 to be free of spills, but both
-    // gain more from the waves than they lose to the spills: C4 at 4 / 5 / 6 per SIMD 4 430 / 5 240 / 5 425 Msamples/s (45 spilled
-    // registers at 6, shading inline; out of line 5 340); C3, which waits for memory 44 % of the time, 642 / 695 / 726 at 4 / 5 / 6
+    // gain more from the waves than they lose to the spills: C4 at 4 / 5 / 6 / 7 per SIMD 4 430 / 5 240 / 5 425 / 5 030 Msamples/s (45 spilled
+    // registers at 6, 80 at 7, shading inline; out of line 5 340 at 6); C3, which waits for memory 44 % of the time, 642 / 695 / 726 at 4 / 5 / 6
     // (13 spilled registers, 25 scratch instructions outside the box loop, shading out of line) and 695 at 7 (27 registers, 154).
     constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? MINW_SPHERES : 6;
     // Sphere-only scenes traversed from GLOBAL memory (C5, 49 MB of items and spheres) run at 8 waves per SIMD / 64 VGPRs with the
