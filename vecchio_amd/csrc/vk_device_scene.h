@@ -85,7 +85,9 @@ enum : uint32_t {  // feature bits -> kernel variant selection
     VKF_SPEC_DIFFUSE = 64u,
     VKF_BOX = 256u,       // canonical Boxy lists stored as DBox
     VKF_ALL_SCENE = 0x17Fu,
-    VKF_INTEG_PDF = 128u  // not a scene property: selects the HEAD integrator (main.rs:123-153) at compile time
+    VKF_INTEG_PDF = 128u, // not a scene property: selects the HEAD integrator (main.rs:123-153) at compile time
+    VKF_NOISE = 512u      // the scene has a Perlin noise texture (implies VKF_TEXTURES; not a variant selector: read at run time by
+                          // vk_kernels.h cooperative_turb)
 };
 
 // What the kernel sees.  All pointers are device (or, in the CPU emulator, host) addresses.

@@ -202,6 +202,53 @@ __device__ __forceinline__ unsigned long long heavy_mask(uint32_t ref) {
 }
 __device__ __forceinline__ uint32_t lanes_with(bool p) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
 
+// ---- Perlin turbulence, the octaves of one lane spread over the wave.  perlin_turb is seven octaves of an 8-corner noise (56
+// dependent gathers) and, in a scene like the final one, is needed by one or two of a shading phase's 64 lanes in three phases out of
+// four: run inside the material code it keeps the whole wave for seven serial noise evaluations.  The octaves are independent until
+// the final ordered sum, so here — at a point of the phase where every lane of the wave is present — the lanes that WILL evaluate a
+// noise texture are found ahead of the material code (a sphere hit outside any instance: its point is o + d*T, its material and
+// texture are two loads away) and, one such lane at a time, lanes 0..6 each evaluate one octave at its point; the seven values come
+// back by readlane and are summed in the reference's order (accum += weight * noise, material.rs:379-390: scaling the point and the
+// weight by powers of two is exact, so octave j alone computes what iteration j of the loop does).  texture_value uses the value
+// only for the texture and point it was made for and runs the loop itself otherwise (lists, instanced objects, SpecDiffuse picks).
+template <uint32_t F, class Mem>
+__device__ __forceinline__ PreTurb cooperative_turb(const Lane &L, const DScene &S, const Mem &M, bool is_shade, uint32_t lane) {
+    PreTurb pt = no_pre_turb();
+    if constexpr ((F & VKF_TEXTURES) != 0u) {
+        if (!(S.features & VKF_NOISE)) return pt;          // (wave-uniform) no noise texture in this scene: nothing to prepare
+        uint32_t perlin = 0u;
+        if (is_shade && L.best_prim != 0u && VKD_KIND(L.best_prim) == DK_SPHERE && (!(F & VKF_INSTANCE) || L.best_inst < 0)) {
+            const DMaterial &m = S.materials[M.smat(VKD_INDEX(L.best_prim))];
+            if (m.tex_kind == VK_TEX_NOISE && m.kind != VK_MAT_DIELECTRIC && m.kind != VK_MAT_SPEC_DIFFUSE) {
+                V3 p = L.o + L.d * L.T;                    // simple_record's R.p for a sphere
+                pt.tex = m.tex; pt.px = p.x; pt.py = p.y; pt.pz = p.z;
+                perlin = S.textures[m.tex].a;
+            }
+        }
+        unsigned long long todo = __builtin_amdgcn_uicmp(pt.tex, 0xFFFFFFFFu, 33 /* ne */);
+        while (todo != 0ull) {                             // wave-uniform: every lane of the wave is here
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const float sx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(pt.px), src));
+            const float sy = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(pt.py), src));
+            const float sz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(pt.pz), src));
+            const uint32_t sp = (uint32_t)__builtin_amdgcn_readlane((int)perlin, src);
+            float n = 0.0f;
+            if (lane < 7u) {
+                const float sc = (float)(1u << lane);      // the point of octave `lane`: p * 2^lane, exactly what six doublings give
+                n = perlin_noise(S.perlins[sp], v3(sx * sc, sy * sc, sz * sc));
+            }
+            float accum = 0.0f, weight = 1.0f;
+            for (int j = 0; j < 7; j++) {
+                accum += weight * __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(n), j));
+                weight *= 0.5f;
+            }
+            if ((int)lane == src) pt.val = fabsf(accum);
+        }
+    }
+    return pt;
+}
+
 // ---- the SHADE + REFILL phase body: shade the lanes whose segment is fully traversed, deposit finished samples, hand new
 // samples to the lanes without a path.  Leaves `fresh` lanes with a new ray parked in L.wo / L.wd / L.time, which the caller
 // installs with ONE begin_segment (its three exact reciprocals are ~60 instructions per call site).  Used inline by the lean variants and through shade_refill_call (below) by the everything-variants.
@@ -218,11 +265,12 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &
     touched = is_shade;           // lanes whose path state is in registers during this phase
     fresh = false;                // lanes that leave this phase with a new ray to install; it is parked in the
                                   // (dead) world-ray fields L.wo / L.wd / L.time, so it costs no registers
+    const PreTurb pre_turb = cooperative_turb<F, Mem>(L, S, M, is_shade, lane);
     if (is_shade) {
         cold_load_path<F>(cold, lane, L);
         if (STATS) st_t1 = clock64();
         V3 no, nd; float nt;
-        bool cont = shade_core<F, Mem>(L, S, M, C, no, nd, nt);
+        bool cont = shade_core<F, Mem>(L, S, M, C, no, nd, nt, pre_turb);
         if (cont) { L.wo = no; L.wd = nd; L.time = nt; fresh = true; }
         if (STATS) st_t_mat += clock64() - st_t1;
         if (!cont) {

@@ -570,6 +570,7 @@ struct Builder {
             else if (t.kind == VK_TEX_NOISE) { if (t.a >= d->n_perlins) return fail(VK_ERR_BAD_ARG, "perlin index out of range"); }
             else if (t.kind != VK_TEX_SOLID) return fail(VK_ERR_BAD_ARG, "unknown texture kind");
             if (t.kind != VK_TEX_SOLID) L.features |= VKF_TEXTURES;
+            if (t.kind == VK_TEX_NOISE) L.features |= VKF_NOISE;
             L.textures.push_back(o);
         }
         for (uint32_t i = 0; i < d->n_images; i++) {

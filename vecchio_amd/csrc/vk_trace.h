@@ -758,8 +758,14 @@ VK_HD float perlin_turb(const DPerlin &P, V3 p, int depth) {  // material.rs:379
 // Non-solid textures (checker / image / Perlin noise).  Out of line on the device: it is
 // reached at most once per bounce, and inlining its 7x8-corner noise and f64 trigonometry
 // into the megakernel is what pushes the whole kernel into spilling.
+// A turbulence value worked out ahead of the material code (vk_kernels.h cooperative_turb: the seven octaves of ONE lane's
+// perlin_turb spread over seven lanes of the wave): valid for texture `tex` at the point (px, py, pz) only; tex = ~0 = none.
+struct PreTurb { uint32_t tex; float val, px, py, pz; };
+VK_HD PreTurb no_pre_turb() { PreTurb t; t.tex = 0xFFFFFFFFu; t.val = 0.0f; t.px = 0.0f; t.py = 0.0f; t.pz = 0.0f; return t; }
+
 VK_COLD V3 texture_value(const DTexture *textures, const DImage *images, const uint8_t *image_bytes, const DPerlin *perlins,
-                         uint32_t tex, float u, float v, float px, float py, float pz) {
+                         uint32_t tex, float u, float v, float px, float py, float pz,
+                         uint32_t pre_tex, float pre_val, float ppx, float ppy, float ppz) {
     V3 p = v3(px, py, pz);
     for (int guard = 0; guard < 16; guard++) {
         const DTexture &t = textures[tex];
@@ -783,15 +789,18 @@ VK_COLD V3 texture_value(const DTexture *textures, const DImage *images, const u
         }
         // VK_TEX_NOISE, material.rs:430-434: Vec3::new_const(1.0) * 0.5 * (1.0 + sin(..))
         const DPerlin &P = perlins[t.a];
-        float s = 1.0f + vk::sinf_(t.scale * p.z + 10.0f * perlin_turb(P, p, 7));
+        const bool pre = tex == pre_tex && px == ppx && py == ppy && pz == ppz;     // the value computed ahead is for this texture at this point
+        float turb = pre_val;
+        if (!pre) turb = perlin_turb(P, p, 7);
+        float s = 1.0f + vk::sinf_(t.scale * p.z + 10.0f * turb);
         return (v3s(1.0f) * 0.5f) * s;
     }
     return v3s(0.0f);
 }
 template <uint32_t F>
-VK_HD V3 material_color(const DScene &S, const DMaterial &m, const Rec &R) {
+VK_HD V3 material_color(const DScene &S, const DMaterial &m, const Rec &R, const PreTurb &pt) {
     if (!(F & VKF_TEXTURES) || m.tex_kind == VK_TEX_SOLID) return v3(m.r, m.g, m.b);
-    return texture_value(S.textures, S.images, S.image_bytes, S.perlins, m.tex, R.u, R.v, R.p.x, R.p.y, R.p.z);
+    return texture_value(S.textures, S.images, S.image_bytes, S.perlins, m.tex, R.u, R.v, R.p.x, R.p.y, R.p.z, pt.tex, pt.val, pt.px, pt.py, pt.pz);
 }
 
 // ------------------------------------------------------------------ samplers (util.rs:31-63, material.rs:51-58)
@@ -973,7 +982,7 @@ VK_HD V3 background_of(const RenderConsts &C, V3 ud) {       // ud = unit(ray di
 // the ray (no, nd, ntime) (the caller installs it with begin_segment), false when the path ended (L.acc is
 // its radiance).
 template <uint32_t F, class Mem>
-VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C, V3 &no, V3 &ndir, float &ntime) {
+VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C, V3 &no, V3 &ndir, float &ntime, const PreTurb &pt = no_pre_turb()) {
     const bool miss = L.best_prim == 0;
     Rec R;
     const DMaterial *m = S.materials;
@@ -1005,11 +1014,11 @@ VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts
         uint32_t kind = m->kind;
         if (kind == VK_MAT_LAMBERTIAN) {                      // material.rs:85-90
             ndir = R.n + lambertian_random(L.rng);
-            atten = material_color<F>(S, *m, R);
+            atten = material_color<F>(S, *m, R, pt);
         } else if (kind == VK_MAT_METAL) {                    // material.rs:118-132
             V3 reflected = reflect(ud, R.n);
             ndir = reflected + random_in_unit_sphere(L.rng) * m->param;
-            atten = material_color<F>(S, *m, R);
+            atten = material_color<F>(S, *m, R, pt);
             scattered = dot(ndir, R.n) > 0.0f;
         } else if (kind == VK_MAT_DIELECTRIC) {               // material.rs:150-175
             atten = v3s(1.0f);
@@ -1024,10 +1033,10 @@ VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts
             }
         } else if (kind == VK_MAT_ISOTROPIC) {                // material.rs:442-446
             ndir = random_in_unit_sphere(L.rng);
-            atten = material_color<F>(S, *m, R);
+            atten = material_color<F>(S, *m, R, pt);
         } else {                                              // DiffuseLight: material.rs:215-225
             scattered = false;
-            if (kind == VK_MAT_DIFFUSE_LIGHT && R.front) emitted = material_color<F>(S, *m, R);
+            if (kind == VK_MAT_DIFFUSE_LIGHT && R.front) emitted = material_color<F>(S, *m, R, pt);
         }
         L.acc = L.acc + L.thr * emitted;
         if (!scattered) return false;
@@ -1036,7 +1045,7 @@ VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts
         // HEAD integrator, main.rs:131-149
         V3 emitted = v3s(0.0f);
         if (m->kind == VK_MAT_DIFFUSE_LIGHT) {
-            if (R.front) emitted = material_color<F>(S, *m, R);
+            if (R.front) emitted = material_color<F>(S, *m, R, pt);
             L.acc = L.acc + L.thr * emitted;                  // scatter_with_pdf is None: return emitted
             return false;
         }
@@ -1053,7 +1062,7 @@ VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts
             V3 reflected = reflect(ud, R.n);
             ndir = reflected + random_in_unit_sphere(L.rng) * m->param;
             ntime = 0.0f;
-            L.thr = L.thr * material_color<F>(S, *m, R);         // specular: emitted is NOT added (main.rs:134-137)
+            L.thr = L.thr * material_color<F>(S, *m, R, pt);         // specular: emitted is NOT added (main.rs:134-137)
         } else if (kind == VK_MAT_DIELECTRIC) {               // material.rs:177-206
             float eta = R.front ? 1.0f / m->param : m->param;
             float cos_theta = fminf(dot(-ud, R.n), 1.0f);
@@ -1065,7 +1074,7 @@ VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts
                 else ndir = refract(ud, R.n, eta);
             }
         } else {                                              // Lambertian / Isotropic: material.rs:92-98,448-454
-            V3 atten = material_color<F>(S, *m, R);
+            V3 atten = material_color<F>(S, *m, R, pt);
             Onb uvw = onb_from_w(R.n);                        // CosinePDF::new(rec.normal)
             // MixturePDF::generate, util.rs:177-185
             if (vk::gen_f32(L.rng) < 0.5f) {
