@@ -585,6 +585,8 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
     if (!H.tie_rank.empty()) UP(tie_rank, tie_rank);
 #undef UP
     D.tie_base_rect = H.tie_base_rect; D.tie_base_box = H.tie_base_box; D.tie_base_list = H.tie_base_list;
+    D.n_noise_spheres = H.n_noise_spheres;
+    for (int k = 0; k < 4; k++) { D.noise_sphere[k] = H.noise_sphere[k]; D.noise_tex[k] = H.noise_tex[k]; D.noise_perlin[k] = H.noise_perlin[k]; }
     D.n_items = (uint32_t)H.items.size(); D.n_world_items = H.world_items; D.n_spheres = (uint32_t)H.spheres.size();
     D.n_lights = (uint32_t)H.lights.size(); D.features = H.features; D.n_boxes = (uint32_t)H.boxes.size();
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->counter), 256));

@@ -111,6 +111,10 @@ struct DScene {
     // t; then the reference's choice is reproduced from their positions in ITS visiting order: entry = block << 20 | position,
     // indexed by object id = sphere index | tie_base_rect + rect | tie_base_box + box | tie_base_list + list.
     const uint32_t *tie_rank; uint32_t tie_base_rect, tie_base_box, tie_base_list;
+    // The spheres whose material reads a Perlin noise texture (vk_kernels.h cooperative_turb finds the lanes that will evaluate one
+    // by comparing their hit with this list instead of chasing sphere -> material -> texture): sphere index, texture, perlin table.
+    // n_noise_spheres = ~0: more than fit here, look the material up.
+    uint32_t n_noise_spheres; uint32_t noise_sphere[4], noise_tex[4], noise_perlin[4];
 };
 
 }  // namespace vkd

@@ -206,11 +206,13 @@ __device__ __forceinline__ uint32_t lanes_with(bool p) { return (uint32_t)__buil
 // dependent gathers) and, in a scene like the final one, is needed by one or two of a shading phase's 64 lanes in three phases out of
 // four: run inside the material code it keeps the whole wave for seven serial noise evaluations.  The octaves are independent until
 // the final ordered sum, so here — at a point of the phase where every lane of the wave is present — the lanes that WILL evaluate a
-// noise texture are found ahead of the material code (a sphere hit outside any instance: its point is o + d*T, its material and
-// texture are two loads away) and, one such lane at a time, lanes 0..6 each evaluate one octave at its point; the seven values come
-// back by readlane and are summed in the reference's order (accum += weight * noise, material.rs:379-390: scaling the point and the
-// weight by powers of two is exact, so octave j alone computes what iteration j of the loop does).  texture_value uses the value
-// only for the texture and point it was made for and runs the loop itself otherwise (lists, instanced objects, SpecDiffuse picks).
+// noise texture are found ahead of the material code (a sphere hit outside any instance: its point is o + d*T; the lineariser lists
+// the few spheres with a noise material) and, nine of them per round, 63 helper lanes each evaluate one octave of one of them; points
+// and values travel by ds_bpermute and each served lane sums its seven values in the reference's order (accum += weight * noise,
+// material.rs:379-390: scaling the point and the weight by powers of two is exact, so octave j alone computes what iteration j of the
+// loop does).  texture_value uses the value only for the texture and point it was made for and runs the loop itself otherwise (lists,
+// instanced objects, SpecDiffuse picks).  C3: 763 -> 799 Msamples/s (with ONE octave instead of seven, i.e. no turbulence cost left
+// to remove, it would be 809).
 template <uint32_t F, class Mem>
 __device__ __forceinline__ PreTurb cooperative_turb(const Lane &L, const DScene &S, const Mem &M, bool is_shade, uint32_t lane) {
     PreTurb pt = no_pre_turb();
@@ -218,32 +220,55 @@ __device__ __forceinline__ PreTurb cooperative_turb(const Lane &L, const DScene 
         if (!(S.features & VKF_NOISE)) return pt;          // (wave-uniform) no noise texture in this scene: nothing to prepare
         uint32_t perlin = 0u;
         if (is_shade && L.best_prim != 0u && VKD_KIND(L.best_prim) == DK_SPHERE && (!(F & VKF_INSTANCE) || L.best_inst < 0)) {
-            const DMaterial &m = S.materials[M.smat(VKD_INDEX(L.best_prim))];
-            if (m.tex_kind == VK_TEX_NOISE && m.kind != VK_MAT_DIELECTRIC && m.kind != VK_MAT_SPEC_DIFFUSE) {
+            const uint32_t idx = VKD_INDEX(L.best_prim);
+            if (S.n_noise_spheres != 0xFFFFFFFFu) {        // the scene's (few) spheres with a noise material, from the lineariser
+                for (uint32_t k = 0; k < 4u; k++)
+                    if (k < S.n_noise_spheres && idx == S.noise_sphere[k]) { pt.tex = S.noise_tex[k]; perlin = S.noise_perlin[k]; }
+            } else {
+                const DMaterial &m = S.materials[M.smat(idx)];
+                if (m.tex_kind == VK_TEX_NOISE) { pt.tex = m.tex; perlin = S.textures[m.tex].a; }
+            }
+            if (pt.tex != 0xFFFFFFFFu) {
                 V3 p = L.o + L.d * L.T;                    // simple_record's R.p for a sphere
-                pt.tex = m.tex; pt.px = p.x; pt.py = p.y; pt.pz = p.z;
-                perlin = S.textures[m.tex].a;
+                pt.px = p.x; pt.py = p.y; pt.pz = p.z;
             }
         }
         unsigned long long todo = __builtin_amdgcn_uicmp(pt.tex, 0xFFFFFFFFu, 33 /* ne */);
-        while (todo != 0ull) {                             // wave-uniform: every lane of the wave is here
-            const int src = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            const float sx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(pt.px), src));
-            const float sy = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(pt.py), src));
-            const float sz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(pt.pz), src));
-            const uint32_t sp = (uint32_t)__builtin_amdgcn_readlane((int)perlin, src);
-            float n = 0.0f;
-            if (lane < 7u) {
-                const float sc = (float)(1u << lane);      // the point of octave `lane`: p * 2^lane, exactly what six doublings give
-                n = perlin_noise(S.perlins[sp], v3(sx * sc, sy * sc, sz * sc));
+        if (todo != 0ull) {                                // wave-uniform: every lane of the wave is here
+            // Up to nine lanes' turbulences per round: helper lane h < 63 evaluates octave h % 7 for the (h / 7)-th of them, so that
+            // the noise evaluation — two dependent rounds of gathers — is paid once per round, not once per lane that needs one
+            const uint32_t my_rank = (uint32_t)__builtin_popcountll(todo & ((1ull << lane) - 1ull));   // of a lane that needs one
+            const uint32_t my_slot = lane / 7u, my_octave = lane - 7u * my_slot;
+            uint32_t base = 0u;
+            while (todo != 0ull) {
+                uint32_t my_src = 0u; bool helper = false;
+                for (uint32_t sl = 0; sl < 9u; sl++) {
+                    if (todo == 0ull) break;               // (uniform)
+                    const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    if (my_slot == sl) { my_src = src; helper = true; }
+                }
+                const int sa = (int)(my_src << 2);
+                const float sx = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)__float_as_uint(pt.px)));
+                const float sy = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)__float_as_uint(pt.py)));
+                const float sz = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)__float_as_uint(pt.pz)));
+                const uint32_t sp = (uint32_t)__builtin_amdgcn_ds_bpermute(sa, (int)perlin);
+                float n = 0.0f;
+                if (helper) {
+                    const float sc = (float)(1u << my_octave); // the point of this octave: p * 2^octave, exactly what the doublings give
+                    n = perlin_noise(S.perlins[sp], v3(sx * sc, sy * sc, sz * sc));
+                }
+                // the lanes served this round sum their seven values in the reference's order
+                const uint32_t slot = my_rank - base;      // (meaningful for lanes with a pending request of this round only)
+                float accum = 0.0f, weight = 1.0f;
+                for (uint32_t j = 0; j < 7u; j++) {
+                    const int ga = (int)(((slot < 9u ? slot : 0u) * 7u + j) << 2);
+                    accum += weight * __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(ga, (int)__float_as_uint(n)));
+                    weight *= 0.5f;
+                }
+                if (pt.tex != 0xFFFFFFFFu && slot < 9u) pt.val = fabsf(accum);     // (my_rank >= base for lanes not served yet; < base wraps to huge)
+                base += 9u;
             }
-            float accum = 0.0f, weight = 1.0f;
-            for (int j = 0; j < 7; j++) {
-                accum += weight * __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(n), j));
-                weight *= 0.5f;
-            }
-            if ((int)lane == src) pt.val = fabsf(accum);
         }
     }
     return pt;

@@ -25,6 +25,8 @@ DScene LinearScene::host_view() const {
     s.features = features;
     s.tie_rank = tie_rank.empty() ? nullptr : tie_rank.data();
     s.tie_base_rect = tie_base_rect; s.tie_base_box = tie_base_box; s.tie_base_list = tie_base_list;
+    s.n_noise_spheres = n_noise_spheres;
+    for (int k = 0; k < 4; k++) { s.noise_sphere[k] = noise_sphere[k]; s.noise_tex[k] = noise_tex[k]; s.noise_perlin[k] = noise_perlin[k]; }
     return s;
 }
 
@@ -621,6 +623,13 @@ struct Builder {
             if (s.material >= d->n_materials) return fail(VK_ERR_BAD_ARG, "material index out of range");
             L.spheres.push_back(DSphere{s.center[0], s.center[1], s.center[2], s.radius});
             L.sphere_mat.push_back(s.material);
+            const DMaterial &sm = L.materials[s.material];
+            if (sm.tex_kind == VK_TEX_NOISE && L.n_noise_spheres != 0xFFFFFFFFu) {       // (tex_kind is only set for materials that read a texture)
+                if (L.n_noise_spheres < 4u) {
+                    L.noise_sphere[L.n_noise_spheres] = i; L.noise_tex[L.n_noise_spheres] = sm.tex; L.noise_perlin[L.n_noise_spheres] = L.textures[sm.tex].a;
+                    L.n_noise_spheres++;
+                } else L.n_noise_spheres = 0xFFFFFFFFu;
+            }
         }
         for (uint32_t i = 0; i < d->n_moving_spheres; i++) {
             const vk_moving_sphere &s = d->moving_spheres[i];
