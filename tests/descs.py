@@ -33,6 +33,23 @@ class Desc:
         self.textures.append(ffi.Texture(ffi.VK_TEX_IMAGE, ffi.F3(0, 0, 0), len(self.images) - 1, 0, 0.0))
         return len(self.textures) - 1
 
+    def noise(self, scale, seed=0):
+        """NoiseTexture (material.rs:416-434) over a seeded Perlin table (material.rs:355-377: 256 unit vectors, three permutations)"""
+        rng = np.random.default_rng(1000 + seed)
+        pl = ffi.Perlin()
+        v = rng.uniform(-1, 1, (256, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        for k in range(256):
+            for c in range(3):
+                pl.ranvec[k][c] = float(np.float32(v[k, c]))
+        for name in ("perm_x", "perm_y", "perm_z"):
+            perm = rng.permutation(256)
+            for k in range(256):
+                getattr(pl, name)[k] = int(perm[k])
+        self.perlins.append(pl)
+        self.textures.append(ffi.Texture(ffi.VK_TEX_NOISE, ffi.F3(0, 0, 0), len(self.perlins) - 1, 0, float(scale)))
+        return len(self.textures) - 1
+
     def mat(self, kind, tex=0, param=0.0, a=0, b=0):
         self.materials.append(ffi.Material(kind, tex, param, a, b))
         return len(self.materials) - 1

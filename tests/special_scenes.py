@@ -118,5 +118,29 @@ def scatter_sky():
     return d, desc, cam, params(48, 32, 8, integrator=ffi.VK_INTEGRATOR_SCATTER, background=ffi.VK_BACKGROUND_SKY)
 
 
-ALL = {"nested_transforms": nested_transforms, "lights_and_specdiffuse": lights_and_specdiffuse,
+def noise_everywhere():
+    """Perlin noise textures wherever one can sit: on more spheres than the lineariser's noise-sphere list holds (the device then
+    looks the material up), on a rect, on a Boxy, on a sphere under a transform, behind a checker, inside a SpecDiffuse and on a
+    moving sphere; two Perlin tables.  The device works the turbulence of plain sphere hits out ahead of the material code, seven
+    octaves on seven lanes (vk_kernels.h cooperative_turb), and must fall back to the serial loop for all the others."""
+    d = Desc()
+    lights = []
+    refs = _room(d, lights)
+    n1, n2 = d.noise(4.0, 1), d.noise(0.7, 2)
+    for k in range(6):
+        refs.append(d.sphere((1.5 + 1.4 * k, 1.0 + 0.3 * k, 3.0 + 0.5 * (k % 3)), 0.7, d.mat(ffi.VK_MAT_LAMBERTIAN, n1 if k % 2 else n2)))
+    refs.append(d.rect(2.0, 8.0, 2.0, 8.0, 9.5, (0, 1, 2), d.mat(ffi.VK_MAT_LAMBERTIAN, n1)))
+    refs.append(d.boxy((0.5, 0.0, 6.0), (2.5, 2.0, 8.0), d.mat(ffi.VK_MAT_LAMBERTIAN, n2)))
+    refs.append(d.translate(d.rotate(d.sphere((0, 0, 0), 1.0, d.mat(ffi.VK_MAT_METAL, n1, 0.2)), 1, 30.0), (7.5, 6.5, 6.0)))
+    refs.append(d.sphere((5.0, 7.5, 5.0), 1.0, d.mat(ffi.VK_MAT_LAMBERTIAN, d.checker(n2, d.solid(0.9, 0.2, 0.2)))))
+    sd = d.mat(ffi.VK_MAT_SPEC_DIFFUSE, 0, 0.5, d.mat(ffi.VK_MAT_METAL, d.solid(0.9, 0.9, 0.9), 0.0), d.mat(ffi.VK_MAT_LAMBERTIAN, n1))
+    refs.append(d.sphere((2.5, 6.5, 4.0), 1.0, sd))
+    refs.append(d.moving_sphere((8, 2, 3), (8.5, 2, 3), 0.0, 1.0, 0.8, d.mat(ffi.VK_MAT_LAMBERTIAN, n2)))
+    world = _bvh_chain(d, refs)
+    desc = d.finish(world, lights)
+    cam = camera((5, 5, -12), (5, 5, 0), vfov=40.0)
+    return d, desc, cam, params(64, 64, 8)
+
+
+ALL = {"nested_transforms": nested_transforms, "noise_everywhere": noise_everywhere, "lights_and_specdiffuse": lights_and_specdiffuse,
        "media_and_textures": media_and_textures, "scatter_sky": scatter_sky}
