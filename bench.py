@@ -135,6 +135,21 @@ def verify_against_oracle(O, hs, cam, img, width, spp, depth, budget_samples=1.5
             "ok": bool(err < 1e-4 and np.isfinite(img).all()), "oracle_seconds": round(time.perf_counter() - t0, 2)}
 
 
+def self_launch(n):
+    """torch.distributed.run with n ranks of this script and this command line, as a child process."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: starting %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ, VK_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,6 +174,11 @@ def main():
                     help="N GPUs from ONE process through vk_scene_create_multi (the library deals tiles, gathers on device 0) "
                          "instead of one process per GPU; run without torchrun")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` (no launcher): start the N ranks ourselves, one process per GPU, as a CHILD process —
+    # never exec: nothing in this process has touched the GPU yet, and nothing will — relay its output and exit with its code.
+    if args.gpus > 1 and "RANK" not in os.environ and not args.in_library:
+        sys.exit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -335,13 +355,24 @@ def main():
             res = {"value": round(value, 2), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
                    "label": label, "integrator": "scatter" if hs.integrator else "pdf", "bvh_items": info.n_items,
                    "scene_in_lds": bool(info.lds_bytes), "verified": verified, "roofline": roof, "cpu_baseline": cpu}
-        if rehearsal and world > 1 and rank == 0:
-            ds1 = DeviceScene(hs.desc, device=0)
-            ref, _ = ds1.render(cam, hs.params(width, spp, depth, seed=2))
-            same = bool((full.cpu().numpy() == ref).all())
-            ds1.close()
-            print(f"rehearsal: gathered {world}-rank image bit-identical to 1-rank render: {same}", file=sys.stderr)
-            assert same
+        if world > 1:
+            # what a driver needs to see that N ranks really ran: every rank's device, and the gathered image against ONE device's
+            # render of the whole frame (bit-identical by construction: order-independent fixed-point pixel sums)
+            names = [None] * world
+            me = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device": torch.cuda.get_device_name(dev_index),
+                  "pci_bus_id": getattr(torch.cuda.get_device_properties(dev_index), "pci_bus_id", None), "pid": os.getpid()}
+            dist.all_gather_object(names, me)
+            if rank == 0:
+                ds1 = DeviceScene(hs.desc, device=dev_index)
+                ref, _ = ds1.render(cam, hs.params(width, spp, depth, seed=2))
+                same = bool((full.cpu().numpy() == ref).all())
+                ds1.close()
+                res["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": names,
+                                      "distinct_devices": len({(n["device_index"]) for n in names}),
+                                      "gathered_image_equals_one_gpu_render": same,
+                                      "self_launched": os.environ.get("VK_BENCH_SELF_LAUNCHED") == "1"}
+                print(f"bench.py: {world} ranks ({dist.get_backend()}), gathered image bit-identical to the 1-GPU render: {same}", file=sys.stderr)
+                assert same, "the gathered multi-rank image differs from the one-GPU render"
         ds.close()
         hs.close()
         return res
@@ -368,6 +399,8 @@ def main():
                        "bvh_builder": args.bvh, "bvh_items": r["bvh_items"], "scene_in_lds": r["scene_in_lds"], "also": also},
             "verified": r["verified"], "roofline": r["roofline"], "cpu_baseline": r["cpu_baseline"],
         }
+        if r.get("distributed"):
+            out["distributed"] = r["distributed"]
         print(json.dumps(out), flush=True)
         if r["verified"] and not r["verified"].get("ok", False):
             print("bench.py: the timed framebuffer does NOT match the oracle", file=sys.stderr)

@@ -15,7 +15,7 @@ extern "C" int emu_render(const vk_scene_desc *desc, const vk_camera *cam, const
 extern "C" const char *emu_last_error(void);
 
 int main() {
-    const char *names[] = {"cornell_box", "final_scene", "random_spheres_iow", "random_spheres_demo", "perlin_demo", "balls_demo"};
+    const char *names[] = {"cornell_box", "final_scene", "random_spheres_iow", "random_spheres_demo", "perlin_demo", "balls_demo", "bowser_demo"};
     for (const char *name : names) {
         vkh_scene *hs = vkh_scene_build(name, 1);
         if (!hs) { fprintf(stderr, "%s: %s\n", name, vkh_last_error()); return 1; }

@@ -52,3 +52,28 @@ def test_hip_iow_regions_match_reference_png_statistical(device, host_scenes):
     rep = G.iow_regions(img)
     print(rep)
     G.check_iow_regions(rep)
+
+
+def test_hip_final_scene_matches_reference_nextweek_png_statistical(device, host_scenes):
+    """final_scene() (scene.rs:732-874) at HEAD's settings — width 900 (main.rs:171), depth 100 (main.rs:29), PDF integrator —
+    rendered by the HIP path at 2000 spp (1.6 G samples) against sample/thenextweek.png: fog haze, light silhouette,
+    motion-blurred sphere, earth texels (the real earthmap), blue medium sphere, Perlin speckle statistics, fuzz-10 metal,
+    the rotated cube of spheres.  The pin of everything C3 has and C4 has not (tests/golden/make_nextweek_regions.py)."""
+    hs, cam = host_scenes("final_scene")
+    ds = DeviceScene(hs.desc)
+    p = hs.params(900, 2000, 100)
+    assert p.height == 900
+    img, st = ds.render(cam, p)
+    ds.close()
+    assert np.isfinite(img).all()
+    rep = G.nextweek_regions(img)
+    print(f"final_scene 900x900x2000: {st.kernel_ms:.0f} ms")
+    for k, v in rep.items():
+        print(k, {a: (np.round(b, 4).tolist() if not isinstance(b, int) else b) for a, b in v.items() if a not in ("mean", "ref")})
+    G.check_nextweek_regions(rep, p.samples_per_pixel)
+    # and the scatter integrator must NOT pass (see the CPU test of the same name)
+    hs2, cam2 = host_scenes("final_scene_nextweek")
+    ds2 = DeviceScene(hs2.desc)
+    img2, _ = ds2.render(cam2, hs2.params(900, 256, 100))
+    ds2.close()
+    assert min(G.nextweek_regions(img2)["haze_upper_right"]["rel"]) > 0.2

@@ -13,8 +13,8 @@ def test_oracle_and_host_under_asan_ubsan(tmp_path):
            [os.path.join(ROOT, "vecchio_amd", "host", f) for f in ("host.cpp", "scene.cpp", "host_api.cpp")] + \
            [os.path.join(ROOT, "tests", "emu", "emu.cpp"), os.path.join(ROOT, "vecchio_amd", "csrc", "vk_linearize.cpp")]
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
-                           "-fno-sanitize-recover=undefined", "-o", str(exe)] + srcs + ["-lpthread"])
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+                           "-fno-sanitize-recover=undefined", "-o", str(exe)] + srcs + ["-lpthread", "-lz"])
+    env = dict(os.environ, VECCHIO_ASSETS=os.path.join(ROOT, "tests", "golden", "assets"), ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
     out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("samples") == 6
+    assert out.stdout.count("samples") == 7

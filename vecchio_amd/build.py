@@ -91,7 +91,7 @@ def build_host(force=False):
     srcs, deps = _host_deps()
     if force or _newer(out, deps, CXXFLAGS):
         os.makedirs(LIB, exist_ok=True)
-        _run_atomic([CXX] + CXXFLAGS + ["-shared", "-o"], out, srcs)
+        _run_atomic([CXX] + CXXFLAGS + ["-shared", "-o"], out, srcs + ["-lz"])   # zlib: the decoded texture images are .ppm.gz
         _stamp(out, deps, CXXFLAGS)
     return out
 

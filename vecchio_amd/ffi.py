@@ -9,6 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
+ASSETS_DIR = os.path.join(os.path.dirname(_HERE), "tests", "golden", "assets")
 
 VK_ABI_VERSION = 2
 VK_OK, VK_ERR_BAD_ARG, VK_ERR_UNSUPPORTED, VK_ERR_HIP, VK_ERR_NO_DEVICE, VK_ERR_OOM = range(6)
@@ -173,6 +174,9 @@ def load_host_lib():
     lib.vkh_write_ppm.restype = C.c_int
     lib.vkh_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
     lib.vkh_to_color.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.vkh_set_assets_dir.argtypes = [C.c_char_p]
+    # the decoded copies of the reference's assets/*.png (data fixtures, tests/golden/make_assets.py)
+    lib.vkh_set_assets_dir((os.environ.get("VECCHIO_ASSETS") or ASSETS_DIR).encode())
     _host = lib
     return lib
 

@@ -3,8 +3,11 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+
+#include <zlib.h>
 
 namespace vecchio {
 
@@ -79,51 +82,61 @@ uint32_t ImageTexture::flatten(FlatBuilder &b) const {
     b.textures.push_back(t);
     return (uint32_t)b.textures.size() - 1;
 }
+// Where ImageTexture::open finds the decoded images: the directory that plays the role of the reference's `assets/`.
+static std::string g_assets_dir;
+void set_assets_dir(const std::string &dir) { g_assets_dir = dir; }
+std::string assets_dir() {
+    if (!g_assets_dir.empty()) return g_assets_dir;
+    const char *e = getenv("VECCHIO_ASSETS");
+    return e && *e ? std::string(e) : std::string("assets");  // relative to the working directory, as in the reference
+}
+
+// A binary 8-bit PPM (P6), plain or gzip'd (zlib's gz* functions read both): the bytes `png::Reader::next_frame` leaves in
+// ImageTexture::buf (material.rs:269-279) — row 0 = top, 3 bytes per pixel.
 std::shared_ptr<ImageTexture> ImageTexture::from_ppm(const std::string &path) {
-    FILE *f = fopen(path.c_str(), "rb");
+    gzFile f = gzopen(path.c_str(), "rb");
     if (!f) throw std::runtime_error("cannot open " + path);
-    char magic[3] = {0, 0, 0};
-    unsigned w = 0, h = 0, maxv = 0;
-    if (fscanf(f, "%2s %u %u %u", magic, &w, &h, &maxv) != 4 || strcmp(magic, "P6") != 0 || maxv != 255 || !w || !h) {
-        fclose(f);
+    auto token = [&]() {  // whitespace-separated header token, '#' comments skipped
+        std::string t;
+        int c;
+        while ((c = gzgetc(f)) != -1) {
+            if (c == '#') { while ((c = gzgetc(f)) != -1 && c != '\n') {} continue; }
+            if (c == ' ' || c == '\t' || c == '\n' || c == '\r') { if (!t.empty()) break; continue; }
+            t.push_back((char)c);
+        }
+        return t;
+    };
+    std::string magic = token();
+    unsigned w = (unsigned)atoi(token().c_str()), h = (unsigned)atoi(token().c_str()), maxv = (unsigned)atoi(token().c_str());
+    if (magic != "P6" || maxv != 255 || !w || !h || w > 65535 || h > 65535) {
+        gzclose(f);
         throw std::runtime_error("not a binary 8-bit PPM: " + path);
     }
-    fgetc(f);
     std::vector<uint8_t> rgb((size_t)w * h * 3);
-    size_t got = fread(rgb.data(), 1, rgb.size(), f);
-    fclose(f);
+    size_t got = 0;
+    while (got < rgb.size()) {
+        int n = gzread(f, rgb.data() + got, (unsigned)std::min<size_t>(rgb.size() - got, 1u << 30));
+        if (n <= 0) break;
+        got += (size_t)n;
+    }
+    gzclose(f);
     if (got != rgb.size()) throw std::runtime_error("short PPM: " + path);
     return std::make_shared<ImageTexture>(w, h, std::move(rgb));
 }
-std::shared_ptr<ImageTexture> ImageTexture::synthetic_earth(uint32_t w, uint32_t h, uint64_t seed) {
-    // Deterministic "continents": a few octaves of value noise thresholded into land/sea/ice.
-    // Stands in for assets/earthmap.png (1024x512 RGB8), which cannot ship to the GPU box.
-    std::vector<uint8_t> rgb((size_t)w * h * 3);
-    auto hash = [seed](int32_t x, int32_t y, int32_t o) {
-        uint64_t k = vk::mix64(seed * 0x9E3779B97F4A7C15ull + ((uint64_t)(uint32_t)x << 32 | (uint32_t)y) + (uint64_t)o * 0xD1B54A32D192ED03ull);
-        return (float)(k >> 40) * (1.0f / 16777216.0f);
-    };
-    for (uint32_t j = 0; j < h; j++)
-        for (uint32_t i = 0; i < w; i++) {
-            float v = 0.0f, amp = 0.5f;
-            for (int o = 0; o < 5; o++) {
-                float cells = (float)(4 << o);
-                float fx = (float)i / (float)w * cells, fy = (float)j / (float)h * cells * 0.5f;
-                int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
-                float tx = fx - (float)x0, ty = fy - (float)y0;
-                int wrap = (int)cells;
-                float a = hash(x0 % wrap, y0, o), bq = hash((x0 + 1) % wrap, y0, o), c = hash(x0 % wrap, y0 + 1, o), d = hash((x0 + 1) % wrap, y0 + 1, o);
-                tx = tx * tx * (3.0f - 2.0f * tx); ty = ty * ty * (3.0f - 2.0f * ty);
-                v += amp * ((a * (1 - tx) + bq * tx) * (1 - ty) + (c * (1 - tx) + d * tx) * ty);
-                amp *= 0.5f;
-            }
-            float lat = fabsf((float)j / (float)h - 0.5f) * 2.0f;
-            uint8_t *p = &rgb[((size_t)j * w + i) * 3];
-            if (lat > 0.88f) { p[0] = 235; p[1] = 240; p[2] = 245; }
-            else if (v > 0.5f) { float g = (v - 0.5f) * 4.0f; p[0] = (uint8_t)(60 + 90 * g); p[1] = (uint8_t)(110 + 40 * g); p[2] = (uint8_t)(50 + 30 * g); }
-            else { float s = v * 2.0f; p[0] = (uint8_t)(10 + 20 * s); p[1] = (uint8_t)(30 + 60 * s); p[2] = (uint8_t)(90 + 110 * s); }
-        }
-    return std::make_shared<ImageTexture>(w, h, std::move(rgb));
+// ImageTexture::new("assets/<name>.png") (material.rs:269-279).  The PNG decode is third-party (`png 0.16.6`, lossless);
+// here the decoded bytes come from <assets_dir>/<name>.ppm.gz (tests/golden/make_assets.py made them from the reference's
+// PNGs), or from <name>.ppm.  A missing file is an error, as it is in the reference (`File::open(path).unwrap()`).
+std::shared_ptr<ImageTexture> ImageTexture::open(const std::string &path) {
+    std::string name = path;
+    size_t slash = name.find_last_of('/');
+    if (slash != std::string::npos) name = name.substr(slash + 1);
+    if (name.size() > 4 && name.compare(name.size() - 4, 4, ".png") == 0) name.resize(name.size() - 4);
+    std::string base = assets_dir() + "/" + name;
+    for (const char *ext : {".ppm.gz", ".ppm"}) {
+        std::string p = base + ext;
+        if (FILE *t = fopen(p.c_str(), "rb")) { fclose(t); return from_ppm(p); }
+    }
+    throw std::runtime_error("cannot open " + base + ".ppm.gz (decoded copy of " + path + "; set VECCHIO_ASSETS or --assets)");
 }
 
 Perlin::Perlin() {  // material.rs:357-377

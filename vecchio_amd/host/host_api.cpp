@@ -39,6 +39,7 @@ vkh_scene *vkh_scene_build(const char *name, uint64_t seed) {
         else if (n == "bowser_demo") s->cfg = bowser_demo();
         else if (n == "cornell_box") s->cfg = cornell_box();
         else if (n == "final_scene") s->cfg = final_scene();
+        else if (n == "final_scene_nextweek") s->cfg = final_scene_nextweek();
         else if (n.rfind("stress_spheres:", 0) == 0) {
             int g = atoi(n.c_str() + 15);
             if (g < 1 || g > 2000) { delete s; g_herr = "stress_spheres grid_half out of range"; return nullptr; }
@@ -56,6 +57,7 @@ vkh_scene *vkh_scene_build(const char *name, uint64_t seed) {
     }
 }
 
+void vkh_set_assets_dir(const char *dir) { set_assets_dir(dir ? dir : ""); }
 void vkh_scene_free(vkh_scene *s) { delete s; }
 const vk_scene_desc *vkh_scene_desc(vkh_scene *s) { return s ? &s->desc : nullptr; }
 int vkh_scene_next_camera(vkh_scene *s, vk_camera *out) {

@@ -12,10 +12,14 @@ extern "C" {
 typedef struct vkh_scene vkh_scene;
 
 /* name: "balls_demo" | "random_spheres_demo" | "random_spheres_iow" | "perlin_demo" |
- *       "cornell_box" | "final_scene" | "stress_spheres:<grid_half>"
+ *       "cornell_box" | "final_scene" | "final_scene_nextweek" | "bowser_demo" | "stress_spheres:<grid_half>"
  * Builds the world list with the seeded build stream, wraps it in BVHNode::new
  * (main.rs:168) and flattens it.  Returns NULL on failure (vkh_last_error()).           */
 vkh_scene *vkh_scene_build(const char *name, uint64_t seed);
+/* directory holding the decoded copies (<name>.ppm.gz / .ppm) of the reference's assets/<name>.png, read by the builders
+ * that call ImageTexture::new (scene.rs:230,355-398,588,822).  Default: $VECCHIO_ASSETS, else "assets" (cwd-relative,
+ * as in the reference).  A missing image fails the build, as File::open(..).unwrap() does (material.rs:270).  */
+void vkh_set_assets_dir(const char *dir);
 void vkh_scene_free(vkh_scene *s);
 const vk_scene_desc *vkh_scene_desc(vkh_scene *s);
 /* next Camera of config.cam_iter (main.rs:176); returns 0 when exhausted */

@@ -3,6 +3,7 @@
 // (the call that replaces main.rs:181-198), write output_%04d.ppm, print the frame time.
 // The reference hard-codes scene/width/spp/depth (main.rs:28-29,159-167,171); here they are
 // arguments:   vecchio_cli <scene> [width=900] [spp=1000] [max_depth=100] [frames=1] [seed=1]
+// Texture images are read from ./assets (as in the reference) or $VECCHIO_ASSETS: <name>.ppm.gz, see host_api.h.
 #include <dlfcn.h>
 
 #include <chrono>
@@ -22,7 +23,7 @@ static T sym(void *h, const char *name) {
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <balls_demo|random_spheres_demo|random_spheres_iow|perlin_demo|cornell_box|final_scene|stress_spheres:N> "
+        fprintf(stderr, "usage: %s <balls_demo|random_spheres_demo|random_spheres_iow|perlin_demo|bowser_demo|cornell_box|final_scene|final_scene_nextweek|stress_spheres:N> "
                         "[width] [spp] [max_depth] [frames] [seed]\n", argv[0]);
         return 2;
     }

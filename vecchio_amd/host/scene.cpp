@@ -55,7 +55,7 @@ SceneConfig random_spheres_demo() {
     }
     world.push_back(std::make_shared<Sphere>(Vec3(0.0f, 1.0f, 0.0f), 1.0f, std::make_shared<Dielectric>(1.5f)));
     world.push_back(std::make_shared<Sphere>(Vec3(-4.0f, 1.0f, 0.0f), 1.0f,
-                                             std::make_shared<Lambertian>(ImageTexture::synthetic_earth(1024, 512, 7))));  // assets/earthmap.png stand-in
+                                             std::make_shared<Lambertian>(ImageTexture::open("assets/earthmap.png"))));
     world.push_back(std::make_shared<Sphere>(Vec3(4.0f, 1.0f, 0.0f), 1.0f, std::make_shared<Metal>(solid(Vec3(0.7f, 0.6f, 0.5f)), 0.0f)));
     auto light = std::make_shared<DiffuseLight>(solid(Vec3(1.0f, 0.77f, 0.56f) * 2.0f));
     auto light_shape = Rect::XZRect(-11.0f, 11.0f, -11.0f, 11.0f, 8.0f, light);
@@ -136,15 +136,15 @@ SceneConfig perlin_demo() {
 
 // scene.rs:340-549: struct Bowser — 5 image-textured rects, a grey bottom, 26 Boxys, in a BVHNode.
 // (The reference wraps the BVH in a Hittable that forwards hit/bounding_box: a no-op here.)
-// assets/bowser_*.png and assets/twitter.png cannot ship: seeded synthetic images of the same role.
+// assets/bowser_*.png and assets/twitter.png: decoded copies, see ImageTexture::open.
 static HittableP bowser_new(float x, float y, float z) {
     std::vector<HittableP> world;
-    auto img = [](uint64_t seed) { return std::make_shared<Lambertian>(ImageTexture::synthetic_earth(256, 256, seed)); };
+    auto img = [](const char *path) { return std::make_shared<Lambertian>(ImageTexture::open(path)); };
     const float y0 = y - 1.875f, zf = z + 4.5f;
-    world.push_back(Rect::XYRect(x - 2.0f, x + 2.0f, y0 + 1.0f, y0 + 4.0f, zf - 3.0f, img(21)));     // face
-    world.push_back(Rect::XZRect(x - 2.0f, x + 2.0f, zf - 6.0f, zf - 3.0f, y0 + 4.0f, img(22)));     // top
-    world.push_back(Rect::XYRect(x - 2.0f, x + 2.0f, y0 + 1.0f, y0 + 4.0f, zf - 6.0f, img(23)));     // back
-    auto side = img(24);
+    world.push_back(Rect::XYRect(x - 2.0f, x + 2.0f, y0 + 1.0f, y0 + 4.0f, zf - 3.0f, img("assets/bowser_face.png")));     // face
+    world.push_back(Rect::XZRect(x - 2.0f, x + 2.0f, zf - 6.0f, zf - 3.0f, y0 + 4.0f, img("assets/bowser_top.png")));     // top
+    world.push_back(Rect::XYRect(x - 2.0f, x + 2.0f, y0 + 1.0f, y0 + 4.0f, zf - 6.0f, img("assets/bowser_back.png")));     // back
+    auto side = img("assets/bowser_side.png");
     world.push_back(Rect::YZRect(y0 + 1.0f, y0 + 4.0f, zf - 6.0f, zf - 3.0f, x - 2.0f, side));       // sides share one texture
     world.push_back(Rect::YZRect(y0 + 1.0f, y0 + 4.0f, zf - 6.0f, zf - 3.0f, x + 2.0f, side));
     auto grey = lambert(Vec3(0.278f, 0.387f, 0.438f));
@@ -193,7 +193,7 @@ SceneConfig bowser_demo() {
     world.push_back(std::make_shared<Translate>(RotateX(RotateY(RotateZ(bowser_new(0.0f, 0.0f, 0.0f), 0.0f), 0.0f), 0.0f),
                                                 Vec3(0.0f, 1.625f, -4.5f)));
     auto light_shape = Rect::XYRect(-2.0f, 2.0f, 1.0f, 4.0f, 3.0f,
-                                    std::make_shared<DiffuseLight>(ImageTexture::synthetic_earth(128, 128, 25)));   // image-textured emitter
+                                    std::make_shared<DiffuseLight>(ImageTexture::open("assets/twitter.png")));   // image-textured emitter, scene.rs:585-590
     world.push_back(std::make_shared<FlipFace>(light_shape));
     cfg.lights.push_back(light_shape);
     float aspect_ratio = 16.0f / 9.0f;
@@ -262,7 +262,7 @@ SceneConfig final_scene() {
     objects.push_back(std::make_shared<ConstantMedium>(boundary1, 0.2f, solid(Vec3(0.2f, 0.4f, 0.9f))));
     auto boundary2 = std::make_shared<Sphere>(Vec3::new_const(0.0f), 5000.0f, std::make_shared<Dielectric>(1.5f));
     objects.push_back(std::make_shared<ConstantMedium>(boundary2, 0.0001f, solid(Vec3::new_const(1.0f))));
-    auto emat = std::make_shared<Lambertian>(ImageTexture::synthetic_earth(1024, 512, 7));  // assets/earthmap.png stand-in
+    auto emat = std::make_shared<Lambertian>(ImageTexture::open("assets/earthmap.png"));  // scene.rs:821-823
     objects.push_back(std::make_shared<Sphere>(Vec3(400.0f, 200.0f, 400.0f), 100.0f, emat));
     auto pertext = std::make_shared<NoiseTexture>(0.1f);
     objects.push_back(std::make_shared<Sphere>(Vec3(220.0f, 280.0f, 300.0f), 80.0f, std::make_shared<Lambertian>(pertext)));
@@ -273,6 +273,18 @@ SceneConfig final_scene() {
     float aspect_ratio = 1.0f;
     cfg.cam_iter = FixedCamera(camera_new(Vec3(478.0f, 278.0f, -600.0f), Vec3(278.0f, 278.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), 40.0f, aspect_ratio, 0.0f, 10.0f, 0.0f, 1.0f));
     cfg.aspect_ratio = aspect_ratio;
+    return cfg;
+}
+
+// The configuration sample/thenextweek.png was rendered with (README.md:9-15): the same objects, but the TheNextWeek tag
+// predates the PDF integrator — ray_color = emitted + attenuation * ray_color(scattered) through Material::scatter
+// (material.rs:21-28), black background.  (The tag itself is unreadable; the picture's light quad, fog and sphere
+// placement are HEAD's, which tests/test_golden_nextweek.py checks.)
+SceneConfig final_scene_nextweek() {
+    SceneConfig cfg = final_scene();
+    cfg.integrator = VK_INTEGRATOR_SCATTER;
+    cfg.background = VK_BACKGROUND_SOLID;
+    cfg.background_color = Vec3::new_const(0.0f);
     return cfg;
 }
 

@@ -124,13 +124,16 @@ class Checker : public Texture {  // material.rs:244-248
     Checker(TextureP o, TextureP e) : odd(o), even(e) {}
     uint32_t flatten(FlatBuilder &b) const override;
 };
+// the directory ImageTexture::open reads (default: $VECCHIO_ASSETS, else "assets" as in the reference)
+void set_assets_dir(const std::string &dir);
+std::string assets_dir();
 class ImageTexture : public Texture {  // material.rs:261-280 (png decode replaced: raw RGB8 or binary PPM)
   public:
     std::vector<uint8_t> buf;
     uint32_t width = 0, height = 0;
     ImageTexture(uint32_t w, uint32_t h, std::vector<uint8_t> rgb) : buf(std::move(rgb)), width(w), height(h) {}
-    static std::shared_ptr<ImageTexture> from_ppm(const std::string &path);   // P6
-    static std::shared_ptr<ImageTexture> synthetic_earth(uint32_t w, uint32_t h, uint64_t seed);  // stand-in for assets/earthmap.png
+    static std::shared_ptr<ImageTexture> open(const std::string &path);       // ImageTexture::new("assets/x.png"): <assets_dir>/x.ppm.gz
+    static std::shared_ptr<ImageTexture> from_ppm(const std::string &path);   // P6, plain or gzip'd
     uint32_t flatten(FlatBuilder &b) const override;
 };
 class Perlin {  // material.rs:306-377
@@ -327,9 +330,10 @@ std::function<bool(vk_camera &)> RotatingCamera(Vec3 lookat, Vec3 vup, float vfo
 SceneConfig balls_demo();            // scene.rs:93-165
 SceneConfig random_spheres_demo();   // scene.rs:167-284 (HEAD: checker ground, earth, sky light, PDF integrator)
 SceneConfig perlin_demo();           // scene.rs:286-338
-SceneConfig bowser_demo();           // scene.rs:340-628 (PNG assets replaced by seeded synthetic images)
+SceneConfig bowser_demo();           // scene.rs:340-628 (PNG assets: decoded copies, ImageTexture::open)
 SceneConfig cornell_box();           // scene.rs:630-730
 SceneConfig final_scene();           // scene.rs:732-874
+SceneConfig final_scene_nextweek();  // the same with the TheNextWeek tag's integrator (scatter + emitted, black background)
 // InOneWeekend-tag variant of random_spheres_demo (sphere-only, sky background, aperture 0.1;
 // BASELINE configs C1/C2) and its 1M-sphere extension (C5).  grid_half = 11 is the book scene.
 SceneConfig random_spheres_iow(int grid_half);
