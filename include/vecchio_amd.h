@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 2
+#define VK_ABI_VERSION 3
 
 /* ---- status codes (reference convention is panic!/unwrap, main.rs:166,202) ---------- */
 enum {
@@ -234,6 +234,13 @@ typedef struct vk_stats {
     double kernel_ms;          /* HIP-event time of the megakernel launch(es)    */
     uint32_t kernel_launches;
     uint32_t scene_in_lds;     /* 1 if the linear BVH + primitives were LDS-resident */
+    /* ABI 3.  Pixel sums (`c += color`, main.rs:193) are kept as 64-bit fixed point with 2^-26 resolution so that they do not
+     * depend on the order samples finish in: a sample component below 2^-26 (1.5e-8) adds 0, and a component beyond
+     * +-min(1e10, 1.3e11 / samples_per_pixel) is CLAMPED to that (the sums saturate, they never wrap).  The reference adds such
+     * a sample in f32; this counts the samples of the call that were clamped (0 on every BASELINE config): non-zero means the
+     * frame's brightest pixels deviate from the reference's.  vk_render fills it; after vk_render_device use
+     * vk_scene_last_clamped_samples().                                                                                     */
+    uint64_t clamped_samples;
 } vk_stats;
 
 typedef struct vk_scene vk_scene;  /* opaque */
@@ -300,6 +307,9 @@ int vk_scene_get_info(const vk_scene *scene, vk_scene_info *out);
  * this scene, on the stream they were launched on; waits for their end event.  (For a
  * multi-device scene: the slowest device's time.)                                         */
 int vk_scene_last_kernel_ms(vk_scene *scene, double *ms_out);
+
+/* see vk_stats.clamped_samples; waits for the end of the last render enqueued on this scene */
+int vk_scene_last_clamped_samples(vk_scene *scene, uint64_t *count_out);
 
 /* test/diagnostic entry points (vk_debug_*) are declared in vecchio_amd_debug.h */
 

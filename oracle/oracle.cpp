@@ -1122,18 +1122,22 @@ static int oracle_render_impl(const vk_scene_desc *desc, const vk_camera *cam_in
     if (n_threads < 1) n_threads = 1;
     const uint32_t tiles_x = (p.width + 7) / 8;
     const uint32_t tile_world = p.tile_world ? p.tile_world : 1;
-    std::atomic<uint32_t> next_row(0);
+    const uint32_t tiles_y = (p.height + 7) / 8;
+    // rayon's par_iter_mut over pixels (main.rs:181) = dynamic stealing; the stand-in's unit is one 8x8 tile (a row would leave
+    // 1080 units for 256 threads)
+    std::atomic<uint32_t> next_tile(0);
     std::atomic<int> panicked(0);
     std::vector<oracle_counters> per_thread(n_threads);
     auto worker = [&](int tid) {
         g_cnt = oracle_counters();
         g_panic = false;
         for (;;) {
-            uint32_t y = next_row.fetch_add(1);
-            if (y >= p.height) break;
-            for (uint32_t x = 0; x < p.width; x++) {
-                uint32_t tile = (y / 8) * tiles_x + (x / 8);
-                if (tile % tile_world != p.tile_rank % tile_world) continue;
+            uint32_t tile = next_tile.fetch_add(1);
+            if (tile >= tiles_x * tiles_y) break;
+            if (tile % tile_world != p.tile_rank % tile_world) continue;
+            const uint32_t x0 = (tile % tiles_x) * 8, y0 = (tile / tiles_x) * 8;
+            for (uint32_t y = y0; y < y0 + 8 && y < p.height; y++)
+            for (uint32_t x = x0; x < x0 + 8 && x < p.width; x++) {
                 uint32_t i = y * p.width + x;  // main.rs:182-183
                 Vec3 c = Vec3::new_const(0.0f);
                 for (uint32_t s = 0; s < p.samples_per_pixel; s++) {  // main.rs:186

@@ -51,7 +51,7 @@ def render(desc, cam, params, threads=None):
     lib = load()
     out = np.zeros((params.height, params.width, 3), dtype=np.float32)
     cnt = Counters()
-    threads = threads or (os.cpu_count() or 1)
+    threads = threads or min(len(os.sched_getaffinity(0)), 32)
     st = lib.oracle_render(desc, C.byref(cam), C.byref(params), out.ctypes.data_as(C.c_void_p), threads, C.byref(cnt))
     if st != 0:
         raise RuntimeError(f"oracle status {st}: {lib.oracle_last_error().decode()}")
@@ -66,7 +66,7 @@ def render_samples(desc, cam, params, threads=None):
                                           C.c_void_p, C.c_void_p, C.c_int]
     img = np.zeros((params.height, params.width, 3), dtype=np.float32)
     ps = np.zeros((params.width * params.height * params.samples_per_pixel, 4), dtype=np.float32)
-    st = lib.oracle_render_samples(desc, C.byref(cam), C.byref(params), img.ctypes.data, ps.ctypes.data, threads or (os.cpu_count() or 1))
+    st = lib.oracle_render_samples(desc, C.byref(cam), C.byref(params), img.ctypes.data, ps.ctypes.data, threads or min(len(os.sched_getaffinity(0)), 32))
     if st != 0:
         raise RuntimeError(f"oracle status {st}: {lib.oracle_last_error().decode()}")
     return img, ps

@@ -127,3 +127,48 @@ def test_max_depth_zero_and_one(device, oracle, host_scenes):
             if depth == 0:
                 assert ref.max() == 0.0 and got.max() == 0.0
         ds.close()
+
+
+def test_firefly_samples_saturate_and_are_counted(device):
+    """ABI 3: a light of radiance 4e10 seen directly.  Every sample that hits it exceeds the accumulator's per-sample clamp
+    (min(1e10, 1.3e11 / spp)): the pixel sums SATURATE (no int64 wrap: the pixel stays huge, where a wrapped sum would come
+    out negative -> NaN -> black) and vk_stats.clamped_samples counts them; a frame without such samples reports 0."""
+    from descs import Desc, camera, params
+    d = Desc()
+    hot = d.light(4e10, 4e10, 4e10)
+    q = d.xy_rect(-1.0, 1.0, -1.0, 1.0, 0.0, hot)
+    grey = d.sphere((0.0, -101.0, 0.0), 100.0, d.lambertian(0.5, 0.5, 0.5))
+    desc = d.finish(d.big_box(q, grey), [q])
+    cam = camera((0, 0, 6), (0, 0, 0), vfov=30.0)
+    ds = DeviceScene(desc)
+    for spp in (4, 64):
+        p = params(32, 32, spp, max_depth=4, integrator=ffi.VK_INTEGRATOR_SCATTER)
+        img, st = ds.render(cam, p)
+        clampv = min(1e10, 1.3e11 / spp)
+        centre = img[12:20, 12:20]                       # the quad covers the middle of the frame
+        assert np.isfinite(img).all() and img.min() >= 0.0
+        assert np.allclose(centre, clampv, rtol=1e-6), (spp, centre.min(), centre.max())
+        assert st.clamped_samples >= 64 * spp
+        n = C.c_uint64()
+        assert ds._lib.vk_scene_last_clamped_samples(ds._h, C.byref(n)) == ffi.VK_OK and n.value == st.clamped_samples
+    # an ordinary frame: nothing clamped
+    d2 = Desc()
+    l2 = d2.light(7.0, 7.0, 7.0)
+    q2 = d2.xy_rect(-1.0, 1.0, -1.0, 1.0, 0.0, l2)
+    desc2 = d2.finish(d2.big_box(q2, d2.sphere((0.0, -101.0, 0.0), 100.0, d2.lambertian(0.5, 0.5, 0.5))), [q2])
+    ds2 = DeviceScene(desc2)
+    _, st2 = ds2.render(cam, params(32, 32, 16, max_depth=4, integrator=ffi.VK_INTEGRATOR_SCATTER))
+    assert st2.clamped_samples == 0
+    ds.close(); ds2.close()
+
+
+def test_unit_count_stays_below_32_bits(device, host_scenes):
+    """tiles x sample chunks is a 32-bit counter: 4096 x 4096 at 2^20 spp would need 4.3 G units at 64 spp per unit.  The call is
+    accepted (the chunks grow) — checked on a partition small enough to render: every 100 000th tile of that frame."""
+    hs, cam = host_scenes("random_spheres_iow")
+    ds = DeviceScene(hs.desc)
+    p = hs.params(4096, 1 << 20, 2, height=4096, tile_rank=7, tile_world=100000)
+    img, st = ds.render(cam, p)
+    assert st.samples == 3 * 64 * (1 << 20)             # tiles 7, 100 007, 200 007 of 262 144
+    assert np.isfinite(img).all()
+    ds.close()

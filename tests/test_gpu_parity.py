@@ -204,11 +204,26 @@ def test_full_frame_per_sample_c2(device, oracle, host_scenes):
     ds.close()
 
 
+def test_c1_full_spp_every_pixel(device, oracle, host_scenes):
+    """BASELINE C1 exactly — InOneWeekend random spheres 400x225, 100 spp, depth 50 — the one config small enough for the
+    oracle to render in full: every pixel of the HIP frame at the FULL spp against the oracle (9 M samples)."""
+    hs, cam = host_scenes("random_spheres_iow")
+    ds = DeviceScene(hs.desc)
+    p = hs.params(400, 100, 50)
+    assert (p.width, p.height) == (400, 225)
+    img, st = ds.render(cam, p)
+    ds.close()
+    ref, cnt = oracle.render(hs.desc, cam, p)
+    assert st.samples == cnt.samples == 400 * 225 * 100
+    assert np.isfinite(img).all()
+    assert np.abs(img - ref).max() < TOL
+
+
 def sparse_oracle(oracle, desc, cam, p_full, hs, rank, world, threads=None):
     """oracle render of the tiles t with t % world == rank only; returns (image with -1 elsewhere, mask)"""
     po = hs.params(p_full.width, p_full.samples_per_pixel, p_full.max_depth, seed=p_full.seed, height=p_full.height, tile_rank=rank, tile_world=world)
     ref = np.full((p_full.height, p_full.width, 3), -1.0, np.float32)
-    stt = oracle.load().oracle_render(desc, C.byref(cam), C.byref(po), ref.ctypes.data, threads or (os.cpu_count() or 1), None)
+    stt = oracle.load().oracle_render(desc, C.byref(cam), C.byref(po), ref.ctypes.data, threads or min(len(os.sched_getaffinity(0)), 32), None)
     assert stt == 0
     return ref, ref[..., 0] >= 0
 

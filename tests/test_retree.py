@@ -117,3 +117,29 @@ def test_retreed_crowd_on_the_gpu(seed, device, oracle):
     img_o, ps_o = oracle.render_samples(desc, cam, p)
     compare_samples(ps_o, ps_d, img_o, img_d)
     ds.close()
+
+
+def test_hollow_sphere_keeps_the_reference_tree(oracle, emu, built):
+    """A negative-radius sphere (the hollow glass sphere of scene.rs:123-127) has an INVERTED bounding box in the reference
+    (center -/+ radius, hittable.rs:97-102), which shrinks its ancestors' boxes: hits on it depend on the tree handed over.
+    With VK_SCENE_FAST_ACCEL the lineariser must therefore leave a subtree that holds one alone — 24 spheres, one hollow,
+    boxes computed as BVHNode::new's surrounding_box would (accel.rs:117-131)."""
+    g = Crowd(77)
+    g.use_pdf = False
+    objs = []
+    for i in range(24):
+        c = g.pos().astype(np.float32)
+        rad = np.float32(-0.9 if i == 11 else g.r.uniform(0.3, 1.0))
+        ref = g.d.sphere(tuple(c), float(rad), g.surface[4] if i == 11 else g.mat())
+        objs.append((ref, (c - rad, c + rad)))                      # inverted for the hollow one, as the reference computes it
+    world, _ = g.tree(objs)
+    desc = g.d.finish(world, [])
+    cam = camera((18, 6, 14), (5, 5, 5), vfov=50.0)
+    p = params(24, 20, 4, max_depth=12, seed=5, integrator=ffi.VK_INTEGRATOR_SCATTER, background=ffi.VK_BACKGROUND_SKY)
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    img_r, ps_r, steps_r, info_r = emu.render_samples(desc, cam, p)            # flags = 0
+    compare(ps_o, ps_r, img_o, img_r)
+    desc.contents.flags = ffi.VK_SCENE_FAST_ACCEL
+    img_e, ps_e, steps, info = emu.render_samples(desc, cam, p)
+    compare(ps_o, ps_e, img_o, img_e)
+    assert (info[0], steps) == (info_r[0], steps_r)                           # not rebuilt: the very same walk

@@ -310,6 +310,12 @@ uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
     if (s->env.chunk_cap >= 1) cap = (uint32_t)s->env.chunk_cap;   // diagnostics
     uint32_t lo = cap < 32 ? cap : 32;
     uint32_t chunk_spp = (uint32_t)(c > cap ? cap : (c < lo ? lo : c));
+    // the unit counter is 32 bits wide: tiles x chunks must stay below 2^32 (4096 x 4096 at 2^20 spp would not at 64 spp per unit)
+    {
+        const uint64_t n_local = tiles / (p->tile_world ? p->tile_world : 1u) + 1u;
+        const uint64_t min_chunk = ((uint64_t)p->samples_per_pixel * n_local + 0xE0000000ull - 1u) / 0xE0000000ull;
+        if (chunk_spp < min_chunk) chunk_spp = (uint32_t)min_chunk;
+    }
     uint32_t n = (p->samples_per_pixel + chunk_spp - 1) / chunk_spp;
     if (n < 1) n = 1;
     return n;
@@ -333,6 +339,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     A.n_local_tiles = g.n_local;
     A.n_chunks = choose_chunks(s, p);
     A.counter = s->counter;
+    A.clamped = reinterpret_cast<unsigned long long *>(s->counter) + 1;     // bytes 8..15 of the counter block
     A.shade_defer = SHADE_DEFER;          // (C5: 1 / 2 / 4 / 8 -> 573 / 588 / 593 / 603-at-pw-2)
     if (s->env.shade_defer >= 1 && s->env.shade_defer <= 64) A.shade_defer = (uint32_t)s->env.shade_defer;   // diagnostics
     // scenes beyond an XCD's L2 (C5: a leaf every 6 box steps, every gather a possible L2 miss): pending sphere tests are served
@@ -356,6 +363,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     HIP_TRY(hipEventRecord(s->ev0, st));
     if (p->max_depth == 0) {
         // ray_color returns (0,0,0) before tracing anything when depth (1) > MAX_DEPTH (main.rs:126-128): a black partition
+        HIP_TRY(hipMemsetAsync(s->counter, 0, 16, st));
         int rc = tile_move<TM_ZERO_F32>(nullptr, d_out, p, g, st);
         if (rc != VK_OK) return rc;
         HIP_TRY(hipEventRecord(s->ev1, st));
@@ -388,10 +396,11 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     size_t shmem = (size_t)waves_per_wg * per_wave_lds_bytes(pick_variant(s));
     if (lds) { A.lds_items = s->dev.n_items; A.lds_spheres = s->dev.n_spheres; A.lds_boxes = s->dev.n_boxes; shmem += s->lds_bytes; }
     // persistent grid: enough workgroups to fill the chip, never more than there are units
-    uint32_t n_units = A.n_local_tiles * A.n_chunks;
+    const uint64_t n_units = (uint64_t)A.n_local_tiles * A.n_chunks;
+    if (n_units >= 0xFFFFFFFFull) return fail(VK_ERR_BAD_ARG, "tiles x sample chunks exceeds the 32-bit unit counter");    // (choose_chunks keeps it below)
     uint32_t grid = (uint32_t)s->num_cus * s->wgs_per_cu;
-    uint32_t need_wgs = (n_units + waves_per_wg - 1) / waves_per_wg;
-    if (grid > need_wgs) grid = need_wgs;
+    uint64_t need_wgs = (n_units + waves_per_wg - 1) / waves_per_wg;
+    if (grid > need_wgs) grid = (uint32_t)need_wgs;
     if (grid < 1) grid = 1;
 
     int rc = VK_OK;
@@ -424,7 +433,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         HIP_TRY(hipGetLastError());
         A.tile_order = s->tile_order;
     }
-    HIP_TRY(hipMemsetAsync(s->counter, 0, sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(s->counter, 0, 16, st));       // work counter + this frame's clamped-sample count
     if (s->want_phase_stats) {
         const uint32_t FULLPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
         if (F != 0u && F != FULLPDF)
@@ -741,6 +750,28 @@ int vk_scene_last_kernel_ms(vk_scene *s, double *ms_out) {
     return VK_OK;
 }
 
+// Samples of the last render whose radiance was clamped on its way into the fixed-point pixel sums; waits for the render's end.
+int vk_scene_last_clamped_samples(vk_scene *s, uint64_t *out) {
+    if (!s || !out) return fail(VK_ERR_BAD_ARG, "null argument");
+    if (!s->last_timed) return fail(VK_ERR_BAD_ARG, "no render enqueued yet");
+    *out = 0;
+    if (!s->parts.empty()) {
+        for (vk_scene *q : s->parts) {
+            uint64_t v = 0;
+            int rc = vk_scene_last_clamped_samples(q, &v);
+            if (rc != VK_OK) return rc;
+            *out += v;
+        }
+        return VK_OK;
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, reinterpret_cast<unsigned long long *>(s->counter) + 1, sizeof(v), hipMemcpyDeviceToHost));
+    *out = v;
+    return VK_OK;
+}
+
 static int render_host(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, void *out_host, vk_stats *stats_out, float *debug_out) {
     if (!out_host) return fail(VK_ERR_BAD_ARG, "null framebuffer");
     int rc = check_render_args(scene, cam, params);
@@ -764,6 +795,8 @@ static int render_host(vk_scene *scene, const vk_camera *cam, const vk_render_pa
     rc = vk_scene_last_kernel_ms(scene, &ms);
     if (rc != VK_OK) return rc;
     st.kernel_ms = ms;
+    rc = vk_scene_last_clamped_samples(scene, &st.clamped_samples);
+    if (rc != VK_OK) return rc;
     HIP_TRY(hipSetDevice(scene->device));
     uint32_t world = params->tile_world ? params->tile_world : 1;
     if (world == 1) {

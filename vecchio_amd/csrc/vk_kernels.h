@@ -40,6 +40,7 @@ struct KArgs {
     long long *accum;        // [width*height*3] fixed-point pixel sums (see to_fixed); null in the probe launch
     float4 *debug;           // optional per-sample (rgb, draws) dump
     uint32_t *counter;       // work-unit counter
+    unsigned long long *clamped;   // number of samples whose radiance was clamped on its way into the fixed-point sums (see to_fixed)
     uint32_t *tile_cost;     // [tiles of the image] time spent on each tile (1.6 us ticks): written by the probe (COST) build only
     const uint32_t *tile_order;   // [n_local_tiles] local tile slots, dearest first (from the probe launch), or null = raster order
     uint32_t tiles_x, tiles_y;
@@ -144,11 +145,15 @@ template <uint32_t F> constexpr uint32_t wave_block_floats() { return 64u * (uin
 // (2^-26 units: 1.5e-8 absolute per sample, sums up to 1.4e11) with integer atomics, so the image does not depend on which
 // lane, wave, work unit, tile partition or GPU traced a sample, nor on the order they finished in — without any lane ever
 // waiting for another one's path.  (The reference's `c += color` in f32, main.rs:193, is re-associated anyway: it never
-// feeds control flow.)  A sample beyond +-1e10 is clamped to it.
+// feeds control flow.)  The sums SATURATE instead of wrapping: a sample's components are clamped to +-min(1e10, 1.3e11 / spp), so
+// that spp of them stay below 2^63 * 2^-26 = 1.37e11, and every clamped sample is counted (vk_stats.clamped_samples): the reference
+// adds such a sample in f32 (main.rs:193) and the caller can tell that this frame deviates from it.
 constexpr float ACCUM_SCALE = 67108864.0f;          // 2^26
 constexpr float ACCUM_CLAMP = 1.0e10f;
-__device__ __forceinline__ long long to_fixed(float v) {
-    v = fminf(fmaxf(v, -ACCUM_CLAMP), ACCUM_CLAMP);
+constexpr float ACCUM_RANGE = 1.3e11f;
+__device__ __forceinline__ float accum_clamp_for(uint32_t spp) { return fminf(ACCUM_CLAMP, ACCUM_RANGE / (float)spp); }
+__device__ __forceinline__ long long to_fixed(float v, float clampv) {
+    v = fminf(fmaxf(v, -clampv), clampv);
     return (long long)(v * ACCUM_SCALE);             // scaling by a power of two is exact; the cast truncates toward zero
 }
 
@@ -305,7 +310,9 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &
             if (dbg) dbg[pix * C.spp + __float_as_uint(cold[CF_SAMPLE * 64 + lane])] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(L.rng.ctr));
             long long *acc = KARG(P, accum);
             if (acc && isfinite(L.acc.x) && isfinite(L.acc.y) && isfinite(L.acc.z)) {   // main.rs:192-194; c += color (main.rs:193)
-                unsigned long long fx = (unsigned long long)to_fixed(L.acc.x), fy = (unsigned long long)to_fixed(L.acc.y), fz = (unsigned long long)to_fixed(L.acc.z);
+                const float clampv = accum_clamp_for(C.spp);
+                if (fmaxf(fmaxf(fabsf(L.acc.x), fabsf(L.acc.y)), fabsf(L.acc.z)) > clampv) atomicAdd(KARG(P, clamped), 1ull);     // (rare)
+                unsigned long long fx = (unsigned long long)to_fixed(L.acc.x, clampv), fy = (unsigned long long)to_fixed(L.acc.y, clampv), fz = (unsigned long long)to_fixed(L.acc.z, clampv);
                 // a sample of the tile the wave is handing out (nearly all of them) lands in the wave's LDS sums, which
                 // reach the frame's accumulators once per unit; a straggler of an earlier unit goes there directly
                 if ((xy & 0xFFF8FFF8u) == __builtin_amdgcn_readfirstlane(wstate[WS_TXY])) {

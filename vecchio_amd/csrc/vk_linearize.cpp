@@ -6,6 +6,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <unordered_map>
 
 namespace vkd {
 
@@ -290,8 +291,10 @@ struct Builder {
         uint32_t k = VK_REF_KIND(r), i = VK_REF_INDEX(r);
         if (k == VK_KIND_SPHERE) {
             const vk_sphere &sp = d->spheres[i];
-            float rad = fabsf(sp.radius);
-            for (int a = 0; a < 3; a++) { mn[a] = sp.center[a] - rad; mx[a] = sp.center[a] + rad; }
+            // center -/+ radius exactly as Sphere::bounding_box does (hittable.rs:97-102): a negative radius (the hollow glass
+            // sphere of scene.rs:123-127) gives an INVERTED box, which shrinks its ancestors' boxes in the reference's tree, so
+            // hits on such a sphere depend on that tree: rt_collect sees the inverted box and keeps the tree handed over
+            for (int a = 0; a < 3; a++) { mn[a] = sp.center[a] - sp.radius; mx[a] = sp.center[a] + sp.radius; }
             return true;
         }
         if (k == VK_KIND_RECT) {
@@ -303,6 +306,7 @@ struct Builder {
         }
         const vk_list &l = d->lists[i];
         if (l.count == 0 || (uint64_t)l.first + l.count > d->n_list_items) return false;
+        bool inverted = false;
         for (uint32_t j = 0; j < l.count; j++) {
             vk_ref it = d->list_items[l.first + j];
             if (!check_ref(it)) return false;
@@ -310,8 +314,10 @@ struct Builder {
             if (ik != VK_KIND_SPHERE && ik != VK_KIND_RECT) return false;
             float a[3], b[3];
             if (!rt_bounds(it, a, b)) return false;
+            for (int x = 0; x < 3; x++) inverted |= !(a[x] <= b[x]);
             if (j == 0) { memcpy(mn, a, 12); memcpy(mx, b, 12); } else rt_grow(mn, mx, a, b);
         }
+        if (inverted) { mn[0] = 1.0f; mx[0] = 0.0f; }      // a hollow sphere among the items: reported as an inverted box, like the sphere itself
         return true;
     }
 
@@ -321,8 +327,10 @@ struct Builder {
         std::vector<Fr> st;
         st.push_back(Fr{VK_MAKE_REF(VK_KIND_BVH, root), flip0});
         ok = true;
+        std::unordered_map<uint32_t, uint32_t> in_block;
         while (!st.empty()) {
             Fr fr = st.back(); st.pop_back();
+            if (VK_REF_KIND(fr.ref) != VK_KIND_BVH) in_block[fr.ref & ~VK_REF_FLIP]++;
             if (VK_REF_KIND(fr.ref) == VK_KIND_BVH) {
                 const vk_bvh_node &n = d->bvh[VK_REF_INDEX(fr.ref)];
                 bool dup = n.left == n.right && VK_REF_KIND(n.left) != VK_KIND_BVH;   // len == 1: the same object twice, the second test is a no-op
@@ -339,6 +347,8 @@ struct Builder {
             if (!convert_object(fr.ref, fr.flip, inst, o.dref)) return false;
             out.push_back(o);
         }
+        for (const auto &kv : in_block)      // a shared object with an occurrence outside this block: see node_refs
+            if (node_refs[kv.first] != kv.second) { ok = false; break; }
         return true;
     }
 
@@ -449,10 +459,24 @@ struct Builder {
         return d->n_spheres + d->n_rects + d->n_lists + i;     // DK_LIST (boxes and lists are both converted vk_lists: <= n_lists each)
     }
 
+    // How often every simple object is the child of a BVH node anywhere in the description (a `len == 1` node's two equal
+    // children count once).  An object has ONE tie rank, valid inside ONE rebuilt block: a shared object (one Arc under two
+    // nodes) whose occurrences do not all lie in the block being collected keeps that block on the reference's tree.
+    std::unordered_map<uint32_t, uint32_t> node_refs;
+    void count_node_refs() {
+        for (uint32_t i = 0; i < d->n_bvh; i++) {
+            const vk_bvh_node &n = d->bvh[i];
+            const bool dup = n.left == n.right;
+            if (VK_REF_KIND(n.left) != VK_KIND_BVH) node_refs[n.left & ~VK_REF_FLIP]++;
+            if (VK_REF_KIND(n.right) != VK_KIND_BVH && !dup) node_refs[n.right & ~VK_REF_FLIP]++;
+        }
+    }
+
     // tries to replace the subtree rooted at BVH node `root` by a rebuilt one; `done` says whether it did
     bool try_retree(uint32_t root, uint32_t flip, int32_t inst, bool &done) {
         done = false;
         if (!retree) return true;
+        if (node_refs.empty()) count_node_refs();
         if (simple_count.empty() || simple_count[root] == -2) { if (!classify(root)) return false; }
         if (simple_count[root] < (int32_t)RETREE_MIN || n_blocks >= 4095u) return true;
         const size_t items0 = L.items.size(), boxes0 = L.boxes.size(), lists0 = L.lists.size(), refs0 = L.list_refs.size();

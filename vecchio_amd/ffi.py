@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 ASSETS_DIR = os.path.join(os.path.dirname(_HERE), "tests", "golden", "assets")
 
-VK_ABI_VERSION = 2
+VK_ABI_VERSION = 3
 VK_OK, VK_ERR_BAD_ARG, VK_ERR_UNSUPPORTED, VK_ERR_HIP, VK_ERR_NO_DEVICE, VK_ERR_OOM = range(6)
 
 (VK_KIND_NONE, VK_KIND_BVH, VK_KIND_SPHERE, VK_KIND_MOVING_SPHERE, VK_KIND_RECT, VK_KIND_LIST,
@@ -123,7 +123,7 @@ class RenderParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("seconds", C.c_double), ("kernel_ms", C.c_double),
-                ("kernel_launches", C.c_uint32), ("scene_in_lds", C.c_uint32)]
+                ("kernel_launches", C.c_uint32), ("scene_in_lds", C.c_uint32), ("clamped_samples", C.c_uint64)]
 
 
 class SceneInfo(C.Structure):
@@ -184,7 +184,7 @@ def load_host_lib():
 DEVICE_SYMBOLS = [
     "vk_abi_version", "vk_device_count", "vk_last_error", "vk_scene_create", "vk_scene_destroy",
     "vk_render", "vk_render_device", "vk_to_color_device", "vk_scene_get_info", "vk_scene_create_multi",
-    "vk_scene_last_kernel_ms",
+    "vk_scene_last_kernel_ms", "vk_scene_last_clamped_samples",
 ]
 
 
@@ -217,6 +217,8 @@ def load_device_lib():
     lib.vk_scene_destroy.argtypes = [C.c_void_p]
     lib.vk_scene_last_kernel_ms.restype = C.c_int
     lib.vk_scene_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.vk_scene_last_clamped_samples.restype = C.c_int
+    lib.vk_scene_last_clamped_samples.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.vk_render.restype = C.c_int
     lib.vk_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
     lib.vk_render_device.restype = C.c_int

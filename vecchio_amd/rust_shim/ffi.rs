@@ -11,7 +11,7 @@ use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
 pub type vk_ref = u32;
-pub const VK_ABI_VERSION: u32 = 2;
+pub const VK_ABI_VERSION: u32 = 3;
 pub const VK_REF_FLIP: u32 = 0x0800_0000;
 pub const VK_KIND_BVH: u32 = 1;
 pub const VK_KIND_SPHERE: u32 = 2;
@@ -71,7 +71,7 @@ pub struct vk_render_params {
 }
 
 #[repr(C)] #[derive(Copy, Clone, Default)]
-pub struct vk_stats { pub samples: u64, pub seconds: f64, pub kernel_ms: f64, pub kernel_launches: u32, pub scene_in_lds: u32 }
+pub struct vk_stats { pub samples: u64, pub seconds: f64, pub kernel_ms: f64, pub kernel_launches: u32, pub scene_in_lds: u32, pub clamped_samples: u64 }
 
 #[repr(C)] pub struct vk_scene { _private: [u8; 0] }
 
@@ -85,6 +85,8 @@ extern "C" {
     pub fn vk_scene_destroy(scene: *mut vk_scene);
     pub fn vk_render(scene: *mut vk_scene, cam: *const vk_camera, params: *const vk_render_params, rgb_out: *mut f32, stats: *mut vk_stats) -> c_int;
     pub fn vk_render_device(scene: *mut vk_scene, cam: *const vk_camera, params: *const vk_render_params, d_rgb: *mut c_void, stream: *mut c_void, stats: *mut vk_stats) -> c_int;
+    pub fn vk_scene_last_kernel_ms(scene: *mut vk_scene, ms_out: *mut f64) -> c_int;
+    pub fn vk_scene_last_clamped_samples(scene: *mut vk_scene, count_out: *mut u64) -> c_int;
 }
 
 /// What `flatten()` pushes into (flatten.rs).  One record per Arc; shared Arcs are de-duplicated
