@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2.0   # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles, 2.4 GHz max clock
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 WORKLOADS = {
     # name: (scene builder, width, spp, max_depth, label)
@@ -43,6 +43,12 @@ WORKLOADS = {
     "C4": ("cornell_box", 1024, 4096, 50, "C4: Cornell box 1024x1024, 4096 spp, depth 50"),
     "C5": ("stress_spheres:500", 4096, 256, 50, "C5: 1M spheres 4096x4096, 256 spp, depth 50"),
 }
+
+
+def WORKLOAD_SAMPLES(name):
+    _, w, spp, _, _ = WORKLOADS[name]
+    h = {"C2": 1080, "C3": 800, "C4": 1024, "C5": 4096}[name]
+    return w * h * spp
 
 
 def algorithmic_bytes_per_sample(c, spp, walked_only=False):
@@ -57,9 +63,39 @@ def algorithmic_bytes_per_sample(c, spp, walked_only=False):
             8.0 * c["n_medium"] + 16.0 * c["n_closest"] + 3.0 * c["n_texel"] + 8.0 * 24.0 * c["n_perlin"]) / n + 12.0 / spp
 
 
+LDS_PEAK_BPS = 150e12           # MI355X_MICROARCH.md: ~150 TB/s aggregate for ds_read_b64/b128 with every CU streaming
+L2_PEAK_BPS = 34.5e12           # MI355X_MICROARCH.md: ~34.5 TB/s aggregate L2
+
+
+def physical_bounds(c, samples, seconds, scene_in_lds, issue):
+    """What physically limits the kernel, every fraction <= 1 by construction (unlike the algorithmic-HBM `roofline`, whose bytes
+    are served from LDS / L2):
+      valu_issue  vector instruction issue: wave-instructions/s against 1024 SIMDs x 2.4 GHz / 2 cycles; x lane fill = the share of
+                  the chip's 78.6 T lane-instructions/s that does useful work
+      lds         (scene staged in LDS) the traversal's record bytes — 32 B per box test, 16 B per sphere test, oracle visit counts —
+                  against the LDS arrays' ~150 TB/s
+      l2          (scene read from global memory) the same record bytes as an upper bound of the L2 request traffic (what L1 absorbs
+                  is not subtracted) against ~34.5 TB/s
+    The dominant one is named in `bound`."""
+    n = float(c["samples"])
+    rec = 32.0 * (c["n_aabb"] - c["n_aabb_nonfinite"]) + 16.0 * (c["n_sphere"] - c["n_sphere_nonfinite"]) + 36.0 * c["n_moving"] + 24.0 * c["n_rect"] + \
+        32.0 * c["n_xform"] + 8.0 * c["n_medium"]
+    rate = rec / n * samples / seconds
+    out = {"bound": "valu_issue", "unit": "wave-instr/s", "achieved": None, "peak": VALU_WAVE_INSTR_PER_S, "frac": None,
+           "lane_fill": None, "useful_lane_frac": None,
+           "memory": {"level": "lds" if scene_in_lds else "l2", "record_bytes_per_sample": round(rec / n, 1), "achieved_Bps": round(rate, 1),
+                      "peak_Bps": LDS_PEAK_BPS if scene_in_lds else L2_PEAK_BPS, "frac": round(rate / (LDS_PEAK_BPS if scene_in_lds else L2_PEAK_BPS), 4)}}
+    if issue:
+        out.update(achieved=issue["achieved_wave_instr_per_s"], frac=issue["frac"], lane_fill=issue["lane_fill"],
+                   useful_lane_frac=round(issue["frac"] * issue["lane_fill"], 4), counters=issue.get("note"))
+    if out["frac"] is not None and out["memory"]["frac"] > out["frac"]:
+        out["bound"] = out["memory"]["level"]
+    return out
+
+
 def pmc_summary(workload):
     """the committed rocprofv3 PMC summary of this workload's bench command (profiles/<round>/), or None"""
-    for rnd in (PROFILE_ROUND, "r01"):
+    for rnd in (PROFILE_ROUND, "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, f"{workload.lower()}_pmc_summary.json")
         if os.path.exists(path) and os.path.getsize(path) > 0:
             try:
@@ -86,7 +122,8 @@ def measure_counters_live(workload, timeout_s=75):
     if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
         return None, "this run is itself being profiled"
     got = {}
-    for group in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU")):
+    for group in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"),
+                  ("SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS")):
         tmp = tempfile.mkdtemp(prefix="vk_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", *group, "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.join(ROOT, "bench.py"),
                "--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu", "--no-verify", "--no-also", "--no-traffic"]
@@ -108,7 +145,7 @@ def measure_counters_live(workload, timeout_s=75):
             return None, f"{group[0]} pass failed: {type(e).__name__}"
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
-    got["read_bytes_upper_bound"], got["written_bytes"] = 2.0 * got["FETCH_SIZE"] * 1024.0, got["WRITE_SIZE"] * 1024.0
+    got["read_bytes"], got["read_bytes_upper_bound"], got["written_bytes"] = got["FETCH_SIZE"] * 1024.0, 2.0 * got["FETCH_SIZE"] * 1024.0, got["WRITE_SIZE"] * 1024.0
     return got, None
 
 
@@ -329,12 +366,15 @@ def main():
             # process, so they come from the committed rocprofv3 passes of this same command (profiles/, tests/prof_r02.sh):
             # WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950: FETCH_SIZE counts half the bytes of wide reads -> upper bound)
             traffic, issue, prof_path = None, None, None
+            t_read = t_write = scratch_share = None
             if n_gpus == 1 and not spp_override and bvh == "reference" and not fast_accel:
                 prof, prof_path = pmc_summary(name)
                 if prof:
                     d = prof.get("derived", {})
                     try:
-                        traffic = float(d["hbm_write_bytes_per_dispatch"] + d["hbm_read_bytes_per_dispatch"]["with_gfx950_x2_correction_upper_bound"])
+                        t_write = float(d["hbm_write_bytes_per_dispatch"])
+                        t_read = float(d["hbm_read_bytes_per_dispatch"]["with_gfx950_x2_correction_upper_bound"])
+                        traffic = t_read + t_write
                     except Exception:
                         traffic = None
                     vi = d.get("SQ_INSTS_VALU_per_sample")
@@ -353,7 +393,13 @@ def main():
                     traffic_note = ("HBM bytes of one launch MEASURED IN THIS RUN: one-step child runs of this script under rocprofv3 --pmc "
                                     f"(FETCH_SIZE x 2 as the gfx950 upper bound: {live['read_bytes_upper_bound']:.0f} B read, WRITE_SIZE: "
                                     f"{live['written_bytes']:.0f} B written); committed profile ({prof_path}): {traffic}")
-                    traffic = live["read_bytes_upper_bound"] + live["written_bytes"]
+                    t_read, t_write = live["read_bytes_upper_bound"], live["written_bytes"]
+                    traffic = t_read + t_write
+                    # scratch (register spill) stores are the kernel's only vector-memory writes apart from the flushes of the LDS tile sums
+                    # and the few straggler deposits (3 wave-level atomics per work unit): a wave-wide dword store is 256 B
+                    n_units_est = ((width + 7) // 8) * ((height + 7) // 8) * max(1, -(-spp // 64)) / max(1, world)
+                    spill_instr = max(0.0, live["SQ_INSTS_VMEM_WR"] - 4.0 * n_units_est)
+                    scratch_share = round(min(1.0, spill_instr * 256.0 / max(1.0, t_write)), 4)
                     if k_ms:
                         vi = live["SQ_INSTS_VALU"] / local_samples
                         rate = live["SQ_INSTS_VALU"] / (k_ms * 1e-3)
@@ -370,6 +416,7 @@ def main():
                 achieved = bps * local_samples / (k_ms * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                        "traffic_read": t_read, "traffic_write": t_write, "scratch_write_share": scratch_share,
                         "traffic_note": traffic_note,
                         "algorithmic_bytes_per_sample": round(bps, 1), "kernel_ms": round(k_ms, 3),
                         "algorithmic_bytes_per_sample_walked": round(bps_walked, 1),
@@ -379,7 +426,9 @@ def main():
                         "note": "algorithmic bytes (SURVEY 8d record sizes x oracle visit counts); the scene is LDS/L2 resident, so this is not "
                                 "a physical bound (it can exceed 1): the physical one is `issue`",
                         "issue": issue}
+            physical = physical_bounds(c, local_samples, k_ms * 1e-3, bool(info.lds_bytes), issue) if k_ms else None
             res = {"value": round(value, 2), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+                   "physical": physical, "kernel_ms": k_ms,
                    "label": label, "integrator": "scatter" if hs.integrator else "pdf", "bvh_items": info.n_items,
                    "scene_in_lds": bool(info.lds_bytes), "verified": verified, "roofline": roof, "cpu_baseline": cpu}
         if world > 1:
@@ -411,6 +460,10 @@ def main():
         for name, spp_o, fa in (("C4", 0, False), ("C3", 0, False), ("C5", 0, False), ("C2", 0, True)):
             r = run_workload(name, 1, 0, spp_o, fast_accel=fa)
             also.append({"workload": r["label"], "Msamples_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": 1,
+                         # one step, no warm-up: `Msamples_per_s` includes the variant's first-use costs (code-object load, buffer
+                         # allocation); the kernel-time rate does not and is the one comparable with the headline
+                         "kernel_ms": r["kernel_ms"], "kernel_Msamples_per_s": round(WORKLOAD_SAMPLES(name) / r["kernel_ms"] / 1e3, 2) if r["kernel_ms"] else None,
+                         "physical": r["physical"],
                          "verified": r["verified"], "roofline_frac": r["roofline"]["frac"] if r["roofline"] else None,
                          "issue_frac": (r["roofline"] or {}).get("issue", None) and r["roofline"]["issue"]["frac"]})
     if rank == 0:
@@ -424,7 +477,7 @@ def main():
             "config": {"workload": r["label"], "scene_seed": 1, "render_seed": 2,
                        "integrator": r["integrator"], "tiles": "8x8 round-robin over ranks", "multi_gpu": mode,
                        "bvh_builder": args.bvh, "bvh_items": r["bvh_items"], "scene_in_lds": r["scene_in_lds"], "also": also},
-            "verified": r["verified"], "roofline": r["roofline"], "cpu_baseline": r["cpu_baseline"],
+            "verified": r["verified"], "roofline": r["roofline"], "physical": r["physical"], "cpu_baseline": r["cpu_baseline"],
         }
         if r.get("distributed"):
             out["distributed"] = r["distributed"]

@@ -55,8 +55,10 @@ static RenderConsts make_consts(const vk_camera *cam, const vk_render_params *p)
 // sequence alone, for n (box, ray, tmax) triples.  fused = 0: the (b - o) * (1/d) form of the general variants; 1: the
 // fma(b, 1/d, -o/d) form of the sphere-only variants.  decisions[i] bit0 = kernel's answer, bit1 = slab_exact's answer,
 // bit2 = the kernel took the exact fallback.
+// perturb != 0: the three reciprocals 1/d are moved by -1, 0 or +1 ulp (pseudo-randomly per case and axis) before the step: what the
+// device's v_rcp_f32 (1 ulp) may hand the fast path instead of the correctly rounded quotient (vk_trace.h set_space)
 template <uint32_t F, bool FUSED>
-static void box_decisions(const float *boxes, const float *rays, size_t n, uint8_t *decisions) {
+static void box_decisions(const float *boxes, const float *rays, size_t n, uint8_t *decisions, uint32_t perturb = 0) {
     for (size_t k = 0; k < n; k++) {
         DItem it;
         it.mnx = boxes[k * 6 + 0]; it.mxx = boxes[k * 6 + 1]; it.mny = boxes[k * 6 + 2]; it.mxy = boxes[k * 6 + 3];
@@ -66,6 +68,19 @@ static void box_decisions(const float *boxes, const float *rays, size_t n, uint8
         memset(&L, 0, sizeof(L));
         V3 o = v3(rays[k * 7 + 0], rays[k * 7 + 1], rays[k * 7 + 2]), d = v3(rays[k * 7 + 3], rays[k * 7 + 4], rays[k * 7 + 5]);
         set_space<FUSED>(L, o, d);
+        if (perturb) {
+            uint64_t h = vk::mix64((uint64_t)perturb * 0x9E3779B97F4A7C15ull + k);
+            float *iv[3] = {&L.inv.x, &L.inv.y, &L.inv.z};
+            for (int a = 0; a < 3; a++) {
+                int step = (int)((h >> (8 * a)) % 3u) - 1;
+                uint32_t b = vk::f32_bits(*iv[a]);
+                if (std::isfinite(*iv[a]) && *iv[a] != 0.0f) *iv[a] = vk::bits_f32(b + (uint32_t)step);     // +-1 ulp in magnitude
+            }
+            if (FUSED && !std::isnan(L.xnan)) {      // o/d and the margin's |o/d| term follow the reciprocal actually used
+                L.oi = v3(o.x * L.inv.x, o.y * L.inv.y, o.z * L.inv.z);
+                L.xnan = fmaxf(fmaxf(fabsf(L.oi.x), fabsf(L.oi.y)), fabsf(L.oi.z)) * 4.76837158203125e-7f;
+            }
+        }
         L.T = rays[k * 7 + 6];
         L.i = 0; L.end = 1; L.pend = 0;
         typename std::conditional<FUSED, FusedMem, GlobalMem>::type M;
@@ -188,6 +203,10 @@ void emu_min_with_tmax(const float *a, const float *t, size_t n, float *out) {
 void emu_box_decisions(const float *boxes, const float *rays, size_t n, uint8_t *decisions, int fused) {
     if (fused) box_decisions<0u, true>(boxes, rays, n, decisions);
     else box_decisions<VKF_ALL_SCENE, false>(boxes, rays, n, decisions);
+}
+void emu_box_decisions_rcp(const float *boxes, const float *rays, size_t n, uint8_t *decisions, int fused, uint32_t perturb) {
+    if (fused) box_decisions<0u, true>(boxes, rays, n, decisions, perturb);
+    else box_decisions<VKF_ALL_SCENE, false>(boxes, rays, n, decisions, perturb);
 }
 
 }  // extern "C"

@@ -1,10 +1,10 @@
 #!/bin/bash
-# rocprofv3 runs for the round-2 profiles (run on the GPU box via gpurun from the repo root):
-#   OUT=gpurun_out/prof_x WL="--workload C2" STEPS=2 WARMUP=1 bash tests/prof_r02.sh [pmc] [cache]
+# rocprofv3 runs for the round-3 profiles (run on the GPU box via gpurun from the repo root):
+#   OUT=gpurun_out/prof_x WL="--workload C2" STEPS=2 WARMUP=1 bash tests/prof_r03.sh [pmc] [cache]
 # Kernel trace + stats first; PMC counters in their own passes (never combined with other trace domains).
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=${OUT:-gpurun_out/prof_r02}
+OUT=${OUT:-gpurun_out/prof_r03}
 WL=${WL:-"--workload C2"}
 STEPS=${STEPS:-2}
 WARMUP=${WARMUP:-1}
@@ -22,7 +22,7 @@ for a in "$@"; do
     pass fetch FETCH_SIZE || exit 2
     pass write WRITE_SIZE || exit 3
     pass sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU || exit 4
-    pass sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_FLAT || exit 5
+    pass sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR || exit 5
   fi
   if [ "$a" == "cache" ]; then
     pass tcc TCC_HIT_sum TCC_MISS_sum || exit 6

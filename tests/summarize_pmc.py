@@ -8,7 +8,7 @@ import sys
 import os
 src, dst, samples = sys.argv[1], sys.argv[2], float(sys.argv[3])
 cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "bench.py --steps 2 --warmup 1 --no-cpu"
-out = {"command": f"rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 {cmd} (separate passes; see tests/prof_r02.sh)",
+out = {"command": f"rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 {cmd} (separate passes; see tests/prof_r03.sh)",
        "samples_per_dispatch": samples, "counters_per_dispatch": {}}
 for f in sorted(glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv")):
     agg = collections.defaultdict(list)

@@ -9,13 +9,14 @@ import numpy as np
 import pytest
 
 
-def decide(emu, boxes, rays, fused):
+def decide(emu, boxes, rays, fused, perturb=0):
+    """perturb != 0: the reciprocals 1/d moved by -1/0/+1 ulp per axis, as the device's v_rcp_f32 may deliver them"""
     lib = emu.load()
-    lib.emu_box_decisions.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    lib.emu_box_decisions_rcp.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_uint32]
     boxes = np.ascontiguousarray(boxes, np.float32)
     rays = np.ascontiguousarray(rays, np.float32)
     out = np.zeros(len(boxes), np.uint8)
-    lib.emu_box_decisions(boxes.ctypes.data, rays.ctypes.data, len(boxes), out.ctypes.data, int(fused))
+    lib.emu_box_decisions_rcp(boxes.ctypes.data, rays.ctypes.data, len(boxes), out.ctypes.data, int(fused), int(perturb))
     return out
 
 
@@ -61,6 +62,11 @@ def test_fast_path_equals_reference_divisions(emu, fused):
         dec = decide(emu, boxes, rays, fused)
         bad = ((dec & 1) != ((dec >> 1) & 1))
         assert not bad.any(), f"{int(bad.sum())} of {n} decisions differ, first: box {boxes[bad][0]} ray {rays[bad][0]}"
+        # the device takes 1/d from v_rcp_f32 (1 ulp): the same cases with every reciprocal moved by -1 / 0 / +1 ulp
+        for seed in (1, 2):
+            decp = decide(emu, boxes, rays, fused, perturb=seed)
+            badp = ((decp & 1) != ((decp >> 1) & 1))
+            assert not badp.any(), f"rcp +-1 ulp: {int(badp.sum())} of {n} decisions differ, first: box {boxes[badp][0]} ray {rays[badp][0]}"
         total_fb += int(((dec >> 2) & 1).sum())
         assert ((dec & 1) == 1).mean() > 0.05 and ((dec & 1) == 0).mean() > 0.05      # both outcomes well covered
     assert 0 < total_fb < 0.2 * 3 * n          # the fallback is exercised, and is the exception

@@ -90,3 +90,26 @@ def test_tile_partition_covers_image_once():
         assert len(allidx) == w * h and len(np.unique(allidx)) == w * h
         top = np.concatenate([tile_pixel_indices(w, h, r, world, top_down=True) for r in range(world)])
         assert np.array_equal(top, (h - 1 - allidx // w) * w + allidx % w)      # RGB8 images are stored top row first
+
+
+@pytest.mark.gpu
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks(device):
+    """`python bench.py --gpus 2` — the driver's command shape, no torchrun — must start two ranks itself (as a CHILD process of
+    a parent that never touches the GPU), render the frame tile-parallel, gather it and say so in its JSON line: world size,
+    backend, one device record per rank, and the gathered image bit-identical to ONE device's render of the whole frame.
+    Rehearsal on the box's single GPU: both ranks on device 0, gloo instead of RCCL (VK_BENCH_REHEARSAL=1)."""
+    import json
+    import subprocess
+    env = dict(os.environ, VK_BENCH_REHEARSAL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--spp", "16",
+                        "--no-cpu", "--no-also", "--no-traffic"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    dd = d["distributed"]
+    assert dd["world_size"] == 2 and dd["self_launched"] and len(dd["ranks"]) == 2 and {x["rank"] for x in dd["ranks"]} == {0, 1}
+    assert dd["gathered_image_equals_one_gpu_render"] is True
+    assert d["verified"]["ok"] is True
