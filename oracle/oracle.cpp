@@ -41,8 +41,10 @@ thread_local bool g_panic = false;              // a reference panic!/unwrap was
 
 inline vk::Rng &thread_rng() { return *g_rng; }
 inline float gen_f32() { uint32_t c0 = g_rng->ctr; float v = vk::gen_f32(*g_rng); g_cnt.n_draws += g_rng->ctr - c0; return v; }
-inline float gen_range(float lo, float hi) { uint32_t c0 = g_rng->ctr; float v = vk::gen_range(*g_rng, lo, hi); g_cnt.n_draws += g_rng->ctr - c0; return v; }
-inline uint32_t gen_index(uint32_t n) { uint32_t c0 = g_rng->ctr; uint32_t v = vk::gen_index(*g_rng, n); g_cnt.n_draws += g_rng->ctr - c0; return v; }
+inline float gen_range(float lo, float hi) { uint32_t c0 = g_rng->ctr; float v = vk::gen_range(*g_rng, lo, hi);
+    g_cnt.n_draws += g_rng->ctr - c0; return v; }
+inline uint32_t gen_index(uint32_t n) { uint32_t c0 = g_rng->ctr; uint32_t v = vk::gen_index(*g_rng, n); g_cnt.n_draws += g_rng->ctr - c0;
+    return v; }
 
 const float PI = 3.14159265358979323846f;  // std::f32::consts::PI
 
@@ -906,11 +908,13 @@ struct Scene {
         for (uint32_t i = 0; i < desc->n_textures; i++) {
             const vk_texture &t = desc->textures[i];
             switch (t.kind) {
-                case VK_TEX_SOLID: { auto p = new SolidColor; p->color_value = Vec3(t.color[0], t.color[1], t.color[2]); textures[i].reset(p); break; }
+                case VK_TEX_SOLID: { auto p = new SolidColor; p->color_value = Vec3(t.color[0], t.color[1], t.color[2]);
+                    textures[i].reset(p); break; }
                 case VK_TEX_CHECKER: { textures[i].reset(new Checker); break; }
                 case VK_TEX_IMAGE: {
                     if (t.a >= desc->n_images) return fail("image index out of range");
-                    auto p = new ImageTexture; p->buf = desc->images[t.a].rgb; p->width = desc->images[t.a].width; p->height = desc->images[t.a].height;
+                    auto p = new ImageTexture; p->buf = desc->images[t.a].rgb; p->width = desc->images[t.a].width;
+                    p->height = desc->images[t.a].height;
                     if (!p->buf || !p->width || !p->height) { delete p; return fail("empty image"); }
                     textures[i].reset(p); break;
                 }
@@ -920,7 +924,8 @@ struct Scene {
                     const vk_perlin &pl = desc->perlins[t.a];
                     for (int k = 0; k < 256; k++) {
                         p->noise.random_data[k] = Vec3(pl.ranvec[k][0], pl.ranvec[k][1], pl.ranvec[k][2]);
-                        p->noise.perm_x[k] = pl.perm_x[k] & 255; p->noise.perm_y[k] = pl.perm_y[k] & 255; p->noise.perm_z[k] = pl.perm_z[k] & 255;
+                        p->noise.perm_x[k] = pl.perm_x[k] & 255; p->noise.perm_y[k] = pl.perm_y[k] & 255;
+                        p->noise.perm_z[k] = pl.perm_z[k] & 255;
                     }
                     textures[i].reset(p); break;
                 }
@@ -938,11 +943,13 @@ struct Scene {
         materials.resize(desc->n_materials);
         for (uint32_t i = 0; i < desc->n_materials; i++) {
             const vk_material &m = desc->materials[i];
-            bool needs_tex = m.kind == VK_MAT_LAMBERTIAN || m.kind == VK_MAT_METAL || m.kind == VK_MAT_DIFFUSE_LIGHT || m.kind == VK_MAT_ISOTROPIC;
+            bool needs_tex = m.kind == VK_MAT_LAMBERTIAN || m.kind == VK_MAT_METAL || m.kind == VK_MAT_DIFFUSE_LIGHT ||
+                m.kind == VK_MAT_ISOTROPIC;
             if (needs_tex && m.texture >= desc->n_textures) return fail("texture index out of range");
             switch (m.kind) {
                 case VK_MAT_LAMBERTIAN: { auto p = new Lambertian; p->albedo = textures[m.texture].get(); materials[i].reset(p); break; }
-                case VK_MAT_METAL: { auto p = new Metal; p->albedo = textures[m.texture].get(); p->fuzz = m.param; materials[i].reset(p); break; }
+                case VK_MAT_METAL: { auto p = new Metal; p->albedo = textures[m.texture].get(); p->fuzz = m.param; materials[i].reset(p);
+                    break; }
                 case VK_MAT_DIELECTRIC: { auto p = new Dielectric; p->ref_idx = m.param; materials[i].reset(p); break; }
                 case VK_MAT_DIFFUSE_LIGHT: { auto p = new DiffuseLight; p->emit = textures[m.texture].get(); materials[i].reset(p); break; }
                 case VK_MAT_ISOTROPIC: { auto p = new Isotropic; p->albedo = textures[m.texture].get(); materials[i].reset(p); break; }

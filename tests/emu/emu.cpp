@@ -30,7 +30,8 @@ static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string
 struct FusedMem : GlobalMem { static constexpr bool FUSED_BOX = true; };
 
 template <uint32_t F, class Mem = GlobalMem>
-static void trace_one(const DScene &S, const GlobalMem &M0, const RenderConsts &C, uint32_t pixel, uint32_t sample, V3 &rgb, uint32_t &draws, uint64_t *steps) {
+static void trace_one(const DScene &S, const GlobalMem &M0, const RenderConsts &C, uint32_t pixel, uint32_t sample, V3 &rgb,
+    uint32_t &draws, uint64_t *steps) {
     Mem M; static_cast<GlobalMem &>(M) = M0;
     Lane L;
     start_sample<F, Mem>(L, S, C, pixel % C.width, pixel / C.width, sample);
@@ -114,10 +115,13 @@ const char *emu_last_error(void) { return g_err.c_str(); }
 // run the fused box test, vk_trace.h set_space); the Cornell-type variants in between are the same code as the full ones
 static const uint32_t FALL = VKF_ALL_SCENE;
 static const uint32_t FPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
-static void trace_any(const DScene &S, const GlobalMem &M, const RenderConsts &C, uint32_t integrator, uint32_t pixel, uint32_t sample, V3 &rgb, uint32_t &draws, uint64_t *steps) {
+static void trace_any(const DScene &S, const GlobalMem &M, const RenderConsts &C, uint32_t integrator, uint32_t pixel, uint32_t sample,
+    V3 &rgb, uint32_t &draws, uint64_t *steps) {
     bool lean = S.features == 0u && !getenv("VK_FORCE_FULL_VARIANT");
-    if (integrator == VK_INTEGRATOR_PDF) { if (lean) trace_one<VKF_INTEG_PDF, FusedMem>(S, M, C, pixel, sample, rgb, draws, steps); else trace_one<FPDF>(S, M, C, pixel, sample, rgb, draws, steps); }
-    else { if (lean) trace_one<0u, FusedMem>(S, M, C, pixel, sample, rgb, draws, steps); else trace_one<FALL>(S, M, C, pixel, sample, rgb, draws, steps); }
+    if (integrator == VK_INTEGRATOR_PDF) { if (lean) trace_one<VKF_INTEG_PDF, FusedMem>(S, M, C, pixel, sample, rgb, draws, steps);
+        else trace_one<FPDF>(S, M, C, pixel, sample, rgb, draws, steps); }
+    else { if (lean) trace_one<0u, FusedMem>(S, M, C, pixel, sample, rgb, draws, steps);
+        else trace_one<FALL>(S, M, C, pixel, sample, rgb, draws, steps); }
 }
 
 int emu_sample(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *p, uint32_t pixel, uint32_t sample,
@@ -136,7 +140,8 @@ int emu_sample(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
 }
 
 // debug: the primary ray of (pixel, sample) and the closest hit of its first segment: out = o3, d3, T, best_prim (bits)
-int emu_first_hit(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *p, uint32_t pixel, uint32_t sample, float out[8]) {
+int emu_first_hit(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *p, uint32_t pixel, uint32_t sample,
+    float out[8]) {
     LinearScene LS;
     int st = linearize_env(desc, LS, g_err);
     if (st != VK_OK) return st;
@@ -157,11 +162,13 @@ int emu_render(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
     LinearScene LS;
     int st = linearize_env(desc, LS, g_err);
     if (st != VK_OK) return st;
-    if (p->integrator == VK_INTEGRATOR_PDF && LS.lights.empty()) { g_err = "PDF integrator needs a non-empty lights list (hittable.rs:431 would panic)"; return VK_ERR_UNSUPPORTED; }
+    if (p->integrator == VK_INTEGRATOR_PDF && LS.lights.empty()) { g_err =
+        "PDF integrator needs a non-empty lights list (hittable.rs:431 would panic)"; return VK_ERR_UNSUPPORTED; }
     DScene S = LS.host_view();
     GlobalMem M{S.items, S.spheres, S.sphere_mat, S.boxes};
     RenderConsts C = make_consts(cam, p);
-    if (info_out) { info_out[0] = S.n_items; info_out[1] = LS.n_prims; info_out[2] = (uint32_t)LS.instances.size(); info_out[3] = LS.features; }
+    if (info_out) { info_out[0] = S.n_items; info_out[1] = LS.n_prims; info_out[2] = (uint32_t)LS.instances.size();
+        info_out[3] = LS.features; }
     if (n_threads < 1) n_threads = 1;
     std::atomic<uint32_t> next_row(0);
     std::atomic<uint64_t> total_steps(0);

@@ -205,7 +205,8 @@ void plan_residency(vk_scene *s, size_t hot) {
     if (best_waves >= cap && !s->env.no_lds_scene) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = best_wg * 64; s->wgs_per_cu = best_n;
     } else {
-        s->lds_bytes = 0; s->wg_threads = spheres_only ? 512 : 256; s->wgs_per_cu = spheres_only ? 4 : 6;   // 32 (sphere-only, 8 waves/SIMD) or 24 waves per CU
+        // 32 (sphere-only, 8 waves/SIMD) or 24 waves per CU
+        s->lds_bytes = 0; s->wg_threads = spheres_only ? 512 : 256; s->wgs_per_cu = spheres_only ? 4 : 6;
     }
 }
 
@@ -213,8 +214,10 @@ template <uint32_t F, int MINW_SPHERES = 6>
 int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shmem, hipStream_t st, bool cost) {
     // Register budget: every variant is held to 80 VGPRs = 6 waves per SIMD, 24 per CU.  The sphere-only kernels fit (76).  The
     // Cornell-type variants (Rect / list / Boxy / instance) need 96 and the everything-variants 120 to be free of spills, but both
-    // gain more from the waves than they lose to the spills: C4 at 4 / 5 / 6 / 7 per SIMD 4 430 / 5 240 / 5 425 / 5 030 Msamples/s (45 spilled
-    // registers at 6, 80 at 7, shading inline; out of line 5 340 at 6); C3, which waits for memory 44 % of the time, 642 / 695 / 726 at 4 / 5 / 6
+    // gain more from the waves than they lose to the spills: C4 at 4 / 5 / 6 / 7 per SIMD 4 430 / 5 240 / 5 425 / 5 030 Msamples/s (45
+    // spilled
+    // registers at 6, 80 at 7, shading inline; out of line 5 340 at 6); C3, which waits for memory 44 % of the time, 642 / 695 / 726 at 4 /
+    // 5 / 6
     // (13 spilled registers, 25 scratch instructions outside the box loop, shading out of line) and 695 at 7 (27 registers, 154).
     constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? MINW_SPHERES : 6;
     // Sphere-only scenes traversed from GLOBAL memory (C5, 49 MB of items and spheres) run at 8 waves per SIMD / 64 VGPRs with the
@@ -249,11 +252,14 @@ int launch_by_features(vk_scene *s, uint32_t F, const KArgs &A, bool lds, dim3 g
 
 int check_render_args(vk_scene *scene, const vk_camera *cam, const vk_render_params *p) {
     if (!scene || !cam || !p) return fail(VK_ERR_BAD_ARG, "null argument");
-    if (p->width < 2 || p->height < 2) return fail(VK_ERR_BAD_ARG, "width and height must be >= 2 (u,v divide by width-1/height-1, main.rs:187-188)");
-    if ((uint64_t)p->width * p->height > (1ull << 31) / 3 || p->width > 65535u || p->height > 65535u) return fail(VK_ERR_BAD_ARG, "image too large");
+    if (p->width < 2 || p->height < 2) return fail(VK_ERR_BAD_ARG,
+        "width and height must be >= 2 (u,v divide by width-1/height-1, main.rs:187-188)");
+    if ((uint64_t)p->width * p->height > (1ull << 31) / 3 || p->width > 65535u || p->height > 65535u) return fail(VK_ERR_BAD_ARG,
+        "image too large");
     if (p->samples_per_pixel == 0 || p->samples_per_pixel > (1u << 26)) return fail(VK_ERR_BAD_ARG, "samples_per_pixel must be in 1..2^26");
     if (!(cam->time0 < cam->time1)) return fail(VK_ERR_BAD_ARG, "camera time0 >= time1 (gen_range panics, main.rs:118)");
-    if (p->integrator > VK_INTEGRATOR_SCATTER || p->background > VK_BACKGROUND_SKY) return fail(VK_ERR_BAD_ARG, "bad integrator/background");
+    if (p->integrator > VK_INTEGRATOR_SCATTER || p->background > VK_BACKGROUND_SKY) return fail(VK_ERR_BAD_ARG,
+        "bad integrator/background");
     if (p->output_format > VK_OUTPUT_RGB8) return fail(VK_ERR_BAD_ARG, "bad output_format");
     uint32_t world = p->tile_world ? p->tile_world : 1;
     if (p->tile_rank >= world) return fail(VK_ERR_BAD_ARG, "tile_rank >= tile_world");
@@ -261,7 +267,8 @@ int check_render_args(vk_scene *scene, const vk_camera *cam, const vk_render_par
     if (p->integrator == VK_INTEGRATOR_PDF && H.lights.empty())
         return fail(VK_ERR_UNSUPPORTED, "PDF integrator with an empty lights list (Vec::random unwraps None, hittable.rs:431)");
     if (p->integrator == VK_INTEGRATOR_SCATTER && (H.features & VKF_SPEC_DIFFUSE))
-        return fail(VK_ERR_UNSUPPORTED, "SpecDiffuse has no Material::scatter (default impl unwraps a None specular ray, material.rs:21-28)");
+        return fail(VK_ERR_UNSUPPORTED,
+            "SpecDiffuse has no Material::scatter (default impl unwraps a None specular ray, material.rs:21-28)");
     return VK_OK;
 }
 
@@ -278,7 +285,8 @@ template <int MODE>
 int tile_move(const void *src, void *dst, const vk_render_params *p, const TileGeom &g, hipStream_t st) {
     if (g.n_local == 0) return VK_OK;
     size_t n = (size_t)g.n_local * 64u;
-    hipLaunchKernelGGL(tile_move_kernel<MODE>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, p->width, p->height, g.tiles_x,
+    hipLaunchKernelGGL(tile_move_kernel<MODE>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, p->width, p->height,
+        g.tiles_x,
                        g.rank, g.world, g.n_local);
     HIP_TRY(hipGetLastError());
     return VK_OK;
@@ -322,7 +330,8 @@ uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
 }
 
 // Enqueues one render of this call's tile partition into the f32 framebuffer d_out (device memory of s->device) on `st`.
-int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params *p, float *d_out, hipStream_t st, bool want_debug, vk_stats *stats) {
+int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params *p, float *d_out, hipStream_t st, bool want_debug,
+    vk_stats *stats) {
     HIP_TRY(hipSetDevice(s->device));
     const TileGeom g(p);
     KArgs A;
@@ -397,7 +406,8 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     if (lds) { A.lds_items = s->dev.n_items; A.lds_spheres = s->dev.n_spheres; A.lds_boxes = s->dev.n_boxes; shmem += s->lds_bytes; }
     // persistent grid: enough workgroups to fill the chip, never more than there are units
     const uint64_t n_units = (uint64_t)A.n_local_tiles * A.n_chunks;
-    if (n_units >= 0xFFFFFFFFull) return fail(VK_ERR_BAD_ARG, "tiles x sample chunks exceeds the 32-bit unit counter");    // (choose_chunks keeps it below)
+    // (choose_chunks keeps it below)
+    if (n_units >= 0xFFFFFFFFull) return fail(VK_ERR_BAD_ARG, "tiles x sample chunks exceeds the 32-bit unit counter");
     uint32_t grid = (uint32_t)s->num_cus * s->wgs_per_cu;
     uint64_t need_wgs = (n_units + waves_per_wg - 1) / waves_per_wg;
     if (grid > need_wgs) grid = (uint32_t)need_wgs;
@@ -407,9 +417,11 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     uint32_t F = pick_variant(s) | (p->integrator == VK_INTEGRATOR_PDF ? (uint32_t)VKF_INTEG_PDF : 0u);
     if (use_order && !s->want_phase_stats) {
         KArgs B = A;                                   // the probe: the same view at 1..4 samples per pixel, one unit per tile
-        // (C2, one rank's 1/8 share: probe of 1 / 2 / 4 / 8 / 16 spp -> 68.6 / 69.0 / 69.8 / 70.5 / 73.0 ms: more samples cost more than they sort better)
+        // (C2, one rank's 1/8 share: probe of 1 / 2 / 4 / 8 / 16 spp -> 68.6 / 69.0 / 69.8 / 70.5 / 73.0 ms: more samples cost more than
+        // they sort better)
         B.C.spp = p->samples_per_pixel / 1024u; B.C.spp = B.C.spp < 1u ? 1u : (B.C.spp > 4u ? 4u : B.C.spp);
-        if (s->env.probe_spp >= 1 && (uint32_t)s->env.probe_spp <= p->samples_per_pixel) B.C.spp = (uint32_t)s->env.probe_spp;   // diagnostics
+        // diagnostics
+        if (s->env.probe_spp >= 1 && (uint32_t)s->env.probe_spp <= p->samples_per_pixel) B.C.spp = (uint32_t)s->env.probe_spp;
         // the probe only ranks the tiles: its paths are cut at 16 segments, so that this short launch does not end on a handful of
         // 50-segment paths (one rank's 1/8 share, efficiency against the whole frame / 8 with the cut at 50 / 16 / 8: C2 0.937 / 0.949 /
         // 0.948, C3 0.93 / 0.95 / 0.96, C5 0.957 / 0.957 / 0.951 — deep paths are part of what makes C5's tiles dear)
@@ -427,9 +439,11 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         if (rc != VK_OK) return rc;
         uint32_t nb = (A.n_local_tiles + 255u) / 256u;
         HIP_TRY(hipMemsetAsync(s->order_hist, 0, ORDER_BUCKETS * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(order_hist_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t *)s->tile_cost, A.n_local_tiles, A.tile_rank, A.tile_world, s->order_hist);
+        hipLaunchKernelGGL(order_hist_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t *)s->tile_cost, A.n_local_tiles, A.tile_rank,
+            A.tile_world, s->order_hist);
         hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1), 0, st, s->order_hist);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, st, s->tile_cost, A.n_local_tiles, A.tile_rank, A.tile_world, s->order_hist, s->tile_order);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, st, s->tile_cost, A.n_local_tiles, A.tile_rank, A.tile_world,
+            s->order_hist, s->tile_order);
         HIP_TRY(hipGetLastError());
         A.tile_order = s->tile_order;
     }
@@ -467,7 +481,8 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
 }
 
 // One device: render (f32) and, for RGB8 output, the fused output stage of this partition.
-int enqueue_render_single(vk_scene *s, const vk_camera *cam, const vk_render_params *p, void *d_out, hipStream_t st, bool want_debug, vk_stats *stats) {
+int enqueue_render_single(vk_scene *s, const vk_camera *cam, const vk_render_params *p, void *d_out, hipStream_t st, bool want_debug,
+    vk_stats *stats) {
     if (p->output_format == VK_OUTPUT_F32) return enqueue_render_f32(s, cam, p, reinterpret_cast<float *>(d_out), st, want_debug, stats);
     HIP_TRY(hipSetDevice(s->device));
     int rc = ensure(s->fb, s->fb_bytes, (size_t)p->width * p->height * 3 * sizeof(float));
@@ -524,7 +539,8 @@ int enqueue_render_multi(vk_scene *grp, const vk_camera *cam, const vk_render_pa
         vk_render_params pj = *p;
         pj.tile_rank = geoms[j].rank; pj.tile_world = geoms[j].world;
         HIP_TRY(hipStreamWaitEvent(st0, q->ev_landed, 0));
-        int rc = u8 ? tile_move<TM_UNPACK_U8>(q->landing, d_out, &pj, geoms[j], st0) : tile_move<TM_UNPACK_F32>(q->landing, d_out, &pj, geoms[j], st0);
+        int rc = u8 ? tile_move<TM_UNPACK_U8>(q->landing, d_out, &pj, geoms[j], st0) : tile_move<TM_UNPACK_F32>(q->landing, d_out, &pj,
+            geoms[j], st0);
         if (rc != VK_OK) return rc;
     }
     grp->last_timed = true;
@@ -535,7 +551,8 @@ int enqueue_render_multi(vk_scene *grp, const vk_camera *cam, const vk_render_pa
     return VK_OK;
 }
 
-int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p, void *d_out, hipStream_t st, bool want_debug, vk_stats *stats) {
+int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p, void *d_out, hipStream_t st, bool want_debug,
+    vk_stats *stats) {
     int rc = check_render_args(s, cam, p);
     if (rc != VK_OK) return rc;
     if (!s->parts.empty()) {
@@ -550,7 +567,8 @@ void destroy_one(vk_scene *s) {
     for (vk_scene *q : s->parts) destroy_one(q);
     (void)hipSetDevice(s->device);
     for (void *p : s->allocs) (void)hipFree(p);
-    for (void *p : {(void *)s->counter, (void *)s->fb, (void *)s->fb8, (void *)s->accum, (void *)s->debug, (void *)s->phase_stats, (void *)s->tile_cost,
+    for (void *p : {(void *)s->counter, (void *)s->fb, (void *)s->fb8, (void *)s->accum, (void *)s->debug, (void *)s->phase_stats,
+        (void *)s->tile_cost,
                     (void *)s->tile_order, (void *)s->order_hist, (void *)s->slab})
         if (p) (void)hipFree(p);
     if (s->landing) { (void)hipSetDevice(s->landing_device); (void)hipFree(s->landing); (void)hipSetDevice(s->device); }
@@ -565,10 +583,12 @@ using ScenePtr = std::unique_ptr<vk_scene, SceneDeleter>;
 
 int check_device(int device, hipDeviceProp_t &pr) {
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(VK_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(VK_ERR_NO_DEVICE,
+        "no HIP device visible (this library has no CPU path)");
     if (device < 0 || device >= n) return fail(VK_ERR_BAD_ARG, "device index out of range");
     HIP_TRY(hipGetDeviceProperties(&pr, device));
-    if (strncmp(pr.gcnArchName, "gfx950", 6) != 0) return fail(VK_ERR_NO_DEVICE, std::string("device is ") + pr.gcnArchName + ", this build targets gfx950 only");
+    if (strncmp(pr.gcnArchName, "gfx950", 6) != 0) return fail(VK_ERR_NO_DEVICE,
+        std::string("device is ") + pr.gcnArchName + ", this build targets gfx950 only");
     return VK_OK;
 }
 
@@ -595,7 +615,8 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
 #undef UP
     D.tie_base_rect = H.tie_base_rect; D.tie_base_box = H.tie_base_box; D.tie_base_list = H.tie_base_list;
     D.n_noise_spheres = H.n_noise_spheres;
-    for (int k = 0; k < 4; k++) { D.noise_sphere[k] = H.noise_sphere[k]; D.noise_tex[k] = H.noise_tex[k]; D.noise_perlin[k] = H.noise_perlin[k]; }
+    for (int k = 0; k < 4; k++) { D.noise_sphere[k] = H.noise_sphere[k]; D.noise_tex[k] = H.noise_tex[k];
+        D.noise_perlin[k] = H.noise_perlin[k]; }
     D.n_items = (uint32_t)H.items.size(); D.n_world_items = H.world_items; D.n_spheres = (uint32_t)H.spheres.size();
     D.n_lights = (uint32_t)H.lights.size(); D.features = H.features; D.n_boxes = (uint32_t)H.boxes.size();
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->counter), 256));
@@ -687,7 +708,8 @@ int vk_scene_create_multi(const vk_scene_desc *desc, const int *devices, int n_d
                 if (can) {
                     HIP_TRY(hipSetDevice(devices[j]));
                     hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
-                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(VK_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(VK_ERR_HIP,
+                        std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
                     (void)hipGetLastError();
                 }
             }
@@ -721,9 +743,11 @@ int vk_scene_get_info(const vk_scene *s, vk_scene_info *out) {
     return VK_OK;
 }
 
-int vk_render_device(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, void *d_rgb_out, void *hip_stream, vk_stats *stats_out) {
+int vk_render_device(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, void *d_rgb_out, void *hip_stream,
+    vk_stats *stats_out) {
     if (!d_rgb_out) return fail(VK_ERR_BAD_ARG, "null device framebuffer");
-    return guarded([&]() -> int { return enqueue_render(scene, cam, params, d_rgb_out, reinterpret_cast<hipStream_t>(hip_stream), false, stats_out); });
+    return guarded([&]() -> int { return enqueue_render(scene, cam, params, d_rgb_out, reinterpret_cast<hipStream_t>(hip_stream), false,
+        stats_out); });
 }
 
 // HIP-event time (ms) of the launches enqueued by the last vk_render_device / vk_render on
@@ -772,7 +796,8 @@ int vk_scene_last_clamped_samples(vk_scene *s, uint64_t *out) {
     return VK_OK;
 }
 
-static int render_host(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, void *out_host, vk_stats *stats_out, float *debug_out) {
+static int render_host(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, void *out_host, vk_stats *stats_out,
+    float *debug_out) {
     if (!out_host) return fail(VK_ERR_BAD_ARG, "null framebuffer");
     int rc = check_render_args(scene, cam, params);
     if (rc != VK_OK) return rc;
@@ -817,7 +842,8 @@ static int render_host(vk_scene *scene, const vk_camera *cam, const vk_render_pa
                 memcpy(dst + i, tmp.data() + i, px_bytes);
             }
     }
-    if (debug_out) HIP_TRY(hipMemcpy(debug_out, scene->debug, n_pixels * params->samples_per_pixel * sizeof(float4), hipMemcpyDeviceToHost));
+    if (debug_out) HIP_TRY(hipMemcpy(debug_out, scene->debug, n_pixels * params->samples_per_pixel * sizeof(float4),
+        hipMemcpyDeviceToHost));
     st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (stats_out) *stats_out = st;
     return VK_OK;
@@ -851,7 +877,8 @@ int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_
     if (!out) return fail(VK_ERR_BAD_ARG, "null argument");
     int rc = check_render_args(scene, cam, params);
     if (rc != VK_OK) return rc;
-    if (!scene->parts.empty() || params->output_format != VK_OUTPUT_F32) return fail(VK_ERR_UNSUPPORTED, "phase statistics: single device, VK_OUTPUT_F32");
+    if (!scene->parts.empty() || params->output_format != VK_OUTPUT_F32) return fail(VK_ERR_UNSUPPORTED,
+        "phase statistics: single device, VK_OUTPUT_F32");
     return guarded([&]() -> int {
         HIP_TRY(hipSetDevice(scene->device));
         int rc2 = ensure(scene->fb, scene->fb_bytes, (size_t)params->width * params->height * 3 * sizeof(float));
@@ -879,7 +906,8 @@ int vk_debug_math(int device, int op, const float *a, const float *b, float *out
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dout.p), n * 4 + 16));
     HIP_TRY(hipMemcpy(da.p, a, n * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(db.p, b, n * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, (const float *)da.p, (const float *)db.p, dout.p, n);
+    hipLaunchKernelGGL(math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, (const float *)da.p,
+        (const float *)db.p, dout.p, n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
     return VK_OK;

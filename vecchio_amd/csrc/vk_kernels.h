@@ -117,7 +117,8 @@ template <uint32_t F, bool LDS_SCENE>
 __device__ __forceinline__ typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type make_mem(const DScene &S, uint32_t lds_items) {
     typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type M;
     if constexpr (LDS_SCENE) {
-        M.items = smem; M.items_hi = smem + lds_items; M.items_hi_off = lds_items << 4; M.spheres = reinterpret_cast<const float4 *>(smem + 2u * lds_items);
+        M.items = smem; M.items_hi = smem + lds_items; M.items_hi_off = lds_items << 4;
+        M.spheres = reinterpret_cast<const float4 *>(smem + 2u * lds_items);
         M.boxes = smem + 2u * lds_items + S.n_spheres; M.sphere_mat = S.sphere_mat;
     } else {
         M.items = S.items; M.spheres = S.spheres; M.sphere_mat = S.sphere_mat; M.boxes = S.boxes;
@@ -135,11 +136,13 @@ constexpr int NCOLD_BASE = 9;
 constexpr int NCOLD_INST = 15;
 template <uint32_t F> constexpr int ncold() { return (F & VKF_INSTANCE) ? NCOLD_INST : NCOLD_BASE; }
 constexpr int WAVE_STATE_WORDS = 8;   // per-wave, wave-uniform: the unit whose samples are being handed out (see render_kernel)
-enum : int { WS_TXY = 0, WS_S0 = 1, WS_TOTAL = 2, WS_NEXT = 3,   // one 16-byte record: tile origin (x | y << 16), first sample, items, items handed out
-              WS_KARGS = 4 };                                      // + the kernel-argument segment's address (2 words), for code that is called (shade_refill_call)
+// one 16-byte record: tile origin (x | y << 16), first sample, items, items handed out
+enum : int { WS_TXY = 0, WS_S0 = 1, WS_TOTAL = 2, WS_NEXT = 3,
+              WS_KARGS = 4 };  // + the kernel-argument segment's address (2 words), for code that is called (shade_refill_call)
 
 // per-wave LDS block, contiguous: [cold lane state][tile sums: 64 x 3 x u64][wave state]
-template <uint32_t F> constexpr uint32_t wave_block_floats() { return 64u * (uint32_t)ncold<F>() + 64u * 3u * 2u + (uint32_t)WAVE_STATE_WORDS; }
+template <uint32_t F> constexpr uint32_t wave_block_floats() { return 64u * (uint32_t)ncold<F>() + 64u * 3u * 2u +
+    (uint32_t)WAVE_STATE_WORDS; }
 
 // Pixel sums are ORDER-INDEPENDENT: every finished sample is added to its pixel's three 64-bit fixed-point accumulators
 // (2^-26 units: 1.5e-8 absolute per sample, sums up to 1.4e11) with integer atomics, so the image does not depend on which
@@ -161,7 +164,8 @@ template <uint32_t F>
 __device__ __forceinline__ void cold_store_path(float *c, uint32_t lane, const Lane &L) {
     c[(CF_THR + 0) * 64 + lane] = L.thr.x; c[(CF_THR + 1) * 64 + lane] = L.thr.y; c[(CF_THR + 2) * 64 + lane] = L.thr.z;
     c[CF_DEPTH * 64 + lane] = __uint_as_float(L.depth);
-    c[CF_KEY * 64 + lane] = __uint_as_float((uint32_t)L.rng.key); c[(CF_KEY + 1) * 64 + lane] = __uint_as_float((uint32_t)(L.rng.key >> 32));
+    c[CF_KEY * 64 + lane] = __uint_as_float((uint32_t)L.rng.key);
+    c[(CF_KEY + 1) * 64 + lane] = __uint_as_float((uint32_t)(L.rng.key >> 32));
     c[CF_CTR * 64 + lane] = __uint_as_float(L.rng.ctr);
     if (F & VKF_INSTANCE) {
         c[(CF_WORLD_RAY + 0) * 64 + lane] = L.wo.x; c[(CF_WORLD_RAY + 1) * 64 + lane] = L.wo.y; c[(CF_WORLD_RAY + 2) * 64 + lane] = L.wo.z;
@@ -188,7 +192,8 @@ __device__ __forceinline__ void cold_load_path(const float *c, uint32_t lane, La
 }
 
 // adds the wave's LDS sums of tile `txy` (x | y << 16 of its origin; lane = pixel slot) to the frame's accumulators and clears them
-__device__ __forceinline__ void flush_tile_sums(unsigned long long *tile_sum, long long *accum, uint32_t txy, uint32_t lane, uint32_t width, uint32_t height) {
+__device__ __forceinline__ void flush_tile_sums(unsigned long long *tile_sum, long long *accum, uint32_t txy, uint32_t lane,
+    uint32_t width, uint32_t height) {
     uint32_t px = (txy & 0xFFFFu) + (lane & 7u), py = (txy >> 16) + (lane >> 3);
     if (!accum || txy == 0xFFFFFFFFu || px >= width || py >= height) return;
     unsigned long long *a = reinterpret_cast<unsigned long long *>(accum) + ((size_t)py * width + px) * 3;
@@ -202,7 +207,8 @@ __device__ __forceinline__ void flush_tile_sums(unsigned long long *tile_sum, lo
 // lane mask of prim_is_heavy<F>(ref), straight from the compare
 template <uint32_t F>
 __device__ __forceinline__ unsigned long long heavy_mask(uint32_t ref) {
-    if constexpr ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) return __builtin_amdgcn_uicmp(ref - ((uint32_t)DK_LIST << 28), 3u << 28, 36 /* ult */);
+    if constexpr ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) return __builtin_amdgcn_uicmp(ref - ((uint32_t)DK_LIST << 28), 3u << 28,
+        36 /* ult */);
     else return __builtin_amdgcn_uicmp(ref, (uint32_t)DK_LIST << 28, 35 /* uge */);
 }
 __device__ __forceinline__ uint32_t lanes_with(bool p) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p)); }
@@ -271,7 +277,8 @@ __device__ __forceinline__ PreTurb cooperative_turb(const Lane &L, const DScene 
                     accum += weight * __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(ga, (int)__float_as_uint(n)));
                     weight *= 0.5f;
                 }
-                if (pt.tex != 0xFFFFFFFFu && slot < 9u) pt.val = fabsf(accum);     // (my_rank >= base for lanes not served yet; < base wraps to huge)
+                // (my_rank >= base for lanes not served yet; < base wraps to huge)
+                if (pt.tex != 0xFFFFFFFFu && slot < 9u) pt.val = fabsf(accum);
                 base += 9u;
             }
         }
@@ -281,11 +288,13 @@ __device__ __forceinline__ PreTurb cooperative_turb(const Lane &L, const DScene 
 
 // ---- the SHADE + REFILL phase body: shade the lanes whose segment is fully traversed, deposit finished samples, hand new
 // samples to the lanes without a path.  Leaves `fresh` lanes with a new ray parked in L.wo / L.wd / L.time, which the caller
-// installs with ONE begin_segment (its three exact reciprocals are ~60 instructions per call site).  Used inline by the lean variants and through shade_refill_call (below) by the everything-variants.
+// installs with ONE begin_segment (its three exact reciprocals are ~60 instructions per call site). Used inline by the lean variants and
+// through shade_refill_call (below) by the everything-variants.
 struct PhaseClocks { unsigned long long mat = 0, refill = 0, t1 = 0; };
 template <uint32_t F, bool LDS_SCENE, bool STATS, bool COST>
-__device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &active, bool &need, bool &fresh, bool &touched, uint32_t &cost_t0,
-                                                  KArgsC P, float *cold, unsigned long long *tile_sum, uint32_t *wstate, uint32_t lane, uint32_t lds_items, PhaseClocks &clk) {
+__device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &active, bool &need, bool &fresh, bool &touched,
+                                                  uint32_t &cost_t0, KArgsC P, float *cold, unsigned long long *tile_sum,
+                                                  uint32_t *wstate, uint32_t lane, uint32_t lds_items, PhaseClocks &clk) {
     using Mem = typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type;
     RenderConsts C = KARG(P, C);
     DScene S = KARG(P, S);
@@ -307,12 +316,14 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &
             uint32_t xy = __float_as_uint(cold[CF_XY * 64 + lane]);
             size_t pix = (size_t)(xy >> 16) * C.width + (xy & 0xFFFFu);
             float4 *dbg = KARG(P, debug);
-            if (dbg) dbg[pix * C.spp + __float_as_uint(cold[CF_SAMPLE * 64 + lane])] = make_float4(L.acc.x, L.acc.y, L.acc.z, __uint_as_float(L.rng.ctr));
+            if (dbg) dbg[pix * C.spp + __float_as_uint(cold[CF_SAMPLE * 64 + lane])] = make_float4(L.acc.x, L.acc.y, L.acc.z,
+                __uint_as_float(L.rng.ctr));
             long long *acc = KARG(P, accum);
             if (acc && isfinite(L.acc.x) && isfinite(L.acc.y) && isfinite(L.acc.z)) {   // main.rs:192-194; c += color (main.rs:193)
                 const float clampv = accum_clamp_for(C.spp);
                 if (fmaxf(fmaxf(fabsf(L.acc.x), fabsf(L.acc.y)), fabsf(L.acc.z)) > clampv) atomicAdd(KARG(P, clamped), 1ull);     // (rare)
-                unsigned long long fx = (unsigned long long)to_fixed(L.acc.x, clampv), fy = (unsigned long long)to_fixed(L.acc.y, clampv), fz = (unsigned long long)to_fixed(L.acc.z, clampv);
+                unsigned long long fx = (unsigned long long)to_fixed(L.acc.x, clampv), fy = (unsigned long long)to_fixed(L.acc.y, clampv),
+                    fz = (unsigned long long)to_fixed(L.acc.z, clampv);
                 // a sample of the tile the wave is handing out (nearly all of them) lands in the wave's LDS sums, which
                 // reach the frame's accumulators once per unit; a straggler of an earlier unit goes there directly
                 if ((xy & 0xFFF8FFF8u) == __builtin_amdgcn_readfirstlane(wstate[WS_TXY])) {
@@ -405,7 +416,8 @@ __device__ __attribute__((noinline)) ShadeIo shade_refill_call(ShadeIo io, uint3
     uint32_t *wstate = reinterpret_cast<uint32_t *>(cold + 64 * ncold<F>() + 64 * 3 * 2);
     KArgsC P;
     {
-        uint64_t a = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(wstate[WS_KARGS]) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(wstate[WS_KARGS + 1]) << 32);
+        uint64_t a = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(wstate[WS_KARGS]) |
+                     ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(wstate[WS_KARGS + 1]) << 32);
         P = (KArgsC)a;
         asm volatile("" : "+s"(P));
     }
@@ -416,8 +428,10 @@ __device__ __attribute__((noinline)) ShadeIo shade_refill_call(ShadeIo io, uint3
     bool active = (io.flags & 2u) != 0u, need = (io.flags & 4u) != 0u, fresh = false, touched = false;
     uint32_t cost_t0 = io.cost_t0;
     PhaseClocks clk;
-    shade_refill_body<F, LDS_SCENE, false, COST>(L, (io.flags & 1u) != 0u, active, need, fresh, touched, cost_t0, P, cold, tile_sum, wstate, lane, lds_items, clk);
-    if (active && touched) cold_store_path<F>(cold, lane, L);      // fresh lanes: L.wo / L.wd hold the NEW ray, which is what the world-ray slots want
+    shade_refill_body<F, LDS_SCENE, false, COST>(L, (io.flags & 1u) != 0u, active, need, fresh, touched, cost_t0, P, cold, tile_sum,
+        wstate, lane, lds_items, clk);
+    // fresh lanes: L.wo / L.wd hold the NEW ray, which is what the world-ray slots want
+    if (active && touched) cold_store_path<F>(cold, lane, L);
     ShadeIo out = io;
     out.flags = (active ? 2u : 0u) | (need ? 4u : 0u) | (fresh ? 8u : 0u) | (touched ? 16u : 0u);
     out.o = L.wo; out.d = L.wd; out.time = L.time; out.cost_t0 = cost_t0;
@@ -428,7 +442,8 @@ __device__ __attribute__((noinline)) ShadeIo shade_refill_call(ShadeIo io, uint3
 // out to its lanes sample by sample (item k -> pixel slot k & 63, sample s0 + (k >> 6): the 64 primary rays of one sample
 // index start together, which keeps the first segments coherent).  A lane whose path ended takes the next item by ballot +
 // prefix popcount (active-ray compaction), and the wave pulls the NEXT unit the moment the current one is handed out:
-// nobody waits for the slowest path of a unit (the "drain" cost 5 % on C2 and most of the lanes on C5).  That is possible because pixel sums are order independent (to_fixed above).
+// nobody waits for the slowest path of a unit (the "drain" cost 5 % on C2 and most of the lanes on C5). That is possible because pixel sums
+// are order independent (to_fixed above).
 template <uint32_t F, bool LDS_SCENE, int MINW, bool STATS, bool COST = false>
 __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ? 768 : 1024))), MINW) void render_kernel(KArgs A_byval) {
     (void)A_byval;
@@ -436,8 +451,10 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
     const uint32_t wave = threadIdx.x >> 6;
     using Mem = typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type;
     // diagnostic counters (STATS build only): phase executions and the lanes that had work in them
-    unsigned long long st_box_steps = 0, st_box_lanes = 0, st_prim_execs = 0, st_prim_lanes = 0, st_shade_execs = 0, st_shade_lanes = 0, st_sched = 0;
-    unsigned long long st_t_box = 0, st_t_light = 0, st_t_heavy = 0, st_t_shade = 0, st_heavy_execs = 0, st_t0 = 0, st_t_total = 0, st_t_mat = 0, st_t_refill = 0, st_t_install = 0, st_t1 = 0;
+    unsigned long long st_box_steps = 0, st_box_lanes = 0, st_prim_execs = 0, st_prim_lanes = 0, st_shade_execs = 0, st_shade_lanes = 0,
+        st_sched = 0;
+    unsigned long long st_t_box = 0, st_t_light = 0, st_t_heavy = 0, st_t_shade = 0, st_heavy_execs = 0, st_t0 = 0, st_t_total = 0,
+        st_t_mat = 0, st_t_refill = 0, st_t_install = 0, st_t1 = 0;
     if (STATS) st_t_total = clock64();
 
     // ---- LDS layout: [items][spheres][boxes][per wave: cold lane state | tile sums | wave state]
@@ -532,7 +549,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
 #ifndef VK_CORNELL_UNROLL
 #define VK_CORNELL_UNROLL 3
 #endif
-            constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? BOX_UNROLL + 1 : (SPHERES ? (LDS_SCENE ? BOX_UNROLL - 1 : BOX_UNROLL) : VK_CORNELL_UNROLL);
+            constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE)
+                ? BOX_UNROLL + 1 : (SPHERES ? (LDS_SCENE ? BOX_UNROLL - 1 : BOX_UNROLL) : VK_CORNELL_UNROLL);
             // The lane masks of the states come straight out of compares (uicmp = v_cmp into an SGPR pair) and are combined and
             // counted with scalar instructions; a ballot of a compound lane boolean goes through a VGPR (v_cndmask 0/1 + v_cmp_ne)
             // for every term.  The lanes that step are the box lanes of the last exit test: their mask is at hand in SGPRs and
@@ -548,7 +566,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 if (F & VKF_INSTANCE) {     // end of an instance's item range: back to the parent space (rare)
                     const unsigned long long m_leave = m_act & ~m_pend & ~m_lt & m_inst;
                     if (m_leave != 0ull) {
-                        if (__builtin_amdgcn_inverse_ballot_w64(m_leave)) { cold_load_world_ray<F>(cold, lane, L); leave_instance<F, Mem>(L, S); }
+                        if (__builtin_amdgcn_inverse_ballot_w64(m_leave)) { cold_load_world_ray<F>(cold, lane, L);
+                            leave_instance<F, Mem>(L, S); }
                         masks();
                     }
                 }
@@ -567,7 +586,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 const unsigned long long m_prim = m_pend & m_act, m_box = (m_lt | m_inst) & ~m_pend & m_act;
                 const uint32_t nb = (uint32_t)__builtin_popcountll(m_box), np = (uint32_t)__builtin_popcountll(m_prim);
                 const uint32_t ns = live - nb - np;
-                if (STATS && !HAS_HEAVY) { st_heavy_execs += live; st_t_light += np; st_t_heavy += ns; st_prim_execs += 1; }   // sphere-only diagnostic: lanes per exit test
+                // sphere-only diagnostic: lanes per exit test
+                if (STATS && !HAS_HEAVY) { st_heavy_execs += live; st_t_light += np; st_t_heavy += ns; st_prim_execs += 1; }
                 // keep stepping while nb != 0, nb >= np * prim_weight and nb * shade_defer >= ns: as sign tests of differences (the
                 // counts are < 2^7), which is a third of the scalar instructions of three compares or-ed together
                 const int keep1 = (int)nb - (int)(np * prim_weight > 1u ? np * prim_weight : 1u), keep2 = (int)(nb * shade_defer) - (int)ns;
@@ -577,7 +597,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     // ~10 box steps
                     const unsigned long long m_light = HAS_HEAVY ? (m_prim & ~heavy_mask<F>(L.pend)) : m_prim;
                     const uint32_t nl = (uint32_t)__builtin_popcountll(m_light);
-                    if ((((int)nl - 1) | ((int)(2u * nl) - (int)np) | ((int)(nl * shade_defer) - (int)ns)) >= 0) {   // nl != 0, 2 nl >= np, nl * shade_defer >= ns
+                    // nl != 0, 2 nl >= np, nl * shade_defer >= ns
+                    if ((((int)nl - 1) | ((int)(2u * nl) - (int)np) | ((int)(nl * shade_defer) - (int)ns)) >= 0) {
                         if (__builtin_amdgcn_inverse_ballot_w64(m_light)) prim_step<F, Mem>(L, S, M);
                         masks();
                         continue;
@@ -594,7 +615,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             if (STATS) { st_prim_execs++; st_prim_lanes += n_prim; st_t0 = clock64(); if (n_heavy > n_light) st_heavy_execs++; }
             if (__builtin_amdgcn_inverse_ballot_w64(n_heavy > n_light ? m_heavy : m_light)) {
                 if (F & VKF_MEDIUM) {    // ConstantMedium::hit draws inside traversal (hittable.rs:473)
-                    L.rng.key = (uint64_t)__float_as_uint(cold[CF_KEY * 64 + lane]) | ((uint64_t)__float_as_uint(cold[(CF_KEY + 1) * 64 + lane]) << 32);
+                    L.rng.key = (uint64_t)__float_as_uint(cold[CF_KEY * 64 + lane]) |
+                                ((uint64_t)__float_as_uint(cold[(CF_KEY + 1) * 64 + lane]) << 32);
                     L.rng.ctr = __float_as_uint(cold[CF_CTR * 64 + lane]);
                 }
                 prim_step<F, Mem>(L, S, M);
@@ -606,7 +628,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             if (STATS) { st_shade_execs++; st_shade_lanes += n_sn; st_t0 = clock64(); }
             // out of line for the everything-variants (see shade_refill_call); one begin_segment for both kinds of new ray
             // ... and for the 8-waves-per-SIMD build of the sphere-only variants (scenes traversed from global memory: every box step a
-            // dependent gather, so more waves in flight pay — C5 629 -> 685 Msamples/s — and 64 VGPRs hold the traversal loops but not shading)
+            // dependent gather, so more waves in flight pay — C5 629 -> 685 Msamples/s — and 64 VGPRs hold the traversal loops but not
+            // shading)
             constexpr bool SPLIT = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE || MINW == 8) && !STATS;
             const bool is_shade = __builtin_amdgcn_inverse_ballot_w64(m_shade);
             bool touched = false, fresh = false;
@@ -621,16 +644,19 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 if (fresh) {
                     KArgsC P = kargs_fresh();
                     DScene S = KARG(P, S);
-                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, io.o, io.d, io.time);      // (the callee stored the path state, new world ray included)
+                    // (the callee stored the path state, new world ray included)
+                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, io.o, io.d, io.time);
                 }
             } else {
                 PhaseClocks clk;
-                shade_refill_body<F, LDS_SCENE, STATS, COST>(L, is_shade, active, need, fresh, touched, cost_t0, kargs_fresh(), cold, tile_sum, wstate, lane, lds_items, clk);
+                shade_refill_body<F, LDS_SCENE, STATS, COST>(L, is_shade, active, need, fresh, touched, cost_t0, kargs_fresh(), cold,
+                    tile_sum, wstate, lane, lds_items, clk);
                 if (STATS) { st_t_mat += clk.mat; st_t_refill += clk.refill; st_t1 = clock64(); }
                 if (fresh) {
                     KArgsC P = kargs_fresh();
                     DScene S = KARG(P, S);
-                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, L.wo, L.wd, L.time);   // one copy of the exact reciprocals for both kinds of new ray
+                    // one copy of the exact reciprocals for both kinds of new ray
+                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, L.wo, L.wd, L.time);
                 }
                 if (active && touched) cold_store_path<F>(cold, lane, L);
                 if (STATS) st_t_install += clock64() - st_t1;
@@ -641,14 +667,17 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
     }
     {   // the last unit's sums
         KArgsC P = kargs_fresh();
-        flush_tile_sums(tile_sum, KARG(P, accum), __builtin_amdgcn_readfirstlane(wstate[WS_TXY]), lane, KARG(P, C.width), KARG(P, C.height));
+        flush_tile_sums(tile_sum, KARG(P, accum), __builtin_amdgcn_readfirstlane(wstate[WS_TXY]), lane, KARG(P, C.width),
+            KARG(P, C.height));
     }
     if (STATS) {
         KArgsC P = kargs_fresh();
         unsigned long long *ps = KARG(P, phase_stats);
         if (ps && lane == 0) {
-            atomicAdd(&ps[0], st_box_steps); atomicAdd(&ps[1], st_box_lanes); atomicAdd(&ps[2], st_prim_execs); atomicAdd(&ps[3], st_prim_lanes);
-            atomicAdd(&ps[4], st_shade_execs); atomicAdd(&ps[5], st_shade_lanes); atomicAdd(&ps[6], st_sched); atomicAdd(&ps[7], st_heavy_execs);
+            atomicAdd(&ps[0], st_box_steps); atomicAdd(&ps[1], st_box_lanes); atomicAdd(&ps[2], st_prim_execs);
+            atomicAdd(&ps[3], st_prim_lanes);
+            atomicAdd(&ps[4], st_shade_execs); atomicAdd(&ps[5], st_shade_lanes); atomicAdd(&ps[6], st_sched);
+            atomicAdd(&ps[7], st_heavy_execs);
             atomicAdd(&ps[8], st_t_box); atomicAdd(&ps[9], st_t_light); atomicAdd(&ps[10], st_t_heavy); atomicAdd(&ps[11], st_t_shade);
             atomicAdd(&ps[12], (unsigned long long)(clock64() - st_t_total));
             atomicAdd(&ps[13], st_t_mat); atomicAdd(&ps[14], st_t_refill); atomicAdd(&ps[15], st_t_install);
@@ -673,7 +702,8 @@ __global__ void order_scan_kernel(uint32_t *hist) {      // one thread: start of
     uint32_t run = 0;
     for (int b = (int)ORDER_BUCKETS - 1; b >= 0; b--) { uint32_t c = hist[b]; hist[b] = run; run += c; }
 }
-__global__ void order_scatter_kernel(uint32_t *cost, uint32_t n_local, uint32_t tile_rank, uint32_t tile_world, uint32_t *hist, uint32_t *order) {
+__global__ void order_scatter_kernel(uint32_t *cost, uint32_t n_local, uint32_t tile_rank, uint32_t tile_world, uint32_t *hist,
+    uint32_t *order) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_local) return;
     uint32_t t = tile_rank + i * tile_world;
@@ -760,7 +790,8 @@ __global__ void math_probe_kernel(int op, const float *a, const float *b, float 
         case 5: r = vk::pow5f_(a[i]); break;
         case 6: r = a[i] / b[i]; break;
         case 7: r = sqrtf(a[i]); break;
-        case 8: { vk::Rng g = vk::rng_for_sample(__float_as_uint(a[i]), (uint32_t)i, 0); r = vk::gen_range(g, -1.0f, 1.0f) + vk::gen_f32(g); break; }
+        case 8: { vk::Rng g = vk::rng_for_sample(__float_as_uint(a[i]), (uint32_t)i, 0);
+            r = vk::gen_range(g, -1.0f, 1.0f) + vk::gen_f32(g); break; }
         case 9: r = a[i] * b[i] + a[i]; break;   // must stay an unfused mul+add
     }
     out[i] = r;

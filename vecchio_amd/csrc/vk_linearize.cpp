@@ -174,7 +174,8 @@ struct Builder {
             } else if (k == VK_KIND_ROTATE) {
                 const vk_rotate &t = d->rotates[i];
                 if (t.axis > 2) return fail(VK_ERR_BAD_ARG, "rotate axis out of range");
-                DOp op; op.kind = t.axis == 0 ? OP_ROTATE_X : (t.axis == 1 ? OP_ROTATE_Y : OP_ROTATE_Z); op.a = t.sin_theta; op.b = t.cos_theta; op.c = 0.0f;
+                DOp op; op.kind = t.axis == 0 ? OP_ROTATE_X : (t.axis == 1 ? OP_ROTATE_Y : OP_ROTATE_Z); op.a = t.sin_theta;
+                op.b = t.cos_theta; op.c = 0.0f;
                 I.ops[I.n_ops++] = op;
                 cur = t.child;
             } else break;
@@ -230,7 +231,8 @@ struct Builder {
         return it;
     }
 
-    static bool draw_free(uint32_t dref) { uint32_t k = VKD_KIND(dref); return k == DK_SPHERE || k == DK_MOVING || k == DK_RECT || k == DK_LIST || k == DK_BOX; }
+    static bool draw_free(uint32_t dref) { uint32_t k = VKD_KIND(dref);
+        return k == DK_SPHERE || k == DK_MOVING || k == DK_RECT || k == DK_LIST || k == DK_BOX; }
 
     // ------------------------------------------------------------------ re-treeing of draw-free subtrees
     // BVHNode::hit (accel.rs:58-83) returns the closest hit of its subtree, and for a subtree whose objects are all
@@ -317,7 +319,8 @@ struct Builder {
             for (int x = 0; x < 3; x++) inverted |= !(a[x] <= b[x]);
             if (j == 0) { memcpy(mn, a, 12); memcpy(mx, b, 12); } else rt_grow(mn, mx, a, b);
         }
-        if (inverted) { mn[0] = 1.0f; mx[0] = 0.0f; }      // a hollow sphere among the items: reported as an inverted box, like the sphere itself
+        // a hollow sphere among the items: reported as an inverted box, like the sphere itself
+        if (inverted) { mn[0] = 1.0f; mx[0] = 0.0f; }
         return true;
     }
 
@@ -333,15 +336,18 @@ struct Builder {
             if (VK_REF_KIND(fr.ref) != VK_KIND_BVH) in_block[fr.ref & ~VK_REF_FLIP]++;
             if (VK_REF_KIND(fr.ref) == VK_KIND_BVH) {
                 const vk_bvh_node &n = d->bvh[VK_REF_INDEX(fr.ref)];
-                bool dup = n.left == n.right && VK_REF_KIND(n.left) != VK_KIND_BVH;   // len == 1: the same object twice, the second test is a no-op
-                if (!dup) st.push_back(Fr{n.right, fr.flip ^ ((VK_REF_KIND(n.right) == VK_KIND_BVH && (n.right & VK_REF_FLIP)) ? DREF_FLIP : 0u)});
+                // len == 1: the same object twice, the second test is a no-op
+                bool dup = n.left == n.right && VK_REF_KIND(n.left) != VK_KIND_BVH;
+                if (!dup) st.push_back(Fr{n.right, fr.flip ^ ((VK_REF_KIND(n.right) == VK_KIND_BVH && (n.right & VK_REF_FLIP))
+                    ? DREF_FLIP : 0u)});
                 st.push_back(Fr{n.left, fr.flip ^ ((VK_REF_KIND(n.left) == VK_KIND_BVH && (n.left & VK_REF_FLIP)) ? DREF_FLIP : 0u)});
                 continue;
             }
             RtObj o;
             if (!rt_bounds(fr.ref, o.mn, o.mx)) { ok = false; return status == VK_OK; }
             for (int a = 0; a < 3; a++) {
-                if (!(o.mn[a] <= o.mx[a]) || !std::isfinite(o.mn[a]) || !std::isfinite(o.mx[a])) { ok = false; return true; }   // NaN / inverted box: keep the reference's tree
+                // NaN / inverted box: keep the reference's tree
+                if (!(o.mn[a] <= o.mx[a]) || !std::isfinite(o.mn[a]) || !std::isfinite(o.mx[a])) { ok = false; return true; }
                 o.c[a] = 0.5f * o.mn[a] + 0.5f * o.mx[a];
             }
             if (!convert_object(fr.ref, fr.flip, inst, o.dref)) return false;
@@ -395,17 +401,20 @@ struct Builder {
                         for (size_t i = fr.begin; i < fr.end; i++) {
                             int b = (int)((objs[i].c[ax] - cmin[ax]) * scale);
                             b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
-                            if (cnt[b]++ == 0) { memcpy(bmn[b], objs[i].mn, 12); memcpy(bmx[b], objs[i].mx, 12); } else rt_grow(bmn[b], bmx[b], objs[i].mn, objs[i].mx);
+                            if (cnt[b]++ == 0) { memcpy(bmn[b], objs[i].mn, 12); memcpy(bmx[b], objs[i].mx, 12);
+                                } else rt_grow(bmn[b], bmx[b], objs[i].mn, objs[i].mx);
                         }
                         double la[NB]; size_t ln[NB];
                         float amn[3], amx[3]; size_t n = 0;
                         for (int b = 0; b < NB; b++) {
-                            if (cnt[b]) { if (n == 0) { memcpy(amn, bmn[b], 12); memcpy(amx, bmx[b], 12); } else rt_grow(amn, amx, bmn[b], bmx[b]); n += cnt[b]; }
+                            if (cnt[b]) { if (n == 0) { memcpy(amn, bmn[b], 12); memcpy(amx, bmx[b], 12);
+                                } else rt_grow(amn, amx, bmn[b], bmx[b]); n += cnt[b]; }
                             la[b] = n ? (double)rt_half_area(amn, amx) : 0.0; ln[b] = n;
                         }
                         n = 0;
                         for (int b = NB - 1; b >= 1; b--) {
-                            if (cnt[b]) { if (n == 0) { memcpy(amn, bmn[b], 12); memcpy(amx, bmx[b], 12); } else rt_grow(amn, amx, bmn[b], bmx[b]); n += cnt[b]; }
+                            if (cnt[b]) { if (n == 0) { memcpy(amn, bmn[b], 12); memcpy(amx, bmx[b], 12);
+                                } else rt_grow(amn, amx, bmn[b], bmx[b]); n += cnt[b]; }
                             if (n == 0 || ln[b - 1] == 0) continue;
                             double cost = la[b - 1] * (double)ln[b - 1] + (double)rt_half_area(amn, amx) * (double)n;
                             if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = b; }
@@ -487,8 +496,10 @@ struct Builder {
         if (!rt_collect(root, flip, inst, objs, ok)) return false;
         if (!ok || objs.size() < RETREE_MIN || objs.size() >= (1u << 20)) {
             // keep the reference's tree for this subtree: undo what collecting converted (memo entries past the old sizes)
-            L.items.resize(items0); L.boxes.resize(boxes0); L.lists.resize(lists0); L.list_refs.resize(refs0); L.n_prims = prims0; L.features = feat0;
-            for (auto it = box_memo.begin(); it != box_memo.end();) { if (it->second != 0xFFFFFFFFu && it->second >= boxes0) it = box_memo.erase(it); else ++it; }
+            L.items.resize(items0); L.boxes.resize(boxes0); L.lists.resize(lists0); L.list_refs.resize(refs0); L.n_prims = prims0;
+            L.features = feat0;
+            for (auto it = box_memo.begin(); it != box_memo.end();) { if (it->second != 0xFFFFFFFFu &&
+                it->second >= boxes0) it = box_memo.erase(it); else ++it; }
             for (auto it = list_memo.begin(); it != list_memo.end();) { if (it->second >= lists0) it = list_memo.erase(it); else ++it; }
             return true;
         }
@@ -591,7 +602,8 @@ struct Builder {
             const vk_texture &t = d->textures[i];
             DTexture o; memset(&o, 0, sizeof(o));
             o.kind = t.kind; o.r = t.color[0]; o.g = t.color[1]; o.b = t.color[2]; o.a = t.a; o.b_ = t.b; o.scale = t.scale;
-            if (t.kind == VK_TEX_CHECKER) { if (t.a >= d->n_textures || t.b >= d->n_textures) return fail(VK_ERR_BAD_ARG, "checker child out of range"); }
+            if (t.kind == VK_TEX_CHECKER) { if (t.a >= d->n_textures || t.b >= d->n_textures) return fail(VK_ERR_BAD_ARG,
+                "checker child out of range"); }
             else if (t.kind == VK_TEX_IMAGE) { if (t.a >= d->n_images) return fail(VK_ERR_BAD_ARG, "image index out of range"); }
             else if (t.kind == VK_TEX_NOISE) { if (t.a >= d->n_perlins) return fail(VK_ERR_BAD_ARG, "perlin index out of range"); }
             else if (t.kind != VK_TEX_SOLID) return fail(VK_ERR_BAD_ARG, "unknown texture kind");
@@ -613,7 +625,8 @@ struct Builder {
             DPerlin o;
             for (int k = 0; k < 256; k++) {
                 o.ranvec[k][0] = p.ranvec[k][0]; o.ranvec[k][1] = p.ranvec[k][1]; o.ranvec[k][2] = p.ranvec[k][2];
-                o.perm_x[k] = (uint8_t)(p.perm_x[k] & 255u); o.perm_y[k] = (uint8_t)(p.perm_y[k] & 255u); o.perm_z[k] = (uint8_t)(p.perm_z[k] & 255u);
+                o.perm_x[k] = (uint8_t)(p.perm_x[k] & 255u); o.perm_y[k] = (uint8_t)(p.perm_y[k] & 255u);
+                o.perm_z[k] = (uint8_t)(p.perm_z[k] & 255u);
             }
             L.perlins.push_back(o);
         }
@@ -621,14 +634,16 @@ struct Builder {
             const vk_material &m = d->materials[i];
             DMaterial o; memset(&o, 0, sizeof(o));
             o.kind = m.kind; o.tex = m.texture; o.param = m.param; o.tex_kind = VK_TEX_SOLID;
-            bool needs_tex = m.kind == VK_MAT_LAMBERTIAN || m.kind == VK_MAT_METAL || m.kind == VK_MAT_DIFFUSE_LIGHT || m.kind == VK_MAT_ISOTROPIC;
+            bool needs_tex = m.kind == VK_MAT_LAMBERTIAN || m.kind == VK_MAT_METAL || m.kind == VK_MAT_DIFFUSE_LIGHT ||
+                m.kind == VK_MAT_ISOTROPIC;
             if (needs_tex) {
                 if (m.texture >= d->n_textures) return fail(VK_ERR_BAD_ARG, "texture index out of range");
                 const vk_texture &t = d->textures[m.texture];
                 o.tex_kind = t.kind; o.r = t.color[0]; o.g = t.color[1]; o.b = t.color[2];
             } else if (m.kind == VK_MAT_SPEC_DIFFUSE) {
                 if (m.a >= d->n_materials || m.b >= d->n_materials) return fail(VK_ERR_BAD_ARG, "spec_diffuse child out of range");
-                if (m.a >= 65536 || m.b >= 65536) return fail(VK_ERR_UNSUPPORTED, "device path: SpecDiffuse children must have material index < 65536");
+                if (m.a >= 65536 || m.b >= 65536) return fail(VK_ERR_UNSUPPORTED,
+                    "device path: SpecDiffuse children must have material index < 65536");
                 o.ab = m.a | (m.b << 16);
                 L.features |= VKF_SPEC_DIFFUSE | VKF_TEXTURES;
             } else if (m.kind != VK_MAT_DIELECTRIC) return fail(VK_ERR_BAD_ARG, "unknown material kind");
@@ -640,7 +655,8 @@ struct Builder {
     bool run() {
         if (!d) return fail(VK_ERR_BAD_ARG, "null scene description");
         if (d->abi_version != VK_ABI_VERSION) return fail(VK_ERR_BAD_ARG, "abi version mismatch");
-        L.tie_base_rect = d->n_spheres; L.tie_base_box = d->n_spheres + d->n_rects; L.tie_base_list = d->n_spheres + d->n_rects + d->n_lists;
+        L.tie_base_rect = d->n_spheres; L.tie_base_box = d->n_spheres + d->n_rects;
+        L.tie_base_list = d->n_spheres + d->n_rects + d->n_lists;
         if (!materials_and_textures()) return false;
         for (uint32_t i = 0; i < d->n_spheres; i++) {
             const vk_sphere &s = d->spheres[i];
@@ -648,9 +664,11 @@ struct Builder {
             L.spheres.push_back(DSphere{s.center[0], s.center[1], s.center[2], s.radius});
             L.sphere_mat.push_back(s.material);
             const DMaterial &sm = L.materials[s.material];
-            if (sm.tex_kind == VK_TEX_NOISE && L.n_noise_spheres != 0xFFFFFFFFu) {       // (tex_kind is only set for materials that read a texture)
+            // (tex_kind is only set for materials that read a texture)
+            if (sm.tex_kind == VK_TEX_NOISE && L.n_noise_spheres != 0xFFFFFFFFu) {
                 if (L.n_noise_spheres < 4u) {
-                    L.noise_sphere[L.n_noise_spheres] = i; L.noise_tex[L.n_noise_spheres] = sm.tex; L.noise_perlin[L.n_noise_spheres] = L.textures[sm.tex].a;
+                    L.noise_sphere[L.n_noise_spheres] = i; L.noise_tex[L.n_noise_spheres] = sm.tex;
+                    L.noise_perlin[L.n_noise_spheres] = L.textures[sm.tex].a;
                     L.n_noise_spheres++;
                 } else L.n_noise_spheres = 0xFFFFFFFFu;
             }
@@ -695,10 +713,12 @@ struct Builder {
             uint32_t out = 0;   // kinds without pdf_value/random impls behave as the trait defaults
             if (k == VK_KIND_RECT && !(r & VK_REF_FLIP)) {
                 const vk_rect &q = d->rects[VK_REF_INDEX(r)];
-                if (!(q.c0 < q.c1) || !(q.d0 < q.d1)) return fail(VK_ERR_BAD_ARG, "light Rect with an empty extent (gen_range(c0,c1) panics, hittable.rs:287-288)");
+                if (!(q.c0 < q.c1) || !(q.d0 < q.d1)) return fail(VK_ERR_BAD_ARG,
+                    "light Rect with an empty extent (gen_range(c0,c1) panics, hittable.rs:287-288)");
             }
             if (k == VK_KIND_SPHERE || k == VK_KIND_RECT) out = simple_dref(r, 0);
-            else if (k == VK_KIND_LIST) { uint32_t li; if (!convert_list(VK_REF_INDEX(r), li)) return false; out = VKD_MAKE(DK_LIST, li) | ((r & VK_REF_FLIP) ? DREF_FLIP : 0u); }
+            else if (k == VK_KIND_LIST) { uint32_t li; if (!convert_list(VK_REF_INDEX(r), li)) return false;
+                out = VKD_MAKE(DK_LIST, li) | ((r & VK_REF_FLIP) ? DREF_FLIP : 0u); }
             L.lights.push_back(out);
         }
         return status == VK_OK;

@@ -73,7 +73,8 @@ struct GlobalMem {
 struct Lane {
     // current-space ray (object space while inside an instance)
     V3 o, d; float time;
-    V3 inv; float a; float xnan;   // xnan: the additive part of the box test's margin (0 unfused), or NaN when its fast path must not be trusted
+    // xnan: the additive part of the box test's margin (0 unfused), or NaN when its fast path must not be trusted
+    V3 inv; float a; float xnan;
     V3 oi;                     // o * (1/d): fused box test only (set_space)
     V3 wo, wd;                 // world-space ray of this segment
     // traversal cursor
@@ -227,12 +228,14 @@ VK_HD bool simple_t(const DScene &S, const Mem &M, uint32_t ref, V3 o, V3 d, flo
     uint32_t k = VKD_KIND(ref), idx = VKD_INDEX(ref);
     if (k == DK_SPHERE) { DSphere s = M.sphere(idx); return sphere_t(s.cx, s.cy, s.cz, s.r, o, d, a, tmin, tmax, t); }
     if (k == DK_RECT) return rect_t(S.rects[idx], o, d, tmin, tmax, t);
-    if (k == DK_MOVING) { const DMoving &m = S.moving[idx]; V3 c = moving_center(m, time); return sphere_t(c.x, c.y, c.z, m.r, o, d, a, tmin, tmax, t); }
+    if (k == DK_MOVING) { const DMoving &m = S.moving[idx]; V3 c = moving_center(m, time);
+        return sphere_t(c.x, c.y, c.z, m.r, o, d, a, tmin, tmax, t); }
     return false;
 }
 // impl Hittable for Vec<Arc<..>>, hittable.rs:381-394: first wins ties (strict <)
 template <class Mem>
-VK_HD bool list_t(const DScene &S, const Mem &M, uint32_t list_ref, V3 o, V3 d, float a, float time, float tmin, float tmax, float &t, uint32_t &item) {
+VK_HD bool list_t(const DScene &S, const Mem &M, uint32_t list_ref, V3 o, V3 d, float a, float time, float tmin, float tmax, float &t,
+    uint32_t &item) {
     DList l = S.lists[VKD_INDEX(list_ref)];
     float closest = tmax;
     bool found = false;
@@ -250,7 +253,8 @@ VK_HD bool list_t(const DScene &S, const Mem &M, uint32_t list_ref, V3 o, V3 d, 
 // compile-time axes.  Same tests in the same order as list_t over the six vk_rects: Rect::hit's
 // inclusive bounds, then the list's strict `rec.t < closest_dist`.
 template <int A0, int A1, int A2>
-VK_HD void box_face(float k, float c0, float c1, float d0, float d1, V3 o, V3 d, float tmin, float &closest, uint32_t f, uint32_t &face, bool &found) {
+VK_HD void box_face(float k, float c0, float c1, float d0, float d1, V3 o, V3 d, float tmin, float &closest, uint32_t f, uint32_t &face,
+    bool &found) {
     float t = (k - comp(o, A2)) / comp(d, A2);
     float a = comp(o, A0) + t * comp(d, A0);
     float b = comp(o, A1) + t * comp(d, A1);
@@ -286,7 +290,8 @@ VK_HD DRect box_face_rect(const DBox &B, uint32_t f) {
 
 // boundary.hit() for ConstantMedium (boundary is a Sphere, MovingSphere, Rect or a Boxy list)
 template <class Mem>
-VK_HD bool boundary_t(const DScene &S, const Mem &M, uint32_t ref, V3 o, V3 d, float a, float time, float tmin, float tmax, float &t, uint32_t &item) {
+VK_HD bool boundary_t(const DScene &S, const Mem &M, uint32_t ref, V3 o, V3 d, float a, float time, float tmin, float tmax, float &t,
+    uint32_t &item) {
     if (VKD_KIND(ref) == DK_LIST) {
         bool h = list_t(S, M, ref, o, d, a, time, tmin, tmax, t, item);
         if (h) item ^= (ref & DREF_FLIP);
@@ -373,7 +378,8 @@ VK_HD void medium_test(Lane &L, const DScene &S, const Mem &M, uint32_t ref) {
         // re-tests the near root against its new tmin and then takes the far one.
         float cx, cy, cz, r;
         if (bk == DK_SPHERE) { DSphere s = M.sphere(VKD_INDEX(m.boundary)); cx = s.cx; cy = s.cy; cz = s.cz; r = s.r; }
-        else { const DMoving &mv = S.moving[VKD_INDEX(m.boundary)]; V3 c = moving_center(mv, L.time); cx = c.x; cy = c.y; cz = c.z; r = mv.r; }
+        else { const DMoving &mv = S.moving[VKD_INDEX(m.boundary)]; V3 c = moving_center(mv, L.time); cx = c.x; cy = c.y; cz = c.z;
+            r = mv.r; }
         V3 oc = L.o - v3(cx, cy, cz);
         float half_b = dot(oc, L.d);
         float c = length2(oc) - r * r;
@@ -568,7 +574,8 @@ template <uint32_t F, class Mem, int N>
 VK_HD void box_steps(Lane &L, const DScene &S, const Mem &M, bool go) {
     if (go) {
         bool queued = box_step_core<F, Mem>(L, M);      // (the mask is at hand: cheaper than comparing pend with 0 again)
-        if (N > 1) box_steps<F, Mem, (N > 1 ? N - 1 : 1)>(L, S, M, (!queued) & (L.i < range_end<F, Mem>(L, S)));   // (&: one mask, one branch)
+        // (&: one mask, one branch)
+        if (N > 1) box_steps<F, Mem, (N > 1 ? N - 1 : 1)>(L, S, M, (!queued) & (L.i < range_end<F, Mem>(L, S)));
     }
 }
 
@@ -707,7 +714,8 @@ VK_HD void build_record(const Lane &L, const DScene &S, const Mem &M, Rec &R) {
     } else {
         bool want_uv = false;
         if (F & VKF_TEXTURES) {
-            uint32_t mi = (k == DK_SPHERE) ? M.smat(VKD_INDEX(ref)) : (k == DK_RECT ? S.rects[VKD_INDEX(ref)].mat : S.moving[VKD_INDEX(ref)].mat);
+            uint32_t mi = (k == DK_SPHERE) ? M.smat(VKD_INDEX(ref))
+                                           : (k == DK_RECT ? S.rects[VKD_INDEX(ref)].mat : S.moving[VKD_INDEX(ref)].mat);
             want_uv = mat_wants_uv(S.materials[mi]);
         }
         simple_record(S, M, ref, o, d, L.time, L.T, want_uv, R);
@@ -743,7 +751,8 @@ VK_HD float perlin_noise(const DPerlin &P, V3 p) {  // material.rs:392-413 + per
     for (uint32_t di = 0; di < 2; di++)
         for (uint32_t dj = 0; dj < 2; dj++)
             for (uint32_t dk = 0; dk < 2; dk++) {
-                uint32_t h = (uint32_t)P.perm_x[(i + di) & 255u] ^ (uint32_t)P.perm_y[(j + dj) & 255u] ^ (uint32_t)P.perm_z[(k + dk) & 255u];
+                uint32_t h = (uint32_t)P.perm_x[(i + di) & 255u] ^ (uint32_t)P.perm_y[(j + dj) & 255u] ^
+                             (uint32_t)P.perm_z[(k + dk) & 255u];
                 V3 c = ld3(P.ranvec[h]);
                 float fi = (float)di, fj = (float)dj, fk = (float)dk;
                 V3 wv = v3(u - fi, v - fj, w - fk);
@@ -799,7 +808,8 @@ VK_COLD V3 texture_value(const DTexture *textures, const DImage *images, const u
         }
         // VK_TEX_NOISE, material.rs:430-434: Vec3::new_const(1.0) * 0.5 * (1.0 + sin(..))
         const DPerlin &P = perlins[t.a];
-        const bool pre = tex == pre_tex && px == ppx && py == ppy && pz == ppz;     // the value computed ahead is for this texture at this point
+        // the value computed ahead is for this texture at this point
+        const bool pre = tex == pre_tex && px == ppx && py == ppy && pz == ppz;
         float turb = pre_val;
         if (!pre) turb = perlin_turb(P, p, 7);
         float s = 1.0f + vk::sinf_(t.scale * p.z + 10.0f * turb);
@@ -810,7 +820,8 @@ VK_COLD V3 texture_value(const DTexture *textures, const DImage *images, const u
 template <uint32_t F>
 VK_HD V3 material_color(const DScene &S, const DMaterial &m, const Rec &R, const PreTurb &pt) {
     if (!(F & VKF_TEXTURES) || m.tex_kind == VK_TEX_SOLID) return v3(m.r, m.g, m.b);
-    return texture_value(S.textures, S.images, S.image_bytes, S.perlins, m.tex, R.u, R.v, R.p.x, R.p.y, R.p.z, pt.tex, pt.val, pt.px, pt.py, pt.pz);
+    return texture_value(S.textures, S.images, S.image_bytes, S.perlins, m.tex, R.u, R.v, R.p.x, R.p.y, R.p.z, pt.tex, pt.val, pt.px,
+        pt.py, pt.pz);
 }
 
 // ------------------------------------------------------------------ samplers (util.rs:31-63, material.rs:51-58)
@@ -992,7 +1003,8 @@ VK_HD V3 background_of(const RenderConsts &C, V3 ud) {       // ud = unit(ray di
 // the ray (no, nd, ntime) (the caller installs it with begin_segment), false when the path ended (L.acc is
 // its radiance).
 template <uint32_t F, class Mem>
-VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C, V3 &no, V3 &ndir, float &ntime, const PreTurb &pt = no_pre_turb()) {
+VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C, V3 &no, V3 &ndir, float &ntime,
+    const PreTurb &pt = no_pre_turb()) {
     const bool miss = L.best_prim == 0;
     Rec R;
     const DMaterial *m = S.materials;

@@ -179,7 +179,8 @@ uint32_t SpecDiffuse::flatten(FlatBuilder &b) const {
 
 // ------------------------------------------------------------------ hittables
 vk_ref Sphere::flatten(FlatBuilder &b) const {
-    vk_sphere s; s.center[0] = center.x; s.center[1] = center.y; s.center[2] = center.z; s.radius = radius; s.material = b.material(material);
+    vk_sphere s; s.center[0] = center.x; s.center[1] = center.y; s.center[2] = center.z; s.radius = radius;
+    s.material = b.material(material);
     b.spheres.push_back(s);
     return VK_MAKE_REF(VK_KIND_SPHERE, b.spheres.size() - 1);
 }

@@ -31,6 +31,13 @@ vkh_scene *vkh_scene_build(const char *name, uint64_t seed) {
         // "<scene>+sah": every BVHNode::new of the scene runs the SAH builder instead (same objects, same geometry)
         set_bvh_builder(BvhBuilder::REFERENCE);
         if (n.size() > 4 && n.compare(n.size() - 4, 4, "+sah") == 0) { n.resize(n.size() - 4); set_bvh_builder(BvhBuilder::SAH); }
+        // "<scene>+treeseed:<n>": the same objects, but main()'s BVHNode::new (main.rs:168) draws its split axes from another stream:
+        // the reference's tree is random (accel.rs:99-100, unseeded), so two runs of it walk different trees over the same world
+        long tree_seed = -1;
+        {
+            size_t at = n.rfind("+treeseed:");
+            if (at != std::string::npos) { tree_seed = atol(n.c_str() + at + 10); n.resize(at); }
+        }
         auto s = new vkh_scene;
         if (n == "balls_demo") s->cfg = balls_demo();
         else if (n == "random_spheres_demo") s->cfg = random_spheres_demo();
@@ -46,6 +53,7 @@ vkh_scene *vkh_scene_build(const char *name, uint64_t seed) {
             s->cfg = random_spheres_iow(g);
         } else { delete s; g_herr = "Not a valid scene: " + n; return nullptr; }  // main.rs:166
         // main.rs:168-169
+        if (tree_seed >= 0) seed_thread_rng((uint64_t)tree_seed * 0x9E3779B97F4A7C15ull + 0x5EEDull);
         auto world_bvh = BVHNode::build(s->cfg.world);
         s->fb.world = s->fb.hittable(world_bvh);
         for (auto &l : s->cfg.lights) s->fb.lights.push_back(s->fb.hittable(l));
@@ -68,7 +76,8 @@ void vkh_scene_defaults(vkh_scene *s, float *aspect_ratio, uint32_t *integrator,
     if (aspect_ratio) *aspect_ratio = s->cfg.aspect_ratio;
     if (integrator) *integrator = s->cfg.integrator;
     if (background) *background = s->cfg.background;
-    if (background_color) { background_color[0] = s->cfg.background_color.x; background_color[1] = s->cfg.background_color.y; background_color[2] = s->cfg.background_color.z; }
+    if (background_color) { background_color[0] = s->cfg.background_color.x; background_color[1] = s->cfg.background_color.y;
+        background_color[2] = s->cfg.background_color.z; }
 }
 void vkh_camera_new(const float lookfrom[3], const float lookat[3], const float vup[3], float vfov, float aspect_ratio,
                     float aperture, float focus_dist, float time0, float time1, vk_camera *out) {

@@ -23,8 +23,8 @@ static T sym(void *h, const char *name) {
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <balls_demo|random_spheres_demo|random_spheres_iow|perlin_demo|bowser_demo|cornell_box|final_scene|final_scene_nextweek|stress_spheres:N> "
-                        "[width] [spp] [max_depth] [frames] [seed]\n", argv[0]);
+        fprintf(stderr, "usage: %s <balls_demo|random_spheres_demo|random_spheres_iow|perlin_demo|bowser_demo|cornell_box|final_scene|"
+                        "final_scene_nextweek|stress_spheres:N> [width] [spp] [max_depth] [frames] [seed]\n", argv[0]);
         return 2;
     }
     const char *name = argv[1];
@@ -56,7 +56,8 @@ int main(int argc, char **argv) {
     std::vector<float> pixels((size_t)width * height * 3, 0.0f);     // main.rs:173
     vk_render_params rp{};
     rp.width = width; rp.height = height; rp.samples_per_pixel = spp; rp.max_depth = depth; rp.seed = seed + 1;
-    rp.integrator = integ; rp.background = bg; rp.background_color[0] = bgc[0]; rp.background_color[1] = bgc[1]; rp.background_color[2] = bgc[2];
+    rp.integrator = integ; rp.background = bg; rp.background_color[0] = bgc[0]; rp.background_color[1] = bgc[1];
+    rp.background_color[2] = bgc[2];
     rp.tile_rank = 0; rp.tile_world = 1;
     vk_camera cam;
     int file_idx = 0;

@@ -21,7 +21,8 @@ SceneConfig balls_demo() {
     world.push_back(std::make_shared<FlipFace>(light_shape));
     cfg.lights.push_back(light_shape);
     float aspect_ratio = 16.0f / 9.0f;
-    cfg.cam_iter = FixedCamera(camera_new(Vec3(0.0f, 2.0f, 10.0f), Vec3(0.0f, 1.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), 40.0f, aspect_ratio, 0.0f, 10.0f, 0.0f, 1.0f));
+    cfg.cam_iter = FixedCamera(camera_new(Vec3(0.0f, 2.0f, 10.0f), Vec3(0.0f, 1.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), 40.0f, aspect_ratio,
+        0.0f, 10.0f, 0.0f, 1.0f));
     cfg.aspect_ratio = aspect_ratio;
     return cfg;
 }
@@ -104,12 +105,14 @@ SceneConfig random_spheres_iow(int grid_half) {
     world.push_back(std::make_shared<Sphere>(Vec3(4.0f, 1.0f, 0.0f), 1.0f, std::make_shared<Metal>(solid(Vec3(0.7f, 0.6f, 0.5f)), 0.0f)));
     float aspect_ratio = 16.0f / 9.0f;
     if (!big) {
-        cfg.cam_iter = FixedCamera(camera_new(Vec3(13.0f, 2.0f, 3.0f), Vec3(0.0f, 0.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), 20.0f, aspect_ratio, 0.1f, 10.0f, 0.0f, 1.0f));
+        cfg.cam_iter = FixedCamera(camera_new(Vec3(13.0f, 2.0f, 3.0f), Vec3(0.0f, 0.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), 20.0f, aspect_ratio,
+            0.1f, 10.0f, 0.0f, 1.0f));
     } else {
         // stress scene: square image, camera pulled back and raised so the field fills the frame
         aspect_ratio = 1.0f;
         float k = (float)grid_half / 11.0f;
-        cfg.cam_iter = FixedCamera(camera_new(Vec3(13.0f * k * 0.35f, 2.0f * k * 1.2f, 3.0f * k * 0.35f), Vec3(0.0f, 0.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f),
+        cfg.cam_iter = FixedCamera(camera_new(Vec3(13.0f * k * 0.35f, 2.0f * k * 1.2f, 3.0f * k * 0.35f), Vec3(0.0f, 0.0f, 0.0f),
+            Vec3(0.0f, 1.0f, 0.0f),
                                               40.0f, aspect_ratio, 0.0f, 10.0f, 0.0f, 1.0f));
     }
     cfg.aspect_ratio = aspect_ratio;
@@ -129,7 +132,8 @@ SceneConfig perlin_demo() {
     world.push_back(std::make_shared<FlipFace>(light_shape));
     cfg.lights.push_back(light_shape);
     float aspect_ratio = 16.0f / 9.0f;
-    cfg.cam_iter = FixedCamera(camera_new(Vec3(0.0f, 2.0f, 10.0f), Vec3(0.0f, 1.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), 40.0f, aspect_ratio, 0.0f, 10.0f, 0.0f, 1.0f));
+    cfg.cam_iter = FixedCamera(camera_new(Vec3(0.0f, 2.0f, 10.0f), Vec3(0.0f, 1.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), 40.0f, aspect_ratio,
+        0.0f, 10.0f, 0.0f, 1.0f));
     cfg.aspect_ratio = aspect_ratio;
     return cfg;
 }
@@ -193,7 +197,8 @@ SceneConfig bowser_demo() {
     world.push_back(std::make_shared<Translate>(RotateX(RotateY(RotateZ(bowser_new(0.0f, 0.0f, 0.0f), 0.0f), 0.0f), 0.0f),
                                                 Vec3(0.0f, 1.625f, -4.5f)));
     auto light_shape = Rect::XYRect(-2.0f, 2.0f, 1.0f, 4.0f, 3.0f,
-                                    std::make_shared<DiffuseLight>(ImageTexture::open("assets/twitter.png")));   // image-textured emitter, scene.rs:585-590
+                                    // image-textured emitter, scene.rs:585-590
+                                    std::make_shared<DiffuseLight>(ImageTexture::open("assets/twitter.png")));
     world.push_back(std::make_shared<FlipFace>(light_shape));
     cfg.lights.push_back(light_shape);
     float aspect_ratio = 16.0f / 9.0f;
@@ -223,7 +228,8 @@ SceneConfig cornell_box() {
     world.push_back(std::make_shared<FlipFace>(light_shape));
     cfg.lights.push_back(light_shape);
     float aspect_ratio = 1.0f;
-    cfg.cam_iter = FixedCamera(camera_new(Vec3(278.0f, 278.0f, -800.0f), Vec3(278.0f, 278.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), 40.0f, aspect_ratio, 0.0f, 10.0f, 0.0f, 1.0f));
+    cfg.cam_iter = FixedCamera(camera_new(Vec3(278.0f, 278.0f, -800.0f), Vec3(278.0f, 278.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), 40.0f,
+        aspect_ratio, 0.0f, 10.0f, 0.0f, 1.0f));
     cfg.aspect_ratio = aspect_ratio;
     return cfg;
 }
@@ -256,7 +262,8 @@ SceneConfig final_scene() {
     Vec3 center2 = center1 + Vec3(30.0f, 0.0f, 0.0f);
     objects.push_back(std::make_shared<MovingSphere>(center1, center2, 0.0f, 1.0f, 50.0f, lambert(Vec3(0.7f, 0.3f, 0.1f))));
     objects.push_back(std::make_shared<Sphere>(Vec3(260.0f, 150.0f, 45.0f), 50.0f, std::make_shared<Dielectric>(1.5f)));
-    objects.push_back(std::make_shared<Sphere>(Vec3(0.0f, 150.0f, 145.0f), 50.0f, std::make_shared<Metal>(solid(Vec3(0.8f, 0.8f, 0.9f)), 10.0f)));
+    objects.push_back(std::make_shared<Sphere>(Vec3(0.0f, 150.0f, 145.0f), 50.0f,
+        std::make_shared<Metal>(solid(Vec3(0.8f, 0.8f, 0.9f)), 10.0f)));
     auto boundary1 = std::make_shared<Sphere>(Vec3(360.0f, 150.0f, 145.0f), 70.0f, std::make_shared<Dielectric>(1.5f));
     objects.push_back(boundary1);
     objects.push_back(std::make_shared<ConstantMedium>(boundary1, 0.2f, solid(Vec3(0.2f, 0.4f, 0.9f))));
@@ -271,7 +278,8 @@ SceneConfig final_scene() {
     for (int i = 0; i < 1000; i++) boxes2.push_back(std::make_shared<Sphere>(Vec3::random_range(0.0f, 165.0f), 10.0f, white));
     objects.push_back(std::make_shared<Translate>(RotateY(BVHNode::build(boxes2), 15.0f), Vec3(-100.0f, 270.0f, 395.0f)));
     float aspect_ratio = 1.0f;
-    cfg.cam_iter = FixedCamera(camera_new(Vec3(478.0f, 278.0f, -600.0f), Vec3(278.0f, 278.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), 40.0f, aspect_ratio, 0.0f, 10.0f, 0.0f, 1.0f));
+    cfg.cam_iter = FixedCamera(camera_new(Vec3(478.0f, 278.0f, -600.0f), Vec3(278.0f, 278.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), 40.0f,
+        aspect_ratio, 0.0f, 10.0f, 0.0f, 1.0f));
     cfg.aspect_ratio = aspect_ratio;
     return cfg;
 }

@@ -227,9 +227,12 @@ class Rect : public Hittable {  // hittable.rs:199-227,258-269
     float c0, c1, d0, d1, k; int axis0, axis1, axis2; MaterialP mat;
     Rect(float c0_, float c1_, float d0_, float d1_, float k_, int a0, int a1, int a2, MaterialP m)
         : c0(c0_), c1(c1_), d0(d0_), d1(d1_), k(k_), axis0(a0), axis1(a1), axis2(a2), mat(m) {}
-    static std::shared_ptr<Rect> XYRect(float x0, float x1, float y0, float y1, float k, MaterialP m) { return std::make_shared<Rect>(x0, x1, y0, y1, k, 0, 1, 2, m); }
-    static std::shared_ptr<Rect> XZRect(float x0, float x1, float z0, float z1, float k, MaterialP m) { return std::make_shared<Rect>(x0, x1, z0, z1, k, 0, 2, 1, m); }
-    static std::shared_ptr<Rect> YZRect(float y0, float y1, float z0, float z1, float k, MaterialP m) { return std::make_shared<Rect>(y0, y1, z0, z1, k, 1, 2, 0, m); }
+    static std::shared_ptr<Rect> XYRect(float x0, float x1, float y0, float y1, float k,
+        MaterialP m) { return std::make_shared<Rect>(x0, x1, y0, y1, k, 0, 1, 2, m); }
+    static std::shared_ptr<Rect> XZRect(float x0, float x1, float z0, float z1, float k,
+        MaterialP m) { return std::make_shared<Rect>(x0, x1, z0, z1, k, 0, 2, 1, m); }
+    static std::shared_ptr<Rect> YZRect(float y0, float y1, float z0, float z1, float k,
+        MaterialP m) { return std::make_shared<Rect>(y0, y1, z0, z1, k, 1, 2, 0, m); }
     std::optional<AxisBB> bounding_box(float, float) const override {
         Vec3 v1, v2;
         v1[axis0] = c0; v1[axis1] = d0; v1[axis2] = k - 0.0001f;
