@@ -366,7 +366,7 @@ def main():
             # process, so they come from the committed rocprofv3 passes of this same command (profiles/, tests/prof_r02.sh):
             # WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950: FETCH_SIZE counts half the bytes of wide reads -> upper bound)
             traffic, issue, prof_path = None, None, None
-            t_read = t_write = scratch_share = None
+            t_read = t_write = scratch_share = scratch_detail = None
             if n_gpus == 1 and not spp_override and bvh == "reference" and not fast_accel:
                 prof, prof_path = pmc_summary(name)
                 if prof:
@@ -395,11 +395,16 @@ def main():
                                     f"{live['written_bytes']:.0f} B written); committed profile ({prof_path}): {traffic}")
                     t_read, t_write = live["read_bytes_upper_bound"], live["written_bytes"]
                     traffic = t_read + t_write
-                    # scratch (register spill) stores are the kernel's only vector-memory writes apart from the flushes of the LDS tile sums
-                    # and the few straggler deposits (3 wave-level atomics per work unit): a wave-wide dword store is 256 B
+                    # Share of the HBM writes that can be register spills — an UPPER bound from two sides: (a) the bytes the spill stores
+                    # issue (scratch stores are the kernel's only vector-memory writes apart from ~4 wave-level atomics per work unit; a
+                    # wave-wide dword store is 256 B; they only reach HBM when the scratch working set outgrows the L2), (b) what is
+                    # left of WRITE_SIZE after the flushes of the tile sums (192 atomics per unit, a 32-B sector each at the memory side)
                     n_units_est = ((width + 7) // 8) * ((height + 7) // 8) * max(1, -(-spp // 64)) / max(1, world)
                     spill_instr = max(0.0, live["SQ_INSTS_VMEM_WR"] - 4.0 * n_units_est)
-                    scratch_share = round(min(1.0, spill_instr * 256.0 / max(1.0, t_write)), 4)
+                    spill_bytes = spill_instr * 256.0
+                    scratch_share = round(max(0.0, min(1.0, spill_bytes / max(1.0, t_write), 1.0 - n_units_est * 192.0 * 32.0 / max(1.0, t_write))), 4)
+                    scratch_detail = {"spill_store_wave_instr": round(spill_instr), "spill_bytes_issued": round(spill_bytes),
+                                      "tile_sum_flush_bytes_estimate": round(n_units_est * 192.0 * 32.0)}
                     if k_ms:
                         vi = live["SQ_INSTS_VALU"] / local_samples
                         rate = live["SQ_INSTS_VALU"] / (k_ms * 1e-3)
@@ -416,7 +421,7 @@ def main():
                 achieved = bps * local_samples / (k_ms * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                        "traffic_read": t_read, "traffic_write": t_write, "scratch_write_share": scratch_share,
+                        "traffic_read": t_read, "traffic_write": t_write, "scratch_write_share": scratch_share, "scratch_detail": scratch_detail,
                         "traffic_note": traffic_note,
                         "algorithmic_bytes_per_sample": round(bps, 1), "kernel_ms": round(k_ms, 3),
                         "algorithmic_bytes_per_sample_walked": round(bps_walked, 1),

@@ -179,13 +179,14 @@ typedef struct vk_scene_desc {
 
 /* vk_scene_desc.flags.
  * VK_SCENE_FAST_ACCEL: the library may rebuild the acceleration structure over subtrees whose objects are all
- * Sphere / Rect / Boxy / lists of those (no ConstantMedium, no transform): BVHNode::hit's result (accel.rs:58-83) does
- * not depend on the tree over such objects, and exact ties in t are resolved as the reference resolves them.  What it
- * cannot reproduce is floating-point noise: a Sphere::hit quadratic that reports a hit a hair OUTSIDE the sphere's own
- * bounding box (small far spheres in f32) is found or not depending on which enclosing boxes a tree happens to have —
- * in the reference as much as here.  Measured: the InOneWeekend scene's full 1920x1080x1024-spp frame (2.1 G samples) is
- * bit-identical with and without the flag (+33 % throughput); on the 1 M-sphere stress scene (0.2-radius spheres 250 units
- * from the ray origins) 0.17 % of the samples differ.  Off by default.                                                   */
+ * Sphere / Rect / Boxy / lists of those (no ConstantMedium, no transform, no negative-radius sphere): BVHNode::hit's result
+ * (accel.rs:58-83) does not depend on the tree over such objects, and exact ties in t are resolved as the reference resolves
+ * them.  What it cannot reproduce is floating-point noise: a Sphere::hit quadratic that reports a hit a hair OUTSIDE the
+ * sphere's own bounding box (small far spheres in f32) is found or not depending on which enclosing boxes a tree happens to
+ * have — in the reference as much as here, whose own tree is random (accel.rs:99-100).  Measured: the InOneWeekend scene's full
+ * 1920x1080x1024-spp frame (2.1 G samples) is bit-identical with and without the flag (+28 % throughput); on the 1 M-sphere
+ * stress scene 0.19 % of the samples differ — exactly as many as between two reference-style trees over the same world
+ * (profiles/r03/tree_variation.log).  Off by default: only the tree handed over matches a seeded reference run sample for sample. */
 enum { VK_SCENE_FAST_ACCEL = 1 };
 
 /* ---- camera: the ten fields of main.rs:57-68, computed by Camera::new on the host --- */
