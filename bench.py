@@ -202,7 +202,13 @@ def self_launch(n):
     print("bench.py: --gpus %d without a launcher: starting %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
     env = dict(os.environ, VK_BENCH_SELF_LAUNCHED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    return subprocess.run(cmd, env=env).returncode
+    # relay: the ranks' JSON line goes to stdout, everything else they print there (gloo's connection banners) to stderr, so that
+    # stdout holds exactly the one line the contract asks for
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def main():
