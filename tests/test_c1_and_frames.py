@@ -64,6 +64,14 @@ def test_cli_harness_writes_reference_style_ppm(device, oracle, built, tmp_path)
     want = np.zeros((48, 48, 3), np.uint8)
     ffi.load_host_lib().vkh_to_color(ref.ctypes.data, 48, 48, want.ctypes.data)
     assert np.abs(got - want.astype(np.int64)).max() <= 1     # 8-bit quantisation of values equal to 1e-6
+    # a scene with an ImageTexture: the CLI finds the decoded copy of assets/earthmap.png through VECCHIO_ASSETS, and fails the way
+    # the reference does (File::open(..).unwrap(), material.rs:270) when the directory does not hold it
+    assets = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "assets")
+    subprocess.check_call([exe, "final_scene", "40", "2", "8", "1", "1"], cwd=tmp_path, env=dict(os.environ, VECCHIO_ASSETS=assets))
+    assert open(tmp_path / "output_0000.ppm").read().split()[1:4] == ["40", "40", "255"]
+    r = subprocess.run([exe, "final_scene", "40", "2", "8", "1", "1"], cwd=tmp_path, env=dict(os.environ, VECCHIO_ASSETS=str(tmp_path)),
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "earthmap" in r.stderr
 
 
 def test_to_color_restatements_agree_on_the_cpu(built):
