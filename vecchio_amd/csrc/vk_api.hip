@@ -349,6 +349,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     A.n_chunks = choose_chunks(s, p);
     A.counter = s->counter;
     A.clamped = reinterpret_cast<unsigned long long *>(s->counter) + 1;     // bytes 8..15 of the counter block
+    A.accum_clamp = accum_clamp_for(p->samples_per_pixel);
     A.shade_defer = SHADE_DEFER;          // (C5: 1 / 2 / 4 / 8 -> 573 / 588 / 593 / 603-at-pw-2)
     if (s->env.shade_defer >= 1 && s->env.shade_defer <= 64) A.shade_defer = (uint32_t)s->env.shade_defer;   // diagnostics
     // scenes beyond an XCD's L2 (C5: a leaf every 6 box steps, every gather a possible L2 miss): pending sphere tests are served

@@ -41,6 +41,7 @@ struct KArgs {
     float4 *debug;           // optional per-sample (rgb, draws) dump
     uint32_t *counter;       // work-unit counter
     unsigned long long *clamped;   // number of samples whose radiance was clamped on its way into the fixed-point sums (see to_fixed)
+    float accum_clamp;       // min(1e10, 1.3e11 / spp), worked out by the host (accum_clamp_for)
     uint32_t *tile_cost;     // [tiles of the image] time spent on each tile (1.6 us ticks): written by the probe (COST) build only
     const uint32_t *tile_order;   // [n_local_tiles] local tile slots, dearest first (from the probe launch), or null = raster order
     uint32_t tiles_x, tiles_y;
@@ -154,7 +155,12 @@ template <uint32_t F> constexpr uint32_t wave_block_floats() { return 64u * (uin
 constexpr float ACCUM_SCALE = 67108864.0f;          // 2^26
 constexpr float ACCUM_CLAMP = 1.0e10f;
 constexpr float ACCUM_RANGE = 1.3e11f;
-__device__ __forceinline__ float accum_clamp_for(uint32_t spp) { return fminf(ACCUM_CLAMP, ACCUM_RANGE / (float)spp); }
+inline float accum_clamp_for(uint32_t spp) { float c = ACCUM_RANGE / (float)spp; return c < ACCUM_CLAMP ? c : ACCUM_CLAMP; }     // (host)
+// Components below 32 in magnitude — every sample of a scene without bright emitters, and nearly every one otherwise — fit 31 bits
+// at 2^-26: ONE v_cvt_i32_f32 (truncating, like the 64-bit cast) and a sign extension, against ~17 instructions for the float ->
+// 64-bit integer conversion the compiler has to expand.
+constexpr float ACCUM_SMALL = 31.999f;
+__device__ __forceinline__ long long to_fixed_small(float v) { return (long long)(int)(v * ACCUM_SCALE); }
 __device__ __forceinline__ long long to_fixed(float v, float clampv) {
     v = fminf(fmaxf(v, -clampv), clampv);
     return (long long)(v * ACCUM_SCALE);             // scaling by a power of two is exact; the cast truncates toward zero
@@ -320,10 +326,17 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &
                 __uint_as_float(L.rng.ctr));
             long long *acc = KARG(P, accum);
             if (acc && isfinite(L.acc.x) && isfinite(L.acc.y) && isfinite(L.acc.z)) {   // main.rs:192-194; c += color (main.rs:193)
-                const float clampv = accum_clamp_for(C.spp);
-                if (fmaxf(fmaxf(fabsf(L.acc.x), fabsf(L.acc.y)), fabsf(L.acc.z)) > clampv) atomicAdd(KARG(P, clamped), 1ull);     // (rare)
-                unsigned long long fx = (unsigned long long)to_fixed(L.acc.x, clampv), fy = (unsigned long long)to_fixed(L.acc.y, clampv),
+                const float clampv = KARG(P, accum_clamp);
+                const float big = fmaxf(fmaxf(fabsf(L.acc.x), fabsf(L.acc.y)), fabsf(L.acc.z));
+                unsigned long long fx, fy, fz;
+                if (big <= ACCUM_SMALL) {      // (nearly always, for the whole wave)
+                    fx = (unsigned long long)to_fixed_small(L.acc.x); fy = (unsigned long long)to_fixed_small(L.acc.y);
+                    fz = (unsigned long long)to_fixed_small(L.acc.z);
+                } else {
+                    if (big > clampv) atomicAdd(KARG(P, clamped), 1ull);     // (rare)
+                    fx = (unsigned long long)to_fixed(L.acc.x, clampv); fy = (unsigned long long)to_fixed(L.acc.y, clampv);
                     fz = (unsigned long long)to_fixed(L.acc.z, clampv);
+                }
                 // a sample of the tile the wave is handing out (nearly all of them) lands in the wave's LDS sums, which
                 // reach the frame's accumulators once per unit; a straggler of an earlier unit goes there directly
                 if ((xy & 0xFFF8FFF8u) == __builtin_amdgcn_readfirstlane(wstate[WS_TXY])) {
