@@ -140,7 +140,7 @@ def measure_counters_live(workload, timeout_s=75):
             for c in group:
                 if not vals[c]:
                     return None, f"no {c} row for the render kernel"
-                got[c] = sum(vals[c]) / len(vals[c])
+                got[c] = sum(vals[c])        # ONE step was run: the frame's production dispatches (two when the library launches 16 + 12 waves per CU)
         except Exception as e:      # a profiler that cannot run here must not take the benchmark down
             return None, f"{group[0]} pass failed: {type(e).__name__}"
         finally:

@@ -10,7 +10,7 @@ for w in ${1:-C2 C4 C3 C5}; do
   esac
   lw=$(echo $w | tr A-Z a-z)
   OUT=gpurun_out/prof_$lw WL="$WLA" STEPS=1 WARMUP=1 TMO=280 bash tests/prof_r03.sh pmc cache || echo "prof $w failed rc=$?"
-  python tests/summarize_pmc.py gpurun_out/prof_$lw gpurun_out/${lw}_pmc_summary.json $N > gpurun_out/${lw}_pmc.log 2>&1
+  python tests/summarize_pmc.py gpurun_out/prof_$lw gpurun_out/${lw}_pmc_summary.json $N 2 > gpurun_out/${lw}_pmc.log 2>&1
   cp gpurun_out/prof_$lw/trace/*/*kernel_stats.csv gpurun_out/${lw}_kernel_stats.csv 2>/dev/null
   tail -3 gpurun_out/${lw}_pmc.log
 done

@@ -7,6 +7,7 @@ import sys
 
 import os
 src, dst, samples = sys.argv[1], sys.argv[2], float(sys.argv[3])
+frames = int(sys.argv[4]) if len(sys.argv) > 4 else 0       # frames rendered per pass (steps + warm-up); 0 = average per DISPATCH
 cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "bench.py --steps 2 --warmup 1 --no-cpu"
 out = {"command": f"rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 {cmd} (separate passes; see tests/prof_r03.sh)",
        "samples_per_dispatch": samples, "counters_per_dispatch": {}}
@@ -18,7 +19,9 @@ for f in sorted(glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv")):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             out["dispatch"] = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
     for k, v in agg.items():
-        out["counters_per_dispatch"][k] = sum(v) / len(v)
+        # per frame: a frame may be more than one dispatch of the production kernel (the dual launch of sphere-only LDS scenes)
+        out["counters_per_dispatch"][k] = sum(v) / (frames if frames else len(v))
+        out["dispatches_per_frame"] = len(v) / frames if frames else 1
 c = out["counters_per_dispatch"]
 d = {}
 if "FETCH_SIZE" in c:

@@ -48,6 +48,10 @@ def test_sphere_only_variant_keeps_six_waves_per_simd(built):
         if minw == 8:      # global-memory build: 64 VGPRs, the shading phase is a function of its own (vk_kernels.h shade_refill_call)
             assert not lds and r["occupancy"] >= 8 and r["vgprs"] <= 64 and r["scratch_ops"] <= 40 and not r["dynamic_stack"], (key, r)
             continue
+        if minw == 7:      # LDS-resident scenes, dual launch (vk_api.hip launch_dual): 16 + 12 waves per CU need 72 VGPRs or fewer
+            assert lds and r["occupancy"] >= 7 and r["vgprs"] <= 72 and r["agprs"] == 0 and not r["dynamic_stack"], (key, r)
+            assert r["scratch"] <= (64 if f != 0 else 16) and r["scratch_ops"] <= (60 if f != 0 else 8), (key, r)
+            continue
         assert minw == 6 and r["occupancy"] >= 6, (key, r)
         assert r["vgprs"] <= 80 and r["agprs"] == 0, (key, r)
         # a few dwords spilled around the shading phase are tolerated (none may sit in the box / primitive loops:

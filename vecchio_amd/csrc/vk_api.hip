@@ -123,6 +123,11 @@ struct vk_scene {
     uint32_t wg_threads = 512; // workgroup size chosen by plan_residency()
     uint32_t sphere_waves = 6; // waves per SIMD of the sphere-only variant (8 was measured 3 % slower: it spills)
     uint32_t wgs_per_cu = 2;
+    // Seven waves per SIMD for sphere-only scenes staged in LDS: ONE 1024-thread and ONE 768-thread workgroup per CU, i.e. two
+    // concurrent launches of the same kernel pulling from the same unit counter (plan_residency); the second one runs on `stream2`.
+    bool dual_launch = false;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool last_timed = false;
     unsigned long long *phase_stats = nullptr;   // device, 16 counters (diagnostic kernel build)
     bool want_phase_stats = false;
@@ -202,6 +207,15 @@ void plan_residency(vk_scene *s, size_t hot) {
         if (w < 1) break;
         if (w * n_wg > best_waves) { best_waves = w * n_wg; best_wg = w; best_n = n_wg; }
     }
+    // Seven waves per SIMD (the sphere-only kernels need 72 VGPRs): 28 waves per CU cannot be two EQUAL workgroups — 14 waves land
+    // 4+4+3+3 on the four SIMDs and the second workgroup does not fit beside the first — but they can be 16 + 12: a 1024-thread
+    // workgroup (4 per SIMD) and a 768-thread one (3 per SIMD), from two concurrent launches.  Needs two LDS copies of the scene.
+    s->dual_launch = false;
+    if (spheres_only && !s->env.no_lds_scene && s->env.max_waves_per_cu == 0 && !getenv("VK_NO_DUAL_LAUNCH") && 2 * hot + 28 * pw <= LDS_PER_CU) {
+        s->lds_bytes = (uint32_t)hot; s->wg_threads = 768; s->wgs_per_cu = 2;      // (the single-launch shape: probe, STATS, tiny frames)
+        s->dual_launch = true;
+        return;
+    }
     if (best_waves >= cap && !s->env.no_lds_scene) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = best_wg * 64; s->wgs_per_cu = best_n;
     } else {
@@ -234,6 +248,23 @@ int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shme
     else rc = lds ? go(&render_kernel<F, true, MINW, false, false>) : go(&render_kernel<F, false, MINW_G, false, false>);
     if (rc != VK_OK) return rc;
     HIP_TRY(hipGetLastError());
+    return VK_OK;
+}
+
+// The dual launch of plan_residency: the same 7-waves-per-SIMD build of a sphere-only LDS variant, once with 1024-thread workgroups on
+// `st` and once with 768-thread workgroups on the scene's second stream, one workgroup of each per CU; both pull units from A.counter.
+template <uint32_t F>
+int launch_dual(vk_scene *s, const KArgs &A, size_t per_wave, hipStream_t st) {
+    auto kernel = &render_kernel<F, true, 7, false, false>;
+    const size_t shm_a = s->lds_bytes + 16 * per_wave, shm_b = s->lds_bytes + 12 * per_wave;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_a));
+    HIP_TRY(hipEventRecord(s->ev_fork, st));                    // everything enqueued so far (memsets of counter and sums)
+    HIP_TRY(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)s->num_cus), dim3(1024), shm_a, st, A);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)s->num_cus), dim3(768), shm_b, s->stream2, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev_join, s->stream2));
+    HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));              // the resolve kernel waits for both
     return VK_OK;
 }
 
@@ -467,7 +498,13 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         HIP_TRY(hipGetLastError());
         F = 0xFFFFFFFFu;   // launched
     }
-    if (F != 0xFFFFFFFFu) rc = launch_by_features(s, F, A, lds, dim3(grid), shmem, st, false);
+    if (F != 0xFFFFFFFFu) {
+        // enough units for 28 waves per CU to stay busy: the dual launch; else (tiny frames) the single 2 x 768-thread shape
+        const bool dual = s->dual_launch && lds && n_units >= (uint64_t)s->num_cus * 28u * 4u && s->stream2;
+        if (dual && F == 0u) rc = launch_dual<0u>(s, A, per_wave_lds_bytes(0u), st);
+        else if (dual && F == (uint32_t)VKF_INTEG_PDF) rc = launch_dual<VKF_INTEG_PDF>(s, A, per_wave_lds_bytes(0u), st);
+        else rc = launch_by_features(s, F, A, lds, dim3(grid), shmem, st, false);
+    }
     if (rc != VK_OK) return rc;
     {
         uint32_t blocks = (uint32_t)((n_pixels + 255) / 256);
@@ -573,9 +610,10 @@ void destroy_one(vk_scene *s) {
                     (void *)s->tile_order, (void *)s->order_hist, (void *)s->slab})
         if (p) (void)hipFree(p);
     if (s->landing) { (void)hipSetDevice(s->landing_device); (void)hipFree(s->landing); (void)hipSetDevice(s->device); }
-    for (hipEvent_t e : {s->ev0, s->ev1, s->ev_landed, s->ev_begin})
+    for (hipEvent_t e : {s->ev0, s->ev1, s->ev_landed, s->ev_begin, s->ev_fork, s->ev_join})
         if (e) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->stream2) (void)hipStreamDestroy(s->stream2);
     delete s;
 }
 
@@ -631,6 +669,11 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
     size_t hot = H.items.size() * sizeof(DItem) + H.spheres.size() * sizeof(DSphere) + H.boxes.size() * sizeof(DBox);
     s->hot_bytes = hot;
     plan_residency(s.get(), hot);
+    if (s->dual_launch) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+    }
     out = std::move(s);
     return VK_OK;
 }

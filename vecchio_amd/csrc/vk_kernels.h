@@ -459,6 +459,7 @@ __device__ __attribute__((noinline)) ShadeIo shade_refill_call(ShadeIo io, uint3
 // are order independent (to_fixed above).
 template <uint32_t F, bool LDS_SCENE, int MINW, bool STATS, bool COST = false>
 __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ? 768 : 1024))), MINW) void render_kernel(KArgs A_byval) {
+    // (MINW == 7: the sphere-only LDS variants' dual launch, 1024- and 768-thread workgroups of the same build: vk_api.hip launch_dual)
     (void)A_byval;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;

@@ -23,10 +23,13 @@
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #define VK_HD __host__ __device__ __forceinline__
-// The f64 transcendental kernels are called once per bounce at most.  Kept out of line on the
-// device so that their ~60 double constants are not hoisted into (and spilled across) the
-// megakernel's persistent loop; arguments and results travel in registers.
-#define VK_COLD __host__ __device__ inline __attribute__((noinline))
+// The f64 transcendental kernels (and the non-solid texture path, vk_trace.h) are called once per bounce at most.  Rounds 1-2 kept
+// them out of line so that their double constants were not hoisted into the megakernel's persistent loop.  With the phases re-reading
+// their constants through laundered pointers (vk_kernels.h) that no longer happens, and a called function costs more than it saves:
+// every value that is live across the call has to sit in a callee-saved register, which the out-of-line shading phase then has to
+// save and restore itself.  Inline since round 3: the everything-variants' shading function has 30 scratch stores instead of 55, the
+// sphere-only LDS kernel 72 VGPRs instead of 76 (C3 +1 %, C2 / C4 +0.4 %).
+#define VK_COLD __host__ __device__ __forceinline__
 #else
 #define VK_HD inline
 #define VK_COLD inline
