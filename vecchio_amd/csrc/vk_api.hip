@@ -501,6 +501,12 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     if (F != 0xFFFFFFFFu) {
         // enough units for 28 waves per CU to stay busy: the dual launch; else (tiny frames) the single 2 x 768-thread shape
         const bool dual = s->dual_launch && lds && n_units >= (uint64_t)s->num_cus * 28u * 4u && s->stream2;
+        if (dual) {
+            // seven waves per SIMD hide more of a parked lane's wait: shading deferred 5x, pending sphere tests served at 2x weight
+            // (C2 at 256 spp, (defer, weight): (4,1) 6 098, (5,1) 6 166, (5,2) 6 230, (6,2) 6 208, (8,2) 6 230, (5,3) 6 071 Msamples/s)
+            if (!(s->env.shade_defer >= 1 && s->env.shade_defer <= 64)) A.shade_defer = 5u;
+            if (!(s->env.prim_weight >= 1 && s->env.prim_weight <= 64)) A.prim_weight = 2u;
+        }
         if (dual && F == 0u) rc = launch_dual<0u>(s, A, per_wave_lds_bytes(0u), st);
         else if (dual && F == (uint32_t)VKF_INTEG_PDF) rc = launch_dual<VKF_INTEG_PDF>(s, A, per_wave_lds_bytes(0u), st);
         else rc = launch_by_features(s, F, A, lds, dim3(grid), shmem, st, false);
