@@ -342,7 +342,9 @@ uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
     uint64_t c = (uint64_t)p->samples_per_pixel * (tiles / (p->tile_world ? p->tile_world : 1u)) / 65536u;      // ~64K units per launch
     // One GPU: 64 (C2: 32 / 64 / 128 / 256 -> 5 218 / 5 235 / 5 221 / 4 960 Msamples/s).  One rank of N: the launch ends on the last
     // units of the rank's dearest tiles, so smaller ones (C2's 1/8 share: 64 -> 54.2 ms, 32 -> 53.1, 16 -> 52.9, 8 -> 53.5; ideal 50.0).
-    uint32_t cap = (p->tile_world > 1u) ? 32u : 64u;
+    // (seven waves per SIMD — the dual launch of sphere-only LDS scenes — like the smaller units too: 16 / 32 / 48 / 64 -> 6 805 / 6 836 /
+    // 6 815 / 6 776 Msamples/s on C2 at full size)
+    uint32_t cap = (p->tile_world > 1u || s->dual_launch) ? 32u : 64u;
     // (Round 1 and the first half of round 2 cut the units of scenes bigger than an XCD's L2 down to 8 spp "because tile costs are
     // skewed by orders of magnitude": the skew was NaN rays walking the whole million-item tree — see begin_segment in vk_trace.h.
     // Without them C5 prefers the common setting: 4 / 8 / 16 / 32 / 64 spp per unit -> 564 / 574 / 579 / 583 / 585 Msamples/s.)
