@@ -172,3 +172,35 @@ def test_unit_count_stays_below_32_bits(device, host_scenes):
     assert st.samples == 3 * 64 * (1 << 20)             # tiles 7, 100 007, 200 007 of 262 144
     assert np.isfinite(img).all()
     ds.close()
+
+
+def test_dual_launch_self_check_falls_back_when_the_launches_do_not_overlap(device, tmp_path):
+    """Sphere-only LDS scenes run as TWO concurrent launches (1024- and 768-thread workgroups: seven waves per SIMD).  If a runtime
+    serialises them the first launch does all the work at 16 waves per CU; each launch counts the units it pulls and after two
+    lopsided frames in a row the scene falls back to the single-launch shape.  Forced here with VK_DUAL_SAME_STREAM=1 (both
+    launches on one stream); every frame is bit-identical to the normal scene's either way."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["VK_ROOT"])
+from vecchio_amd import DeviceScene, HostScene
+hs = HostScene("random_spheres_iow", 1); cam = hs.next_camera(); p = hs.params(1920, 64, 50)
+ds = DeviceScene(hs.desc)
+imgs = [ds.render(cam, p)[0].copy() for _ in range(4)]
+assert all(np.array_equal(imgs[0], im) for im in imgs[1:])
+np.save(os.environ["VK_OUT"], imgs[0])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for label, extra in (("normal", {"VK_DUAL_DEBUG": "1"}), ("serial", {"VK_DUAL_SAME_STREAM": "1", "VK_DUAL_DEBUG": "1"})):
+        env = dict(os.environ, VK_ROOT=root, VK_OUT=str(tmp_path / (label + ".npy")), **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[label] = r.stderr
+    assert "single-launch shape" not in outs["normal"] and "dual launch:" in outs["normal"], outs["normal"][-800:]
+    assert "single-launch shape" in outs["serial"], outs["serial"][-800:]
+    assert outs["serial"].count("dual launch:") == 2          # two lopsided frames, then no dual launch any more
+    assert np.array_equal(np.load(tmp_path / "normal.npy"), np.load(tmp_path / "serial.npy"))

@@ -81,6 +81,8 @@ struct EnvSwitches {
     int probe_spp = 0;                 // VK_PROBE_SPP=n
     int probe_depth = 0;               // VK_PROBE_DEPTH=n: depth limit of the probe launch's paths (default 16)
     int prim_weight = 0;               // VK_PRIM_WEIGHT=n
+    bool dual_same_stream = false;     // VK_DUAL_SAME_STREAM=1 (tests): see launch_dual
+    bool dual_debug = false;           // VK_DUAL_DEBUG=1: print each checked frame's unit split
     int retree = -1;                   // VK_RETREE=0/1: force the SAH rebuild of draw-free subtrees off / on (default: vk_scene_desc.flags)
     static int int_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
     static EnvSwitches read() {
@@ -89,6 +91,8 @@ struct EnvSwitches {
         if (const char *e = getenv("VK_NO_LDS_SCENE")) v.no_lds_scene = e[0] == '1';
         if (const char *e = getenv("VK_TILE_ORDER")) { v.tile_order = e[0] != '0'; v.tile_order_forced = e[0] == '1'; }
         if (const char *e = getenv("VK_RETREE")) v.retree = e[0] != '0' ? 1 : 0;
+        if (const char *e = getenv("VK_DUAL_SAME_STREAM")) v.dual_same_stream = e[0] == '1';
+        if (const char *e = getenv("VK_DUAL_DEBUG")) v.dual_debug = e[0] == '1';
         v.max_waves_per_cu = int_env("VK_MAX_WAVES_PER_CU");
         v.chunk_cap = int_env("VK_CHUNK_CAP");
         v.shade_defer = int_env("VK_SHADE_DEFER");
@@ -128,6 +132,12 @@ struct vk_scene {
     bool dual_launch = false;
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // Self-check of the dual launch: the two launches must OVERLAP, or the first one does all the work at 16 waves per CU.  Each
+    // launch counts the units it pulls (two words of the counter block); the 768-thread launch should get ~12/28 of them.  A frame in
+    // which one launch got under a tenth counts as a strike; after two strikes in a row the scene uses the single-launch shape for
+    // good.  Checked where the caller synchronises anyway (vk_scene_last_kernel_ms, vk_render).
+    bool dual_last = false;        // the last render used the dual launch
+    int dual_strikes = 0;
     bool last_timed = false;
     unsigned long long *phase_stats = nullptr;   // device, 16 counters (diagnostic kernel build)
     bool want_phase_stats = false;
@@ -258,13 +268,16 @@ int launch_dual(vk_scene *s, const KArgs &A, size_t per_wave, hipStream_t st) {
     auto kernel = &render_kernel<F, true, 7, false, false>;
     const size_t shm_a = s->lds_bytes + 16 * per_wave, shm_b = s->lds_bytes + 12 * per_wave;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_a));
+    // (VK_DUAL_SAME_STREAM=1, tests: both launches on ONE stream, i.e. serialised — what the self-check must notice)
+    hipStream_t st2 = s->env.dual_same_stream ? st : s->stream2;
     HIP_TRY(hipEventRecord(s->ev_fork, st));                    // everything enqueued so far (memsets of counter and sums)
-    HIP_TRY(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+    HIP_TRY(hipStreamWaitEvent(st2, s->ev_fork, 0));
     hipLaunchKernelGGL(kernel, dim3((unsigned)s->num_cus), dim3(1024), shm_a, st, A);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)s->num_cus), dim3(768), shm_b, s->stream2, A);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)s->num_cus), dim3(768), shm_b, st2, A);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->ev_join, s->stream2));
+    HIP_TRY(hipEventRecord(s->ev_join, st2));
     HIP_TRY(hipStreamWaitEvent(st, s->ev_join, 0));              // the resolve kernel waits for both
+    s->dual_last = true;
     return VK_OK;
 }
 
@@ -382,6 +395,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     A.n_chunks = choose_chunks(s, p);
     A.counter = s->counter;
     A.clamped = reinterpret_cast<unsigned long long *>(s->counter) + 1;     // bytes 8..15 of the counter block
+    A.launch_units = s->counter + 4;                                         // bytes 16..23: units pulled by each launch of a dual launch
     A.accum_clamp = accum_clamp_for(p->samples_per_pixel);
     A.shade_defer = SHADE_DEFER;          // (C5: 1 / 2 / 4 / 8 -> 573 / 588 / 593 / 603-at-pw-2)
     if (s->env.shade_defer >= 1 && s->env.shade_defer <= 64) A.shade_defer = (uint32_t)s->env.shade_defer;   // diagnostics
@@ -406,7 +420,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     HIP_TRY(hipEventRecord(s->ev0, st));
     if (p->max_depth == 0) {
         // ray_color returns (0,0,0) before tracing anything when depth (1) > MAX_DEPTH (main.rs:126-128): a black partition
-        HIP_TRY(hipMemsetAsync(s->counter, 0, 16, st));
+        HIP_TRY(hipMemsetAsync(s->counter, 0, 32, st));
         int rc = tile_move<TM_ZERO_F32>(nullptr, d_out, p, g, st);
         if (rc != VK_OK) return rc;
         HIP_TRY(hipEventRecord(s->ev1, st));
@@ -439,6 +453,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     size_t shmem = (size_t)waves_per_wg * per_wave_lds_bytes(pick_variant(s));
     if (lds) { A.lds_items = s->dev.n_items; A.lds_spheres = s->dev.n_spheres; A.lds_boxes = s->dev.n_boxes; shmem += s->lds_bytes; }
     // persistent grid: enough workgroups to fill the chip, never more than there are units
+    s->dual_last = false;
     const uint64_t n_units = (uint64_t)A.n_local_tiles * A.n_chunks;
     // (choose_chunks keeps it below)
     if (n_units >= 0xFFFFFFFFull) return fail(VK_ERR_BAD_ARG, "tiles x sample chunks exceeds the 32-bit unit counter");
@@ -481,7 +496,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         HIP_TRY(hipGetLastError());
         A.tile_order = s->tile_order;
     }
-    HIP_TRY(hipMemsetAsync(s->counter, 0, 16, st));       // work counter + this frame's clamped-sample count
+    HIP_TRY(hipMemsetAsync(s->counter, 0, 32, st));       // work counter, this frame's clamped-sample count, per-launch unit counts
     if (s->want_phase_stats) {
         const uint32_t FULLPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
         if (F != 0u && F != FULLPDF)
@@ -823,6 +838,22 @@ int vk_scene_last_kernel_ms(vk_scene *s, double *ms_out) {
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     *ms_out = (double)ms;
+    if (s->dual_last && s->dual_launch) {        // did the two launches of the last frame share the work?  (see vk_scene::dual_strikes)
+        uint32_t u[2] = {0u, 0u};
+        if (hipMemcpy(u, s->counter + 4, sizeof(u), hipMemcpyDeviceToHost) == hipSuccess && u[0] + u[1] > 0u) {
+            const double share = (double)u[1] / (double)(u[0] + u[1]);       // ~12 / 28 when both run side by side
+            const bool lopsided = share < 0.10 || share > 0.90;
+            s->dual_strikes = lopsided ? s->dual_strikes + 1 : 0;
+            if (s->env.dual_debug) fprintf(stderr, "vecchio_amd: dual launch: 1024-thread launch %u units, 768-thread launch %u units (%.2f)\n", u[0], u[1], share);
+            if (s->dual_strikes >= 2) {
+                s->dual_launch = false;
+                fprintf(stderr, "vecchio_amd: the two launches of the 7-waves-per-SIMD shape do not run side by side on this runtime "
+                                "(unit split %u / %u); using the single-launch shape from now on\n", u[0], u[1]);
+            }
+        }
+        (void)hipGetLastError();
+        s->dual_last = false;
+    }
     return VK_OK;
 }
 

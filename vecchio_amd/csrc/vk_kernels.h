@@ -42,6 +42,7 @@ struct KArgs {
     uint32_t *counter;       // work-unit counter
     unsigned long long *clamped;   // number of samples whose radiance was clamped on its way into the fixed-point sums (see to_fixed)
     float accum_clamp;       // min(1e10, 1.3e11 / spp), worked out by the host (accum_clamp_for)
+    uint32_t *launch_units;  // [2] units pulled by the 1024-thread / the other launch (the dual launch's self-check, vk_api.hip)
     uint32_t *tile_cost;     // [tiles of the image] time spent on each tile (1.6 us ticks): written by the probe (COST) build only
     const uint32_t *tile_order;   // [n_local_tiles] local tile slots, dearest first (from the probe launch), or null = raster order
     uint32_t tiles_x, tiles_y;
@@ -366,7 +367,10 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &
         uint32_t total = __builtin_amdgcn_readfirstlane(ws.z), next = __builtin_amdgcn_readfirstlane(ws.w);
         if (next >= total) {
             uint32_t unit = 0;
-            if (lane == 0) unit = atomicAdd(KARG(P, counter), 1u);
+            if (lane == 0) {
+                unit = atomicAdd(KARG(P, counter), 1u);
+                atomicAdd(KARG(P, launch_units) + (blockDim.x == 1024u ? 0 : 1), 1u);      // (once per 2 048 samples or more)
+            }
             unit = __builtin_amdgcn_readfirstlane(unit);
             const uint32_t n_chunks = KARG(P, n_chunks);
             if (unit >= KARG(P, n_local_tiles) * n_chunks) {                      // the launch's units are all handed out:
