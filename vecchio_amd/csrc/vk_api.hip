@@ -1,7 +1,8 @@
 // vk_api.hip — the C ABI of include/vecchio_amd.h (libvecchio_amd.so) around the HIP megakernel of vk_kernels.h.
 //
 // Kernel structure (gfx950 / CDNA4, wave64):
-//   * persistent workgroups (512-768 threads, sized by plan_residency); each WAVE pulls work units =
+//   * persistent workgroups (256-1024 threads, sized by plan_residency; sphere-only scenes staged in LDS run as TWO concurrent
+//     launches, one 1024-thread and one 768-thread workgroup per CU = seven waves per SIMD: launch_dual); each WAVE pulls work units =
 //     (8x8-pixel tile, sample chunk) from a global atomic counter and hands them to its lanes sample by
 //     sample; it pulls the next unit the moment the current one is handed out (no per-unit drain);
 //   * one ray per lane.  A lane whose path ended takes the next (pixel, sample) through a ballot +
@@ -13,7 +14,7 @@
 //     (box_steps: nested steps under one shrinking EXEC mask, light primitive tests inline), PRIM heavy,
 //     SHADE + REFILL (out of line for the everything-variants); lane state that only shading needs
 //     (throughput, RNG, depth, pixel) is parked in LDS between SHADE phases so the traversal loops fit
-//     80 VGPRs (6 waves/SIMD; 64 = 8 waves/SIMD for sphere-only scenes traversed from global memory);
+//     80 VGPRs (6 waves/SIMD; 72 = 7 for sphere-only scenes in LDS; 64 = 8 for sphere-only scenes traversed from global memory);
 //   * traversal is the stack-free threaded walk of vk_trace.h; when the linear BVH + spheres + boxes
 //     fit next to that per-wave state WITHOUT costing occupancy, every workgroup stages them into its
 //     LDS (160 KB/CU) once and item fetches are ds_read_b128; otherwise they are L1/L2 gathers;
