@@ -82,6 +82,7 @@ struct EnvSwitches {
     int probe_spp = 0;                 // VK_PROBE_SPP=n
     int probe_depth = 0;               // VK_PROBE_DEPTH=n: depth limit of the probe launch's paths (default 16)
     int prim_weight = 0;               // VK_PRIM_WEIGHT=n
+    bool order_reuse = true;           // VK_ORDER_REUSE=0: probe the tile costs in every frame of a partition
     bool dual_same_stream = false;     // VK_DUAL_SAME_STREAM=1 (tests): see launch_dual
     bool dual_debug = false;           // VK_DUAL_DEBUG=1: print each checked frame's unit split
     int retree = -1;                   // VK_RETREE=0/1: force the SAH rebuild of draw-free subtrees off / on (default: vk_scene_desc.flags)
@@ -93,6 +94,7 @@ struct EnvSwitches {
         if (const char *e = getenv("VK_TILE_ORDER")) { v.tile_order = e[0] != '0'; v.tile_order_forced = e[0] == '1'; }
         if (const char *e = getenv("VK_RETREE")) v.retree = e[0] != '0' ? 1 : 0;
         if (const char *e = getenv("VK_DUAL_SAME_STREAM")) v.dual_same_stream = e[0] == '1';
+        if (const char *e = getenv("VK_ORDER_REUSE")) v.order_reuse = e[0] != '0';
         if (const char *e = getenv("VK_DUAL_DEBUG")) v.dual_debug = e[0] == '1';
         v.max_waves_per_cu = int_env("VK_MAX_WAVES_PER_CU");
         v.chunk_cap = int_env("VK_CHUNK_CAP");
@@ -145,6 +147,11 @@ struct vk_scene {
     // heavy-first tile order: per-tile times of the probe launch and the order derived from them
     uint32_t *tile_cost = nullptr, *tile_order = nullptr, *order_hist = nullptr;
     size_t tile_cost_n = 0, tile_order_n = 0;
+    // Frame-to-frame reuse of the order: the frames of an animation (and the steps of a benchmark) see nearly the same tile costs,
+    // so the order found for a partition is kept while the partition's geometry is the same, the camera has hardly moved and the
+    // order is younger than ORDER_MAX_AGE frames; then the probe launch and the three sorting kernels are skipped (~1.7 ms of a
+    // 1/8 share of C2's 42 ms).  The order never changes a pixel, so a stale one only costs balance.
+    struct { uint32_t width = 0, height = 0, rank = 0, world = 0, depth = 0, age = 0; float org[3] = {0, 0, 0}, llc[3] = {0, 0, 0}; bool valid = false; } order_for;
     // ---- multi-device group (empty for an ordinary scene)
     std::vector<vk_scene *> parts;
     // a part's own stream, its slab (on its device), the slab's landing buffer on devices[0] and the event that says it landed
@@ -465,7 +472,21 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
 
     int rc = VK_OK;
     uint32_t F = pick_variant(s) | (p->integrator == VK_INTEGRATOR_PDF ? (uint32_t)VKF_INTEG_PDF : 0u);
-    if (use_order && !s->want_phase_stats) {
+    // (VK_ORDER_REUSE=0 probes every frame)
+    bool reuse_order = false;
+    if (use_order && !s->want_phase_stats && s->env.order_reuse) {
+        auto &o = s->order_for;
+        auto close3 = [](const float *a, const float *b, float scale) {
+            float d = fabsf(a[0] - b[0]) + fabsf(a[1] - b[1]) + fabsf(a[2] - b[2]);
+            return d <= 0.05f * scale;
+        };
+        const float hscale = fabsf(cam->horizontal[0]) + fabsf(cam->horizontal[1]) + fabsf(cam->horizontal[2]) +
+                             fabsf(cam->vertical[0]) + fabsf(cam->vertical[1]) + fabsf(cam->vertical[2]);      // size of the view plane
+        reuse_order = o.valid && o.width == p->width && o.height == p->height && o.rank == g.rank && o.world == g.world &&
+                      o.depth == p->max_depth && o.age < 16u && close3(o.org, cam->origin, hscale) && close3(o.llc, cam->lower_left_corner, hscale);
+        if (reuse_order) { o.age++; A.tile_order = s->tile_order; }
+    }
+    if (use_order && !s->want_phase_stats && !reuse_order) {
         KArgs B = A;                                   // the probe: the same view at 1..4 samples per pixel, one unit per tile
         // (C2, one rank's 1/8 share: probe of 1 / 2 / 4 / 8 / 16 spp -> 68.6 / 69.0 / 69.8 / 70.5 / 73.0 ms: more samples cost more than
         // they sort better)
@@ -496,6 +517,9 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
             s->order_hist, s->tile_order);
         HIP_TRY(hipGetLastError());
         A.tile_order = s->tile_order;
+        auto &o = s->order_for;
+        o.valid = true; o.width = p->width; o.height = p->height; o.rank = g.rank; o.world = g.world; o.depth = p->max_depth; o.age = 0;
+        for (int k = 0; k < 3; k++) { o.org[k] = cam->origin[k]; o.llc[k] = cam->lower_left_corner[k]; }
     }
     HIP_TRY(hipMemsetAsync(s->counter, 0, 32, st));       // work counter, this frame's clamped-sample count, per-launch unit counts
     if (s->want_phase_stats) {
