@@ -187,7 +187,7 @@ typedef struct vk_scene_desc {
  * 1920x1080x1024-spp frame (2.1 G samples) is bit-identical with and without the flag (+28 % throughput); on the 1 M-sphere
  * stress scene 0.19 % of the samples differ — exactly as many as between two reference-style trees over the same world
  * (profiles/r03/tree_variation.log).  Off by default: only the tree handed over matches a seeded reference run sample for sample. */
-enum { VK_SCENE_FAST_ACCEL = 1 };
+enum { VK_SCENE_FAST_ACCEL = 1, VK_SCENE_REFERENCE_TREE = 2 };
 
 /* ---- camera: the ten fields of main.rs:57-68, computed by Camera::new on the host --- */
 typedef struct vk_camera {
@@ -311,6 +311,10 @@ int vk_scene_last_kernel_ms(vk_scene *scene, double *ms_out);
 
 /* see vk_stats.clamped_samples; waits for the end of the last render enqueued on this scene */
 int vk_scene_last_clamped_samples(vk_scene *scene, uint64_t *count_out);
+/* Exact re-treeing (see vk_scene_desc.flags): samples of the last render that were rendered by the second launch, on the tree as
+ * handed over; waits for the render's end.  Returns VK_ERR_OOM when the queues between the two launches overflowed: that frame is
+ * incomplete (vk_render reports the same). */
+int vk_scene_last_requeued_samples(vk_scene *scene, uint64_t *count_out);
 
 /* test/diagnostic entry points (vk_debug_*) are declared in vecchio_amd_debug.h */
 

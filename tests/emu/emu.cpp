@@ -14,20 +14,44 @@
 #include "../../vecchio_amd/csrc/vk_trace.h"
 
 #include <cstdlib>
+#include <cstdio>
 
 using namespace vkd;
 
 static thread_local std::string g_err;
+static std::atomic<uint64_t> g_redo(0), g_segments(0);      // exact re-treeing: segments walked twice / all segments
 
 // VK_RETREE=0/1 forces re-treeing off / on (same switch as the device library); default: vk_scene_desc.flags
 static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string &err) {
     LinearizeOptions opt;
-    if (const char *e = getenv("VK_RETREE")) opt.retree = e[0] != '0' ? 1 : 0;
+    if (const char *e = getenv("VK_RETREE")) opt.retree = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     return linearize(desc, LS, err, opt);
+}
+// EMU_GLOBAL_VARIANT=1: scenes of spheres only as the device runs them from GLOBAL memory (unfused box test; exact re-treeing with both
+// trees in one item array, early segments walked again in place) instead of as it runs them from LDS (fused test, queued samples)
+static bool global_variant() { const char *e = getenv("EMU_GLOBAL_VARIANT"); return e && e[0] == '1'; }
+static DScene scene_view(const LinearScene &LS, std::vector<DItem> &both) {
+    DScene S = LS.host_view();
+    if (global_variant() && !LS.ref_items.empty()) {
+        uint32_t ws = 0;
+        both = LS.combined_items(ws);
+        S.items = both.data(); S.n_items = (uint32_t)both.size(); S.n_world_items = (uint32_t)both.size(); S.walk_start = ws;
+        S.ref_items = nullptr; S.n_ref_items = 0;
+    }
+    return S;
 }
 
 // the same records as GlobalMem, with the fused box test the device runs on LDS-resident scenes (vk_trace.h set_space)
 struct FusedMem : GlobalMem { static constexpr bool FUSED_BOX = true; };
+
+// the scene as handed over: what a sample dropped by exact re-treeing is rendered on (vk_api.hip builds the same view for the
+// second launch)
+static DScene reference_view(const DScene &S) {
+    DScene r = S;
+    r.items = S.ref_items; r.n_items = S.n_ref_items; r.n_world_items = S.n_ref_items;
+    r.ref_items = nullptr; r.n_ref_items = 0; r.t_pad = 0.0f; r.gate_scale = 1.0f; r.tmin_gate = T_MIN; r.tie_rank = nullptr;
+    return r;
+}
 
 template <uint32_t F, class Mem = GlobalMem>
 static void trace_one(const DScene &S, const GlobalMem &M0, const RenderConsts &C, uint32_t pixel, uint32_t sample, V3 &rgb,
@@ -37,6 +61,19 @@ static void trace_one(const DScene &S, const GlobalMem &M0, const RenderConsts &
     start_sample<F, Mem>(L, S, C, pixel % C.width, pixel / C.width, sample);
     for (;;) {
         while (traversing(L)) { traverse_step<F, Mem>(L, S, M); if (steps) (*steps)++; }
+        if (S.walk_start != 0u && winner_is_early(L, S)) {      // exact re-treeing, both trees in items[] (the device's global-memory
+            g_redo++;                                           // scenes): this segment again, on the tree as handed over
+            begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, L.o, L.d, L.time, true);
+            continue;
+        }
+        if (winner_is_early(L, S)) {       // exact re-treeing: the whole sample again on the tree as handed over (the device's LDS scenes)
+            DScene Sr = reference_view(S);
+            GlobalMem Mr = M0; Mr.items = Sr.items;
+            g_redo++;
+            trace_one<F, Mem>(Sr, Mr, C, pixel, sample, rgb, draws, steps);
+            return;
+        }
+        g_segments++;
         if (!shade<F, Mem>(L, S, M, C)) break;
     }
     rgb = L.acc;
@@ -86,7 +123,8 @@ static void box_decisions(const float *boxes, const float *rays, size_t n, uint8
         L.i = 0; L.end = 1; L.pend = 0;
         typename std::conditional<FUSED, FusedMem, GlobalMem>::type M;
         M.items = &it; M.spheres = nullptr; M.sphere_mat = nullptr; M.boxes = nullptr;
-        box_step_core<F, decltype(M)>(L, M);
+        DScene S0; memset(&S0, 0, sizeof(S0)); S0.gate_scale = 1.0f; S0.tmin_gate = T_MIN;
+        box_step_core<F, decltype(M)>(L, S0, M);
         bool fast = L.pend != 0;
         bool exact = slab_exact(it, o, d, T_MIN, rays[k * 7 + 6]);
         // was the fallback taken?  the margin test exactly as box_step_core writes it
@@ -111,6 +149,9 @@ extern "C" {
 
 const char *emu_last_error(void) { return g_err.c_str(); }
 
+// exact re-treeing: samples rendered again on the tree as handed over since the last call (and segments walked)
+void emu_take_redo_stats(uint64_t out[2]) { out[0] = g_redo.exchange(0); out[1] = g_segments.exchange(0); }
+
 // the full-feature variants, and for scenes of spheres only the sphere-only ones (as the device library picks them: they
 // run the fused box test, vk_trace.h set_space); the Cornell-type variants in between are the same code as the full ones
 static const uint32_t FALL = VKF_ALL_SCENE;
@@ -118,10 +159,16 @@ static const uint32_t FPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
 static void trace_any(const DScene &S, const GlobalMem &M, const RenderConsts &C, uint32_t integrator, uint32_t pixel, uint32_t sample,
     V3 &rgb, uint32_t &draws, uint64_t *steps) {
     bool lean = S.features == 0u && !getenv("VK_FORCE_FULL_VARIANT");
-    if (integrator == VK_INTEGRATOR_PDF) { if (lean) trace_one<VKF_INTEG_PDF, FusedMem>(S, M, C, pixel, sample, rgb, draws, steps);
-        else trace_one<FPDF>(S, M, C, pixel, sample, rgb, draws, steps); }
-    else { if (lean) trace_one<0u, FusedMem>(S, M, C, pixel, sample, rgb, draws, steps);
-        else trace_one<FALL>(S, M, C, pixel, sample, rgb, draws, steps); }
+    const bool glob = lean && global_variant();
+    if (integrator == VK_INTEGRATOR_PDF) {
+        if (glob) trace_one<VKF_INTEG_PDF, GlobalMem>(S, M, C, pixel, sample, rgb, draws, steps);
+        else if (lean) trace_one<VKF_INTEG_PDF, FusedMem>(S, M, C, pixel, sample, rgb, draws, steps);
+        else trace_one<FPDF>(S, M, C, pixel, sample, rgb, draws, steps);
+    } else {
+        if (glob) trace_one<0u, GlobalMem>(S, M, C, pixel, sample, rgb, draws, steps);
+        else if (lean) trace_one<0u, FusedMem>(S, M, C, pixel, sample, rgb, draws, steps);
+        else trace_one<FALL>(S, M, C, pixel, sample, rgb, draws, steps);
+    }
 }
 
 int emu_sample(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_params *p, uint32_t pixel, uint32_t sample,
@@ -129,7 +176,8 @@ int emu_sample(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
     LinearScene LS;
     int st = linearize_env(desc, LS, g_err);
     if (st != VK_OK) return st;
-    DScene S = LS.host_view();
+    std::vector<DItem> both;
+    DScene S = scene_view(LS, both);
     GlobalMem M{S.items, S.spheres, S.sphere_mat, S.boxes};
     RenderConsts C = make_consts(cam, p);
     V3 c; uint32_t dr;
@@ -145,7 +193,8 @@ int emu_first_hit(const vk_scene_desc *desc, const vk_camera *cam, const vk_rend
     LinearScene LS;
     int st = linearize_env(desc, LS, g_err);
     if (st != VK_OK) return st;
-    DScene S = LS.host_view();
+    std::vector<DItem> both;
+    DScene S = scene_view(LS, both);
     GlobalMem M{S.items, S.spheres, S.sphere_mat, S.boxes};
     RenderConsts C = make_consts(cam, p);
     Lane L;
@@ -164,7 +213,8 @@ int emu_render(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
     if (st != VK_OK) return st;
     if (p->integrator == VK_INTEGRATOR_PDF && LS.lights.empty()) { g_err =
         "PDF integrator needs a non-empty lights list (hittable.rs:431 would panic)"; return VK_ERR_UNSUPPORTED; }
-    DScene S = LS.host_view();
+    std::vector<DItem> both;
+    DScene S = scene_view(LS, both);
     GlobalMem M{S.items, S.spheres, S.sphere_mat, S.boxes};
     RenderConsts C = make_consts(cam, p);
     if (info_out) { info_out[0] = S.n_items; info_out[1] = LS.n_prims; info_out[2] = (uint32_t)LS.instances.size();
@@ -200,6 +250,7 @@ int emu_render(const vk_scene_desc *desc, const vk_camera *cam, const vk_render_
     worker();
     for (auto &t : ths) t.join();
     if (steps_out) *steps_out = total_steps.load();
+    if (getenv("VK_EMU_STATS")) fprintf(stderr, "emu: %llu segments, %llu samples rendered again on the reference tree\n", (unsigned long long)g_segments.load(), (unsigned long long)g_redo.load());
     return VK_OK;
 }
 

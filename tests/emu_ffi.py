@@ -38,3 +38,11 @@ def render_samples(desc, cam, p, threads=None):
     if st != 0:
         raise RuntimeError(f"emu status {st}: {lib.emu_last_error().decode()}")
     return img, ps, steps.value, list(info)
+
+
+def take_redo_stats():
+    """exact re-treeing: (samples rendered again on the tree as handed over, segments walked) since the last call"""
+    lib = load()
+    out = (C.c_uint64 * 2)()
+    lib.emu_take_redo_stats(out)
+    return int(out[0]), int(out[1])

@@ -98,11 +98,45 @@ def test_retree_cuts_the_box_tests_of_the_headline_scene(emu, built):
     hs = HostScene("random_spheres_iow", 1)
     cam = hs.next_camera()
     p = hs.params(64, 2, 50)
-    _, ps_r, steps_r, info_r = emu.render_samples(hs.desc, cam, p)          # flags = 0: the tree handed over
+    hs.desc.contents.flags = ffi.VK_SCENE_REFERENCE_TREE
+    _, ps_r, steps_r, info_r = emu.render_samples(hs.desc, cam, p)          # the tree handed over
     hs.desc.contents.flags = ffi.VK_SCENE_FAST_ACCEL
     _, ps, steps, info = emu.render_samples(hs.desc, cam, p)
     assert np.array_equal(ps.view(np.uint32), ps_r.view(np.uint32))      # bit-identical samples
     assert info_r[0] == 511 and steps < 0.7 * steps_r
+    hs.desc.contents.flags = 0                                           # the default: exact re-treeing (a scene of spheres only)
+    _, ps_x, steps_x, _ = emu.render_samples(hs.desc, cam, p)
+    assert np.array_equal(ps_x.view(np.uint32), ps_r.view(np.uint32))
+    assert steps_x < 0.8 * steps_r
+
+
+@pytest.mark.parametrize("variant", ["lds", "global"])
+@pytest.mark.parametrize("grid_half", [40, 130])
+def test_exact_retree_gives_the_handed_over_trees_samples_on_far_small_spheres(grid_half, variant, oracle, emu, built, monkeypatch):
+    """The default for a scene of spheres only (vk_trace.h accept_exact): a tree rebuilt over the reference's leaf units; where the
+    winner of a segment could depend on the visiting order, the tree as handed over decides — for the whole sample (scenes the device
+    stages in LDS: a second launch) or for that segment (scenes it traverses from global memory: both trees in one array).  Thousands
+    of pixel-sized spheres on a ground sphere of radius 1e5 are where computed hits precede their box entries: every sample must still
+    be the handed-over tree's, bit for bit, and the oracle's within the usual tolerance."""
+    import emu_ffi
+    from vecchio_amd import HostScene
+    monkeypatch.setenv("EMU_GLOBAL_VARIANT", "1" if variant == "global" else "0")
+    hs = HostScene(f"stress_spheres:{grid_half}", 1)
+    cam = hs.next_camera()
+    p = hs.params(72, 2, 50, seed=5)
+    img_o, ps_o = oracle.render_samples(hs.desc, cam, p)                    # the recursive restatement on the tree handed over
+    emu_ffi.take_redo_stats()
+    img_x, ps_x, steps_x, info = emu.render_samples(hs.desc, cam, p)
+    redone, segments = emu_ffi.take_redo_stats()
+    compare(ps_o, ps_x, img_o, img_x)
+    hs.desc.contents.flags = ffi.VK_SCENE_REFERENCE_TREE
+    _, ps_r, steps_r, _ = emu.render_samples(hs.desc, cam, p)
+    assert emu_ffi.take_redo_stats()[0] == 0
+    assert np.array_equal(ps_x.view(np.uint32), ps_r.view(np.uint32))
+    assert redone > 0, "nothing took the second walk: the scene does not exercise it"
+    print(f"stress_spheres:{grid_half} {variant}: {redone} of {segments} segments / {ps_o.shape[0]} samples again; steps {steps_x} against {steps_r}")
+    if variant == "global" and grid_half > 100:      # (the small grid is mostly ground sphere, radius 1e5: every fifth segment is early)
+        assert redone < 0.1 * segments and steps_x < 0.9 * steps_r
 
 
 @pytest.mark.gpu

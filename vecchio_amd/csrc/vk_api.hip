@@ -92,7 +92,7 @@ struct EnvSwitches {
         if (const char *e = getenv("VK_FORCE_FULL_VARIANT")) v.force_full_variant = e[0] == '1';
         if (const char *e = getenv("VK_NO_LDS_SCENE")) v.no_lds_scene = e[0] == '1';
         if (const char *e = getenv("VK_TILE_ORDER")) { v.tile_order = e[0] != '0'; v.tile_order_forced = e[0] == '1'; }
-        if (const char *e = getenv("VK_RETREE")) v.retree = e[0] != '0' ? 1 : 0;
+        if (const char *e = getenv("VK_RETREE")) v.retree = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
         if (const char *e = getenv("VK_DUAL_SAME_STREAM")) v.dual_same_stream = e[0] == '1';
         if (const char *e = getenv("VK_ORDER_REUSE")) v.order_reuse = e[0] != '0';
         if (const char *e = getenv("VK_DUAL_DEBUG")) v.dual_debug = e[0] == '1';
@@ -142,6 +142,13 @@ struct vk_scene {
     bool dual_last = false;        // the last render used the dual launch
     int dual_strikes = 0;
     bool last_timed = false;
+    // Exact re-treeing (vk_trace.h): the scene's own tree is a rebuilt one; samples it cannot vouch for are queued by the first launch
+    // and rendered by a second one on `ref_view`, the scene as handed over.  redo_count: REDO_REGIONS counters + the 3 plan words.
+    bool exact = false;            // host->ref_items is there and the switch VK_EXACT_RETREE is not 0
+    DScene ref_view;
+    uint2 *redo_list = nullptr; size_t redo_bytes = 0;
+    uint32_t *redo_count = nullptr;
+    bool redo_last = false;        // the last render had a second launch
     unsigned long long *phase_stats = nullptr;   // device, 16 counters (diagnostic kernel build)
     bool want_phase_stats = false;
     // heavy-first tile order: per-tile times of the probe launch and the order derived from them
@@ -391,6 +398,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     KArgs A;
     memset(&A, 0, sizeof(A));
     A.S = s->dev;
+    const bool exact = s->exact && !s->want_phase_stats;     // (the diagnostic builds render on the rebuilt tree alone)
     A.C.cam = *cam;
     A.C.width = p->width; A.C.height = p->height; A.C.spp = p->samples_per_pixel; A.C.max_depth = p->max_depth;
     A.C.seed = p->seed; A.C.integrator = p->integrator; A.C.background = p->background;
@@ -455,11 +463,26 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         HIP_TRY(hipMemsetAsync(s->accum, 0, n_pixels * 3 * sizeof(long long), st));
         A.accum = s->accum;
     }
+    s->redo_last = false;
+    if (exact) {
+        // queues for the samples the first launch drops: an eighth of the partition's samples, spread over REDO_REGIONS (a scene of a
+        // million pixel-sized spheres drops 5 %; a full queue is reported where the caller synchronises, vk_scene_last_kernel_ms)
+        const uint64_t samples = partition_samples(p, g);
+        const uint64_t per_region = samples / 8u / REDO_REGIONS + 4096u;
+        if (per_region * REDO_REGIONS >= 0xFFFFFFFFull) return fail(VK_ERR_UNSUPPORTED, "frame too large for the redo queues of exact re-treeing (VK_EXACT_RETREE=0 renders it on the tree handed over)");
+        int rc = ensure(s->redo_list, s->redo_bytes, (size_t)per_region * REDO_REGIONS * sizeof(uint2));
+        if (rc != VK_OK) return rc;
+        HIP_TRY(hipMemsetAsync(s->redo_count, 0, (REDO_REGIONS * REDO_COUNT_STRIDE + 16) * sizeof(uint32_t), st));
+        A.redo_list = s->redo_list; A.redo_count = s->redo_count; A.redo_plan = s->redo_count + REDO_REGIONS * REDO_COUNT_STRIDE;
+        A.redo_region_cap = (uint32_t)per_region;
+    } else if (s->exact) {
+        A.S = s->ref_view;      // the diagnostic builds have no second launch: they render on the tree as handed over
+    }
     // LDS residency of the hot records
     bool lds = s->lds_bytes != 0;
     const uint32_t waves_per_wg = s->wg_threads / 64;
     size_t shmem = (size_t)waves_per_wg * per_wave_lds_bytes(pick_variant(s));
-    if (lds) { A.lds_items = s->dev.n_items; A.lds_spheres = s->dev.n_spheres; A.lds_boxes = s->dev.n_boxes; shmem += s->lds_bytes; }
+    if (lds) { A.lds_items = A.S.n_items; A.lds_spheres = s->dev.n_spheres; A.lds_boxes = s->dev.n_boxes; shmem += s->lds_bytes; }
     // persistent grid: enough workgroups to fill the chip, never more than there are units
     s->dual_last = false;
     const uint64_t n_units = (uint64_t)A.n_local_tiles * A.n_chunks;
@@ -501,6 +524,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
             if (B.C.max_depth > cut) B.C.max_depth = cut;
         }
         B.n_chunks = 1; B.accum = nullptr; B.debug = nullptr; B.tile_order = nullptr;   // no sums: the probe only times the tiles
+        B.redo_list = nullptr;                         // ... and drops nothing
         B.tile_cost = s->tile_cost;
         HIP_TRY(hipMemsetAsync(s->tile_cost, 0, (size_t)tiles * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(s->counter, 0, sizeof(uint32_t), st));
@@ -554,6 +578,20 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         else rc = launch_by_features(s, F, A, lds, dim3(grid), shmem, st, false);
     }
     if (rc != VK_OK) return rc;
+    if (exact) {
+        // the second launch: the queued samples on the scene as handed over, in the single-launch shape
+        uint32_t *plan = s->redo_count + REDO_REGIONS * REDO_COUNT_STRIDE;
+        hipLaunchKernelGGL(redo_plan_kernel, dim3((REDO_REGIONS + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)s->redo_count,
+            A.redo_region_cap, plan);
+        HIP_TRY(hipMemsetAsync(s->counter, 0, sizeof(uint32_t), st));      // the unit counter only: clamped samples and unit counts add up
+        KArgs B = A;
+        B.S = s->ref_view; B.list_mode = 1u; B.tile_order = nullptr;
+        if (lds) B.lds_items = B.S.n_items;
+        B.shade_defer = SHADE_DEFER; B.prim_weight = s->hot_bytes > (4u << 20) ? 3u : 1u;
+        rc = launch_by_features(s, F, B, lds, dim3((uint32_t)s->num_cus * s->wgs_per_cu), shmem, st, false);
+        if (rc != VK_OK) return rc;
+        s->redo_last = true;
+    }
     {
         uint32_t blocks = (uint32_t)((n_pixels + 255) / 256);
         hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(256), 0, st, (const long long *)A.accum, d_out, p->width, p->height,
@@ -655,7 +693,7 @@ void destroy_one(vk_scene *s) {
     for (void *p : s->allocs) (void)hipFree(p);
     for (void *p : {(void *)s->counter, (void *)s->fb, (void *)s->fb8, (void *)s->accum, (void *)s->debug, (void *)s->phase_stats,
         (void *)s->tile_cost,
-                    (void *)s->tile_order, (void *)s->order_hist, (void *)s->slab})
+                    (void *)s->tile_order, (void *)s->order_hist, (void *)s->slab, (void *)s->redo_list, (void *)s->redo_count})
         if (p) (void)hipFree(p);
     if (s->landing) { (void)hipSetDevice(s->landing_device); (void)hipFree(s->landing); (void)hipSetDevice(s->device); }
     for (hipEvent_t e : {s->ev0, s->ev1, s->ev_landed, s->ev_begin, s->ev_fork, s->ev_join})
@@ -694,7 +732,33 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
     DScene &D = s->dev;
     memset(&D, 0, sizeof(D));
 #define UP(vec, field) do { rc = upload(s.get(), H.vec, D.field); if (rc != VK_OK) return rc; } while (0)
-    UP(items, items); UP(spheres, spheres); UP(sphere_mat, sphere_mat); UP(moving, moving); UP(rects, rects); UP(boxes, boxes);
+    // LDS residency: items + spheres + accumulators must leave room for >= 2 workgroups per CU
+    // (exact re-treeing: the second launch stages the tree as handed over instead of the rebuilt one, whichever is larger counts)
+    size_t hot = std::max(H.items.size(), H.ref_items.size()) * sizeof(DItem) + H.spheres.size() * sizeof(DSphere) + H.boxes.size() * sizeof(DBox);
+    s->hot_bytes = hot;
+    plan_residency(s.get(), hot);
+    D.gate_scale = 1.0f; D.tmin_gate = T_MIN;
+    if (!H.ref_items.empty()) {
+        // Exact re-treeing (vk_trace.h).  Staged in LDS: the rebuilt tree is the scene's, the tree as handed over serves the second launch
+        // (`exact`).  Traversed from global memory: both trees in one array, early segments are walked again in place (DScene::walk_start).
+        const DScene hv = H.host_view();
+        D.t_pad = hv.t_pad; D.gate_scale = hv.gate_scale; D.tmin_gate = hv.tmin_gate;
+        if (s->lds_bytes != 0) {
+            UP(items, items); UP(ref_items, ref_items);
+            D.n_ref_items = hv.n_ref_items; D.n_items = (uint32_t)H.items.size(); D.n_world_items = H.world_items;
+            s->exact = true;
+        } else {
+            uint32_t walk_start = 0;
+            const std::vector<DItem> both = H.combined_items(walk_start);
+            rc = upload(s.get(), both, D.items);
+            if (rc != VK_OK) return rc;
+            D.n_items = (uint32_t)both.size(); D.n_world_items = (uint32_t)both.size(); D.walk_start = walk_start;
+        }
+    } else {
+        UP(items, items);
+        D.n_items = (uint32_t)H.items.size(); D.n_world_items = H.world_items;
+    }
+    UP(spheres, spheres); UP(sphere_mat, sphere_mat); UP(moving, moving); UP(rects, rects); UP(boxes, boxes);
     UP(lists, lists); UP(list_refs, list_refs); UP(media, media); UP(instances, instances);
     UP(materials, materials); UP(textures, textures); UP(images, images); UP(image_bytes, image_bytes);
     UP(perlins, perlins); UP(lights, lights);
@@ -704,7 +768,7 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
     D.n_noise_spheres = H.n_noise_spheres;
     for (int k = 0; k < 4; k++) { D.noise_sphere[k] = H.noise_sphere[k]; D.noise_tex[k] = H.noise_tex[k];
         D.noise_perlin[k] = H.noise_perlin[k]; }
-    D.n_items = (uint32_t)H.items.size(); D.n_world_items = H.world_items; D.n_spheres = (uint32_t)H.spheres.size();
+    D.n_spheres = (uint32_t)H.spheres.size();
     D.n_lights = (uint32_t)H.lights.size(); D.features = H.features; D.n_boxes = (uint32_t)H.boxes.size();
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->counter), 256));
     HIP_TRY(hipEventCreate(&s->ev0));
@@ -713,10 +777,14 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
         HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_landed, hipEventDisableTiming));
     }
-    // LDS residency: items + spheres + accumulators must leave room for >= 2 workgroups per CU
-    size_t hot = H.items.size() * sizeof(DItem) + H.spheres.size() * sizeof(DSphere) + H.boxes.size() * sizeof(DBox);
-    s->hot_bytes = hot;
-    plan_residency(s.get(), hot);
+    if (s->exact) {
+        // the scene as handed over (tests/emu/emu.cpp reference_view is the same thing on the host)
+        s->ref_view = D;
+        s->ref_view.items = D.ref_items; s->ref_view.n_items = D.n_ref_items; s->ref_view.n_world_items = D.n_ref_items;
+        s->ref_view.ref_items = nullptr; s->ref_view.n_ref_items = 0; s->ref_view.t_pad = 0.0f; s->ref_view.gate_scale = 1.0f;
+        s->ref_view.tmin_gate = T_MIN; s->ref_view.tie_rank = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->redo_count), (REDO_REGIONS * REDO_COUNT_STRIDE + 16) * sizeof(uint32_t)));
+    }
     if (s->dual_launch) {
         HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
@@ -904,6 +972,33 @@ int vk_scene_last_clamped_samples(vk_scene *s, uint64_t *out) {
     return VK_OK;
 }
 
+// Exact re-treeing: samples of the last render that the first launch handed to the second one (rendered on the tree as handed
+// over); waits for the render's end.  A queue that overflowed (more than an eighth of the samples, or a very uneven spread) means
+// the frame is INCOMPLETE: reported as an error here, in vk_scene_last_kernel_ms and by vk_render.
+int vk_scene_last_requeued_samples(vk_scene *s, uint64_t *out) {
+    if (!s || !out) return fail(VK_ERR_BAD_ARG, "null argument");
+    if (!s->last_timed) return fail(VK_ERR_BAD_ARG, "no render enqueued yet");
+    *out = 0;
+    if (!s->parts.empty()) {
+        for (vk_scene *q : s->parts) {
+            uint64_t v = 0;
+            int rc = vk_scene_last_requeued_samples(q, &v);
+            if (rc != VK_OK) return rc;
+            *out += v;
+        }
+        return VK_OK;
+    }
+    if (!s->redo_last) return VK_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    uint32_t plan[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpy(plan, s->redo_count + REDO_REGIONS * REDO_COUNT_STRIDE, sizeof(plan), hipMemcpyDeviceToHost));
+    *out = plan[1];
+    if (plan[2] != 0u) return fail(VK_ERR_OOM, "exact re-treeing: " + std::to_string(plan[2]) + " samples did not fit the redo queues, the frame is "
+        "incomplete (VK_RETREE=0 or VK_SCENE_REFERENCE_TREE renders on the tree handed over)");
+    return VK_OK;
+}
+
 static int render_host(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, void *out_host, vk_stats *stats_out,
     float *debug_out) {
     if (!out_host) return fail(VK_ERR_BAD_ARG, "null framebuffer");
@@ -930,6 +1025,7 @@ static int render_host(vk_scene *scene, const vk_camera *cam, const vk_render_pa
     st.kernel_ms = ms;
     rc = vk_scene_last_clamped_samples(scene, &st.clamped_samples);
     if (rc != VK_OK) return rc;
+    { uint64_t requeued = 0; rc = vk_scene_last_requeued_samples(scene, &requeued); if (rc != VK_OK) return rc; }
     HIP_TRY(hipSetDevice(scene->device));
     uint32_t world = params->tile_world ? params->tile_world : 1;
     if (world == 1) {

@@ -29,6 +29,7 @@ enum : uint32_t {
 };
 constexpr uint32_t DREF_FLIP = 0x08000000u;
 constexpr uint32_t DREF_INDEX = 0x07FFFFFFu;
+constexpr uint32_t DREF_EARLY = 0x04000000u;   // in Lane::best_prim under exact re-treeing (scenes of < 2^26 spheres): see vk_trace.h accept_exact
 #define VKD_KIND(r) ((r) >> 28)
 #define VKD_INDEX(r) ((r) & 0x07FFFFFFu)
 #define VKD_MAKE(kind, idx) (((uint32_t)(kind) << 28) | ((uint32_t)(idx) & 0x07FFFFFFu))
@@ -115,6 +116,15 @@ struct DScene {
     // by comparing their hit with this list instead of chasing sphere -> material -> texture): sphere index, texture, perlin table.
     // n_noise_spheres = ~0: more than fit here, look the material up.
     uint32_t n_noise_spheres; uint32_t noise_sphere[4], noise_tex[4], noise_perlin[4];
+    // Exact re-treeing (vk_linearize.cpp rt_collect, vk_trace.h accept_exact): t_pad > 0 says that items[0, n_world_items) is a tree
+    // REBUILT over the reference's leaf units, walked with the closest hit so far padded by (1 + t_pad); ref_items[0, n_ref_items) is
+    // the tree as handed over, on which the rare sample whose result may depend on the visiting order is rendered again.
+    // gate_scale = 1 / (1 + t_pad) and tmin_gate = T_MIN * gate_scale (rounded down); 1 and T_MIN when t_pad == 0.
+    const DItem *ref_items; uint32_t n_ref_items; float t_pad, gate_scale, tmin_gate;
+    // Scenes traversed from global memory keep BOTH trees in items[]: [the tree as handed over | a sentinel no ray passes | the
+    // rebuilt tree], walk_start = index of the rebuilt tree's first item (0: items[] is one tree).  A segment whose winner is early
+    // is then walked again right away, from item 0, instead of its sample being queued (vk_trace.h begin_segment).
+    uint32_t walk_start;
 };
 
 }  // namespace vkd

@@ -53,7 +53,17 @@ struct KArgs {
     uint32_t prim_weight;    // pending primitive tests run when prim_weight x their lanes outnumber the box lanes
     uint32_t lds_items, lds_spheres, lds_boxes;   // record counts staged into LDS (LDS variant)
     unsigned long long *phase_stats;   // optional (diagnostic build of the kernel): 16 counters, see vk_debug_phase_stats
+    // Exact re-treeing (vk_trace.h): samples dropped by the first launch (the winner of one of their segments may depend on the visiting
+    // order) are queued here, REDO_REGIONS queues of redo_region_cap entries {x | y << 16, sample}, one counter per region (64 bytes
+    // apart); a workgroup appends to the region of its block index.  The second launch (list_mode = 1, S = the scene as handed over)
+    // takes its units from these queues instead of from the tiles: unit u = entries [2048 k, 2048 (k + 1)) of region u % REDO_REGIONS,
+    // k = u / REDO_REGIONS, for k below the slice count redo_plan_kernel leaves in redo_plan[0].  redo_list == null: nothing is dropped
+    // (the probe launch, scenes without a rebuilt tree).
+    uint2 *redo_list; uint32_t *redo_count; const uint32_t *redo_plan; uint32_t redo_region_cap; uint32_t list_mode;
 };
+constexpr uint32_t REDO_REGIONS = 512u;
+constexpr uint32_t REDO_COUNT_STRIDE = 16u;        // uint32 words between two regions' counters
+constexpr uint32_t REDO_UNIT = 256u;               // queue entries per work unit of the second launch (small: a short list must reach every wave)
 
 // LDS-resident hot records
 struct LdsMem {
@@ -299,7 +309,7 @@ __device__ __forceinline__ PreTurb cooperative_turb(const Lane &L, const DScene 
 // through shade_refill_call (below) by the everything-variants.
 struct PhaseClocks { unsigned long long mat = 0, refill = 0, t1 = 0; };
 template <uint32_t F, bool LDS_SCENE, bool STATS, bool COST>
-__device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &active, bool &need, bool &fresh, bool &touched,
+__device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &active, bool &need, bool &fresh, bool &touched, bool &rearm,
                                                   uint32_t &cost_t0, KArgsC P, float *cold, unsigned long long *tile_sum,
                                                   uint32_t *wstate, uint32_t lane, uint32_t lds_items, PhaseClocks &clk) {
     using Mem = typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type;
@@ -308,10 +318,41 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &
     Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
     unsigned long long &st_t_mat = clk.mat, &st_t_refill = clk.refill, &st_t1 = clk.t1;
     (void)st_t_mat; (void)st_t_refill; (void)st_t1; (void)cost_t0;
-    touched = is_shade;           // lanes whose path state is in registers during this phase
     fresh = false;                // lanes that leave this phase with a new ray to install; it is parked in the
                                   // (dead) world-ray fields L.wo / L.wd / L.time, so it costs no registers
     const PreTurb pre_turb = cooperative_turb<F, Mem>(L, S, M, is_shade, lane);
+    rearm = false;
+    if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && !LDS_SCENE) {
+        // exact re-treeing, scene in global memory (both trees in items[], DScene::walk_start): a segment won by an "early" object
+        // (vk_trace.h accept_exact) is walked again, now on the tree as handed over; the caller re-installs the same ray for that
+        if (S.walk_start != 0u && is_shade && winner_is_early(L, S)) {
+            rearm = true; is_shade = false;
+            L.wo = L.o; L.wd = L.d;      // (L.time is the segment's)
+        }
+    }
+    if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && LDS_SCENE) {
+        // exact re-treeing, scene in LDS (the rebuilt tree only): the sample of such a segment is dropped here and rendered by the second
+        // launch on the tree as handed over.  One counter update per wave and phase, prefix sums over the dropping lanes.
+        uint2 *rl = KARG(P, redo_list);
+        const unsigned long long m_drop = __builtin_amdgcn_ballot_w64(is_shade && rl != nullptr && winner_is_early(L, S));
+        if (m_drop != 0ull) {
+            const uint32_t region = (blockIdx.x + (blockDim.x == 1024u ? 0u : gridDim.x)) & (REDO_REGIONS - 1u);      // (dual launch: 0..255 | 256..511)
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(KARG(P, redo_count) + region * REDO_COUNT_STRIDE, (uint32_t)__popcll(m_drop));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if ((m_drop >> lane) & 1ull) {
+                const uint32_t slot = base + (uint32_t)__popcll(m_drop & ((1ull << lane) - 1ull));
+                const uint32_t cap = KARG(P, redo_region_cap);
+                // (a full region: the counter keeps counting and the host sees the overflow, vk_api.hip)
+                if (slot < cap) rl[(size_t)region * cap + slot] = make_uint2(__float_as_uint(cold[CF_XY * 64 + lane]),
+                    __float_as_uint(cold[CF_SAMPLE * 64 + lane]));
+                is_shade = false; active = false; need = true;
+            }
+        }
+        // (the probe launch shades such a segment like any other; lanes still traversing keep their flag)
+        if (S.t_pad > 0.0f && is_shade) L.best_prim &= ~DREF_EARLY;
+    }
+    touched = is_shade;
     if (is_shade) {
         cold_load_path<F>(cold, lane, L);
         if (STATS) st_t1 = clock64();
@@ -365,13 +406,29 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &
         uint4 ws = *reinterpret_cast<const uint4 *>(wstate);       // one ds_read_b128, the same address in every lane
         uint32_t txy = __builtin_amdgcn_readfirstlane(ws.x), s0 = __builtin_amdgcn_readfirstlane(ws.y);
         uint32_t total = __builtin_amdgcn_readfirstlane(ws.z), next = __builtin_amdgcn_readfirstlane(ws.w);
+        // the second launch of exact re-treeing (sphere-only variants): units are slices of the redo queues
+        const bool list_mode = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) && LDS_SCENE && KARG(P, list_mode) != 0u;
         if (next >= total) {
             uint32_t unit = 0;
             if (lane == 0) {
                 unit = atomicAdd(KARG(P, counter), 1u);
-                atomicAdd(KARG(P, launch_units) + (blockDim.x == 1024u ? 0 : 1), 1u);      // (once per 2 048 samples or more)
+                // (once per 2 048 samples or more; the dual launch's self-check counts the first launch's units only)
+                if (!list_mode) atomicAdd(KARG(P, launch_units) + (blockDim.x == 1024u ? 0 : 1), 1u);
             }
             unit = __builtin_amdgcn_readfirstlane(unit);
+            if (list_mode) {
+                const uint32_t cap = KARG(P, redo_region_cap);
+                if (unit >= REDO_REGIONS * KARG(P, redo_plan)[0]) { need = false; break; }
+                flush_tile_sums(tile_sum, KARG(P, accum), txy, lane, C.width, C.height);      // (nothing after the first unit)
+                const uint32_t region = unit % REDO_REGIONS, first = (unit / REDO_REGIONS) * REDO_UNIT;
+                uint32_t cnt = KARG(P, redo_count)[region * REDO_COUNT_STRIDE];
+                cnt = __builtin_amdgcn_readfirstlane(cnt < cap ? cnt : cap);
+                txy = 0xFFFFFFFEu;                              // no tile: every sample goes to the frame's sums directly
+                s0 = region * cap + first;                      // (here: the unit's first queue entry)
+                next = 0u; total = first < cnt ? (cnt - first < REDO_UNIT ? cnt - first : REDO_UNIT) : 0u;
+                if (lane == 0) { wstate[WS_TXY] = txy; wstate[WS_S0] = s0; wstate[WS_TOTAL] = total; wstate[WS_NEXT] = 0u; }
+                if (total == 0u) continue;                      // an empty slice: the next unit
+            } else {
             const uint32_t n_chunks = KARG(P, n_chunks);
             if (unit >= KARG(P, n_local_tiles) * n_chunks) {                      // the launch's units are all handed out:
                 need = false;                                                     // these lanes idle until the wave's last path ends
@@ -389,11 +446,16 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &
             txy = ((tile % tiles_x) * TILE) | (((tile / tiles_x) * TILE) << 16);
             next = 0u; total = 64u * (s1 - s0);
             if (lane == 0) { wstate[WS_TXY] = txy; wstate[WS_S0] = s0; wstate[WS_TOTAL] = total; }
+            }
         }
         uint32_t k = next + (uint32_t)__popcll(need_mask & ((1ull << lane) - 1ull));
         if (need && k < total) {
             uint32_t q = k & 63u, smp = s0 + (k >> 6);
             uint32_t px = (txy & 0xFFFFu) + (q & 7u), py = (txy >> 16) + (q >> 3);
+            if (list_mode) {
+                const uint2 e = KARG(P, redo_list)[(size_t)s0 + k];
+                px = e.x & 0xFFFFu; py = e.x >> 16; smp = e.y;
+            }
             if (px < C.width && py < C.height) {   // slots outside the image (edge tiles) are skipped: the lane asks again
                 cold[CF_XY * 64 + lane] = __uint_as_float(px | (py << 16));
                 cold[CF_SAMPLE * 64 + lane] = __uint_as_float(smp);
@@ -418,7 +480,7 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &
 // traversal state inside the box and primitive loops as soon as anything in the kernel changed: C3 moved between 330 and 520
 // Msamples/s with the spill placement).  Only what shading reads of the traversal state crosses, by value.
 struct ShadeIo {
-    uint32_t flags;            // in: 1 is_shade, 2 active, 4 need;   out: 2 active, 4 need, 8 fresh, 16 touched
+    uint32_t flags;            // in: 1 is_shade, 2 active, 4 need;   out: 2 active, 4 need, 8 fresh, 16 touched, 32 rearm (same ray again)
     float T; uint32_t best_prim; int32_t best_inst; float best_aux;
     V3 o, d; float time;       // in: the segment's ray (world ray when the scene has no instances); out: the new ray of fresh lanes
     uint32_t cost_t0;
@@ -442,15 +504,15 @@ __device__ __attribute__((noinline)) ShadeIo shade_refill_call(ShadeIo io, uint3
     __builtin_memset(&L, 0, sizeof(L));     // (the intrinsic: HIP's device memset() is a loop, which keeps a Lane this large in scratch)
     L.T = io.T; L.best_prim = io.best_prim; L.best_inst = io.best_inst; L.best_aux = io.best_aux;
     L.o = io.o; L.d = io.d; L.time = io.time;
-    bool active = (io.flags & 2u) != 0u, need = (io.flags & 4u) != 0u, fresh = false, touched = false;
+    bool active = (io.flags & 2u) != 0u, need = (io.flags & 4u) != 0u, fresh = false, touched = false, rearm = false;
     uint32_t cost_t0 = io.cost_t0;
     PhaseClocks clk;
-    shade_refill_body<F, LDS_SCENE, false, COST>(L, (io.flags & 1u) != 0u, active, need, fresh, touched, cost_t0, P, cold, tile_sum,
+    shade_refill_body<F, LDS_SCENE, false, COST>(L, (io.flags & 1u) != 0u, active, need, fresh, touched, rearm, cost_t0, P, cold, tile_sum,
         wstate, lane, lds_items, clk);
     // fresh lanes: L.wo / L.wd hold the NEW ray, which is what the world-ray slots want
     if (active && touched) cold_store_path<F>(cold, lane, L);
     ShadeIo out = io;
-    out.flags = (active ? 2u : 0u) | (need ? 4u : 0u) | (fresh ? 8u : 0u) | (touched ? 16u : 0u);
+    out.flags = (active ? 2u : 0u) | (need ? 4u : 0u) | (fresh ? 8u : 0u) | (touched ? 16u : 0u) | (rearm ? 32u : 0u);
     out.o = L.wo; out.d = L.wd; out.time = L.time; out.cost_t0 = cost_t0;
     return out;
 }
@@ -658,23 +720,25 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 io.o = L.o; io.d = L.d; io.time = L.time; io.cost_t0 = cost_t0;
                 io = shade_refill_call<F, LDS_SCENE, COST>(io, lds_items, wave_block);
                 active = (io.flags & 2u) != 0u; need = (io.flags & 4u) != 0u; fresh = (io.flags & 8u) != 0u;
+                const bool rearm = (io.flags & 32u) != 0u;      // exact re-treeing: the same ray again, on the tree as handed over
                 cost_t0 = io.cost_t0;
-                if (fresh) {
+                if (fresh | rearm) {
                     KArgsC P = kargs_fresh();
                     DScene S = KARG(P, S);
                     // (the callee stored the path state, new world ray included)
-                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, io.o, io.d, io.time);
+                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, io.o, io.d, io.time, rearm);
                 }
             } else {
                 PhaseClocks clk;
-                shade_refill_body<F, LDS_SCENE, STATS, COST>(L, is_shade, active, need, fresh, touched, cost_t0, kargs_fresh(), cold,
+                bool rearm = false;
+                shade_refill_body<F, LDS_SCENE, STATS, COST>(L, is_shade, active, need, fresh, touched, rearm, cost_t0, kargs_fresh(), cold,
                     tile_sum, wstate, lane, lds_items, clk);
                 if (STATS) { st_t_mat += clk.mat; st_t_refill += clk.refill; st_t1 = clock64(); }
-                if (fresh) {
+                if (fresh | rearm) {
                     KArgsC P = kargs_fresh();
                     DScene S = KARG(P, S);
                     // one copy of the exact reciprocals for both kinds of new ray
-                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, L.wo, L.wd, L.time);
+                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, L.wo, L.wd, L.time, rearm);
                 }
                 if (active && touched) cold_store_path<F>(cold, lane, L);
                 if (STATS) st_t_install += clock64() - st_t1;
@@ -701,6 +765,18 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             atomicAdd(&ps[13], st_t_mat); atomicAdd(&ps[14], st_t_refill); atomicAdd(&ps[15], st_t_install);
         }
     }
+}
+
+// Between the two launches of exact re-treeing: plan[0] = slices of REDO_UNIT entries in the fullest queue (the second launch's units
+// are REDO_REGIONS x that), plan[1] = samples queued (vk_stats), plan[2] = entries that did not fit their queue (must be 0).
+__global__ void redo_plan_kernel(const uint32_t *count, uint32_t cap, uint32_t *plan) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= REDO_REGIONS) return;
+    const uint32_t c = count[r * REDO_COUNT_STRIDE];
+    const uint32_t kept = c < cap ? c : cap;
+    atomicMax(&plan[0], (kept + REDO_UNIT - 1u) / REDO_UNIT);
+    atomicAdd(&plan[1], kept);
+    if (c > cap) atomicAdd(&plan[2], c - cap);
 }
 
 // ---- heavy-first tile order (bucket sort of the probe's per-tile times, dearest first).

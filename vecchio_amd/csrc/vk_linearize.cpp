@@ -28,7 +28,31 @@ DScene LinearScene::host_view() const {
     s.tie_base_rect = tie_base_rect; s.tie_base_box = tie_base_box; s.tie_base_list = tie_base_list;
     s.n_noise_spheres = n_noise_spheres;
     for (int k = 0; k < 4; k++) { s.noise_sphere[k] = noise_sphere[k]; s.noise_tex[k] = noise_tex[k]; s.noise_perlin[k] = noise_perlin[k]; }
+    s.ref_items = ref_items.empty() ? nullptr : ref_items.data(); s.n_ref_items = (uint32_t)ref_items.size();
+    s.t_pad = ref_items.empty() ? 0.0f : t_pad;
+    s.gate_scale = 1.0f / (1.0f + s.t_pad);
+    s.tmin_gate = s.t_pad > 0.0f ? 0.001f * s.gate_scale * 0.999999f : 0.001f;     // (T_MIN of vk_trace.h)
     return s;
+}
+
+std::vector<DItem> LinearScene::combined_items(uint32_t &walk_start) const {
+    const uint32_t n_ref = (uint32_t)ref_items.size(), n_new = (uint32_t)items.size(), total = n_ref + 1u + n_new;
+    std::vector<DItem> out;
+    out.reserve(total);
+    for (DItem it : ref_items) {                      // the tree as handed over: its exits lead past everything
+        if ((it.w0 >> 28) == 0u && it.w0 >= n_ref) it.w0 = total;
+        out.push_back(it);
+    }
+    DItem stop; memset(&stop, 0, sizeof(stop));       // after its last leaf: an inner item no ray passes (an x slab at +infinity)
+    stop.mnx = INFINITY; stop.mxx = INFINITY; stop.mny = -3.0e38f; stop.mxy = 3.0e38f; stop.mnz = -3.0e38f; stop.mxz = 3.0e38f;
+    stop.w0 = total; stop.w1 = 0;
+    out.push_back(stop);
+    walk_start = n_ref + 1u;
+    for (DItem it : items) {                          // the rebuilt tree, moved up
+        if ((it.w0 >> 28) == 0u) it.w0 += walk_start;
+        out.push_back(it);
+    }
+    return out;
 }
 
 namespace {
@@ -246,6 +270,7 @@ struct Builder {
     static constexpr uint32_t RETREE_MIN = 16;     // objects: below this the reference's tree is kept as it is
     std::vector<int32_t> simple_count;      // per vk_bvh_node: number of object slots if the subtree is draw-free, -1 if not, -2 unknown
     uint32_t n_blocks = 0;
+    bool world_rebuilt = false;             // the block is the whole world tree
 
     static bool retree_kind(uint32_t k) { return k == VK_KIND_SPHERE || k == VK_KIND_RECT || k == VK_KIND_LIST; }
 
@@ -279,7 +304,8 @@ struct Builder {
         return true;
     }
 
-    struct RtObj { float mn[3], mx[3], c[3]; uint32_t dref; };
+    struct RtObj { float mn[3], mx[3], c[3]; uint32_t dref; uint32_t dref2 = 0; uint32_t parent = 0xFFFFFFFFu; uint32_t rank = 0, rank2 = 0; };
+    bool retree_units = false;              // LinearizeOptions::retree == 2 (see rt_collect)
     static float rt_half_area(const float *mn, const float *mx) {
         float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
         return dx * dy + dy * dz + dz * dx;
@@ -324,33 +350,63 @@ struct Builder {
         return true;
     }
 
-    // objects of the subtree in the REFERENCE's visiting order (pre-order, left first)
+    // objects of the subtree in the REFERENCE's visiting order (pre-order, left first).
+    // UNIT mode (retree_units): what is collected is not the single object but the reference's GATE for it: BVHNode::hit tests an
+    // object child iff the node's own box passes (accel.rs:58-72), and — boxes of a BVHNode::new tree being nested — iff the boxes of
+    // all its ancestors pass as well (a box that contains another passes whenever the inner one does: fl(b - o) / d is monotone in b,
+    // and tmax only shrinks).  So a unit = {the node's box as handed over, its one or two object children in the reference's order},
+    // and ANY tree of nested boxes over the units tests an object under the same condition as the reference: its unit's box against
+    // the closest hit so far.  Checked here: every box of the subtree lies inside its parent's and is regular (finite, min <= max);
+    // otherwise the reference's tree is kept.
     bool rt_collect(uint32_t root, uint32_t flip0, int32_t inst, std::vector<RtObj> &out, bool &ok) {
-        struct Fr { vk_ref ref; uint32_t flip; };
+        struct Fr { vk_ref ref; uint32_t flip; uint32_t parent; };
         std::vector<Fr> st;
-        st.push_back(Fr{VK_MAKE_REF(VK_KIND_BVH, root), flip0});
+        st.push_back(Fr{VK_MAKE_REF(VK_KIND_BVH, root), flip0, 0xFFFFFFFFu});
         ok = true;
         std::unordered_map<uint32_t, uint32_t> in_block;
+        uint32_t rank = 0;
         while (!st.empty()) {
             Fr fr = st.back(); st.pop_back();
             if (VK_REF_KIND(fr.ref) != VK_KIND_BVH) in_block[fr.ref & ~VK_REF_FLIP]++;
             if (VK_REF_KIND(fr.ref) == VK_KIND_BVH) {
-                const vk_bvh_node &n = d->bvh[VK_REF_INDEX(fr.ref)];
+                const uint32_t ni = VK_REF_INDEX(fr.ref);
+                const vk_bvh_node &n = d->bvh[ni];
+                if (retree_units) {
+                    for (int a = 0; a < 3; a++) {
+                        if (!(n.bb_min[a] <= n.bb_max[a]) || !std::isfinite(n.bb_min[a]) || !std::isfinite(n.bb_max[a])) { ok = false; return true; }
+                        if (fr.parent != 0xFFFFFFFFu) {
+                            const vk_bvh_node &pn = d->bvh[fr.parent];
+                            if (!(pn.bb_min[a] <= n.bb_min[a] && n.bb_max[a] <= pn.bb_max[a])) { ok = false; return true; }
+                        }
+                    }
+                }
                 // len == 1: the same object twice, the second test is a no-op
                 bool dup = n.left == n.right && VK_REF_KIND(n.left) != VK_KIND_BVH;
                 if (!dup) st.push_back(Fr{n.right, fr.flip ^ ((VK_REF_KIND(n.right) == VK_KIND_BVH && (n.right & VK_REF_FLIP))
-                    ? DREF_FLIP : 0u)});
-                st.push_back(Fr{n.left, fr.flip ^ ((VK_REF_KIND(n.left) == VK_KIND_BVH && (n.left & VK_REF_FLIP)) ? DREF_FLIP : 0u)});
+                    ? DREF_FLIP : 0u), ni});
+                st.push_back(Fr{n.left, fr.flip ^ ((VK_REF_KIND(n.left) == VK_KIND_BVH && (n.left & VK_REF_FLIP)) ? DREF_FLIP : 0u), ni});
                 continue;
             }
             RtObj o;
+            if (retree_units && VK_REF_KIND(fr.ref) != VK_KIND_SPHERE) { ok = false; return true; }      // exact re-treeing: spheres only
             if (!rt_bounds(fr.ref, o.mn, o.mx)) { ok = false; return status == VK_OK; }
+            if (retree_units) {
+                const vk_bvh_node &pn = d->bvh[fr.parent];
+                memcpy(o.mn, pn.bb_min, 12); memcpy(o.mx, pn.bb_max, 12);
+            }
             for (int a = 0; a < 3; a++) {
                 // NaN / inverted box: keep the reference's tree
                 if (!(o.mn[a] <= o.mx[a]) || !std::isfinite(o.mn[a]) || !std::isfinite(o.mx[a])) { ok = false; return true; }
                 o.c[a] = 0.5f * o.mn[a] + 0.5f * o.mx[a];
             }
-            if (!convert_object(fr.ref, fr.flip, inst, o.dref)) return false;
+            uint32_t dref;
+            if (!convert_object(fr.ref, fr.flip, inst, dref)) return false;
+            // the second object child of the same node (they are visited back to back): same unit
+            if (retree_units && !out.empty() && out.back().parent == fr.parent && out.back().dref2 == 0u) {
+                out.back().dref2 = dref; out.back().rank2 = rank++;
+                continue;
+            }
+            o.dref = dref; o.parent = fr.parent; o.rank = rank++;
             out.push_back(o);
         }
         for (const auto &kv : in_block)      // a shared object with an occurrence outside this block: see node_refs
@@ -374,7 +430,14 @@ struct Builder {
                 memcpy(mn, objs[fr.begin].mn, 12); memcpy(mx, objs[fr.begin].mx, 12);
                 for (size_t i = fr.begin + 1; i < fr.end; i++) rt_grow(mn, mx, objs[i].mn, objs[i].mx);
                 it.mnx = mn[0]; it.mny = mn[1]; it.mnz = mn[2]; it.mxx = mx[0]; it.mxy = mx[1]; it.mxz = mx[2];
-                if (len <= 2) {
+                if (retree_units && len == 1) {          // one unit per leaf: the reference's box, its objects in the reference's order
+                    it.w0 = objs[fr.begin].dref; it.w1 = objs[fr.begin].dref2;
+                    L.items.push_back(it);
+                    L.n_prims += it.w1 ? 2u : 1u;
+                    st.pop_back();
+                    continue;
+                }
+                if (!retree_units && len <= 2) {
                     size_t a = fr.begin, b = fr.begin + 1;
                     // the larger object first: its hit's t culls more of what follows in this fixed-order walk
                     if (len == 2 && rt_half_area(objs[b].mn, objs[b].mx) > rt_half_area(objs[a].mn, objs[a].mx)) std::swap(a, b);
@@ -488,13 +551,15 @@ struct Builder {
         if (node_refs.empty()) count_node_refs();
         if (simple_count.empty() || simple_count[root] == -2) { if (!classify(root)) return false; }
         if (simple_count[root] < (int32_t)RETREE_MIN || n_blocks >= 4095u) return true;
+        // exact re-treeing is for the world tree as a whole (the second render pass walks the whole tree as handed over)
+        if (retree_units && !(inst < 0 && VK_REF_KIND(d->world) == VK_KIND_BVH && root == VK_REF_INDEX(d->world))) { retree = false; return true; }
         const size_t items0 = L.items.size(), boxes0 = L.boxes.size(), lists0 = L.lists.size(), refs0 = L.list_refs.size();
         const uint32_t prims0 = L.n_prims, feat0 = L.features;
         std::vector<RtObj> objs;
         objs.reserve((size_t)simple_count[root]);
         bool ok = true;
         if (!rt_collect(root, flip, inst, objs, ok)) return false;
-        if (!ok || objs.size() < RETREE_MIN || objs.size() >= (1u << 20)) {
+        if (!ok || objs.size() < RETREE_MIN || objs.size() >= (1u << 20) || (!objs.empty() && (objs.back().rank | objs.back().rank2) >= (1u << 20))) {
             // keep the reference's tree for this subtree: undo what collecting converted (memo entries past the old sizes)
             L.items.resize(items0); L.boxes.resize(boxes0); L.lists.resize(lists0); L.list_refs.resize(refs0); L.n_prims = prims0;
             L.features = feat0;
@@ -510,12 +575,17 @@ struct Builder {
         // Rect it reaches, else with the FIRST object it reached (see tie_replaces in vk_trace.h), so a Rect is ranked by its last
         // occurrence and everything else by its first.
         for (size_t i = 0; i < objs.size(); i++) {
-            uint32_t id = tie_id(objs[i].dref);
-            bool first = (L.tie_rank[id] >> 20) != n_blocks;
-            if (first || VKD_KIND(objs[i].dref) == DK_RECT) L.tie_rank[id] = (n_blocks << 20) | (uint32_t)i;
+            for (int k = 0; k < 2; k++) {
+                const uint32_t dr = k ? objs[i].dref2 : objs[i].dref;
+                if (k && !dr) continue;
+                uint32_t id = tie_id(dr);
+                bool first = (L.tie_rank[id] >> 20) != n_blocks;
+                if (first || VKD_KIND(dr) == DK_RECT) L.tie_rank[id] = (n_blocks << 20) | (k ? objs[i].rank2 : objs[i].rank);
+            }
         }
         rt_emit(objs, 0, objs.size(), 0);
         done = true;
+        if (inst < 0 && VK_REF_KIND(d->world) == VK_KIND_BVH && root == VK_REF_INDEX(d->world)) world_rebuilt = true;
         return true;
     }
 
@@ -730,9 +800,31 @@ struct Builder {
 
 int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, const LinearizeOptions &opt) {
     Builder b(desc, out, err);
-    b.retree = opt.retree >= 0 ? opt.retree != 0 : (desc && (desc->flags & VK_SCENE_FAST_ACCEL) != 0);
+    int mode = opt.retree;
+    if (mode < 0) mode = !desc ? 0 : ((desc->flags & VK_SCENE_FAST_ACCEL) ? 1 : ((desc->flags & VK_SCENE_REFERENCE_TREE) ? 0 : 2));
+    b.retree = mode != 0;
+    b.retree_units = mode == 2;
     if (!b.run()) return b.status == VK_OK ? VK_ERR_BAD_ARG : b.status;
     out.world_items = b.world_items;
+    if (b.retree_units && b.n_blocks != 0 && !(b.n_blocks == 1 && b.world_rebuilt && out.features == 0u && out.instances.empty() &&
+        out.spheres.size() < (1u << 26))) {
+        // (cannot happen for a world of spheres only; never leave a unit-mode tree without its second pass)
+        out = LinearScene();
+        LinearizeOptions o0; o0.retree = 0;
+        return linearize(desc, out, err, o0);
+    }
+    if (b.retree_units && b.n_blocks == 1) {
+        // exact mode: the tree as handed over rides along (same conversion order, hence the same sphere indices)
+        LinearScene ref; std::string e2;
+        LinearizeOptions o2; o2.retree = 0;
+        int st = linearize(desc, ref, e2, o2);
+        if (st != VK_OK) { err = e2; return st; }
+        if (ref.spheres.size() != out.spheres.size() || memcmp(ref.spheres.data(), out.spheres.data(), ref.spheres.size() * sizeof(DSphere)) != 0 ||
+            ref.sphere_mat != out.sphere_mat) { err = "exact re-tree: the two linearisations number the spheres differently"; return VK_ERR_UNSUPPORTED; }
+        out.ref_items = ref.items;
+        out.t_pad = 1.0f / 256.0f;
+        if (const char *e = getenv("VK_T_PAD")) out.t_pad = (float)atof(e);
+    }
     return VK_OK;
 }
 

@@ -34,16 +34,24 @@ struct LinearScene {
     // in a rebuilt subtree) and its position in the reference's visiting order inside the block (bits 19..0)
     std::vector<uint32_t> tie_rank;
     uint32_t tie_base_rect = 0, tie_base_box = 0, tie_base_list = 0;
+    std::vector<DItem> ref_items; float t_pad = 0.0f;      // see DScene
     uint32_t features = 0;
     uint32_t n_prims = 0;
     uint32_t world_items = 0;   // items[0, world_items) is the world BVH; instance child ranges follow
 
     DScene host_view() const;   // DScene whose pointers address these vectors
+    // exact re-treeing, for a scene traversed from global memory: [ref_items | sentinel | items] in one array (see DScene::walk_start)
+    std::vector<DItem> combined_items(uint32_t &walk_start) const;
 };
 
 struct LinearizeOptions {
-    // rebuild draw-free subtrees with the SAH builder (vk_linearize.cpp): -1 = as vk_scene_desc.flags & VK_SCENE_FAST_ACCEL says
-    // (default off: the reference's tree everywhere), 0 / 1 = force (diagnostic switch VK_RETREE)
+    // What may be rebuilt (vk_linearize.cpp; diagnostic switch VK_RETREE):
+    //   0  nothing: the tree as handed over, everywhere
+    //   1  every draw-free subtree, object by object (VK_SCENE_FAST_ACCEL: results may differ where a hit lies a rounding error
+    //      outside its box)
+    //   2  EXACT re-treeing: the world tree of a scene of spheres only, over the reference's leaf units, with the tree as handed
+    //      over riding along for the samples that need it (vk_trace.h accept_exact): results are the reference's
+    //  -1  as vk_scene_desc.flags says: VK_SCENE_FAST_ACCEL -> 1, VK_SCENE_REFERENCE_TREE -> 0, else 2
     int retree = -1;
 };
 

@@ -96,8 +96,10 @@ VK_HD float nextafter_up(float t) { return (t > 0.0f && t < INFINITY) ? vk::bits
 // only the sphere-only variants have to spare, and its margin carries a term in |o/d| (cancellation when b*(1/d) ~ o/d).
 template <uint32_t F, class Mem> constexpr bool fused_box() { return (F & ~(uint32_t)VKF_INTEG_PDF) == 0u && Mem::FUSED_BOX; }
 
+// gate_scale: 1, or DScene::gate_scale = 1 / (1 + t_pad) under exact re-treeing (see exact re-treeing below): the box test then runs
+// on distances scaled by it, i.e. it compares the boxes with the closest hit so far times (1 + t_pad)
 template <bool FUSED = false>
-VK_HD void set_space(Lane &L, V3 o, V3 d) {
+VK_HD void set_space(Lane &L, V3 o, V3 d, float gate_scale = 1.0f) {
     L.o = o; L.d = d;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(VK_EXACT_INV)
     // v_rcp_f32 (1 ulp) instead of three correctly rounded divisions (~36 instructions per new ray and per instance entered or
@@ -110,6 +112,7 @@ VK_HD void set_space(Lane &L, V3 o, V3 d) {
 #else
     L.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 #endif
+    L.inv = L.inv * gate_scale;          // (times 1.0f is exact)
     L.a = length2(d);
     float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
     if (FUSED) {
@@ -322,11 +325,13 @@ VK_HD bool slab_exact(const DItem &n, V3 o, V3 d, float tmin, float tmax) {
     return true;
 }
 // ------------------------------------------------------------------ traversal
+// redo (exact re-treeing of a scene traversed from global memory, DScene::walk_start != 0): this lane walks the tree as handed over,
+// items[0, walk_start - 1), on unscaled distances
 template <uint32_t ISHIFT = 0, bool FUSED = false>
-VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time) {
+VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time, bool redo = false) {
     L.wo = o; L.wd = d; L.time = time;
-    set_space<FUSED>(L, o, d);
-    L.i = 0; L.end = S.n_world_items << ISHIFT; L.pend = 0; L.pend2 = 0; L.cur_inst = -1;
+    set_space<FUSED>(L, o, d, redo ? 1.0f : S.gate_scale);
+    L.i = redo ? 0u : (S.walk_start << ISHIFT); L.end = S.n_world_items << ISHIFT; L.pend = 0; L.pend2 = 0; L.cur_inst = -1;
     L.T = INFINITY; L.best_prim = 0; L.best_inst = -1; L.best_aux = 0.0f;
     // A ray with a NaN (or infinite) direction or origin hits EVERY box — f32::min/max drop the NaN quotients, accel.rs:21-31 —
     // and no sphere: Sphere::hit's discriminant is NaN (hittable.rs:66-70).  The reference walks its whole tree for such a ray
@@ -356,14 +361,16 @@ VK_HD uint32_t tie_entry(const DScene &S, uint32_t ref) {
     return (k == DK_SPHERE || k == DK_RECT || k == DK_BOX || k == DK_LIST) ? S.tie_rank[id] : 0u;
 }
 // x was just hit at exactly L.T, the t of the current best w: does x replace it?
+template <bool EXACT_CAPABLE = false>       // true: the sphere-only variants, whose best_prim may carry DREF_EARLY
 VK_HD bool tie_replaces(const Lane &L, const DScene &S, uint32_t x) {
     bool x_inclusive = VKD_KIND(x) == DK_RECT;
     if (!S.tie_rank || L.best_prim == 0u || L.best_inst != L.cur_inst) return x_inclusive;      // x is visited after w, as in the reference
-    uint32_t ex = tie_entry(S, x), ew = tie_entry(S, L.best_prim);
+    const uint32_t w = (EXACT_CAPABLE && S.t_pad > 0.0f) ? (L.best_prim & ~DREF_EARLY) : L.best_prim;
+    uint32_t ex = tie_entry(S, x), ew = tie_entry(S, w);
     if ((ex >> 20) == 0u || (ex >> 20) != (ew >> 20)) return x_inclusive;                      // not both in one rebuilt block: ditto
     if (ex == ew) return false;                                                                // the same object again
     if (ex > ew) return x_inclusive;                                                           // the reference reaches x after w
-    return VKD_KIND(L.best_prim) != DK_RECT;                                                   // ... w after x: w replaced x only if Rect
+    return VKD_KIND(w) != DK_RECT;                                                             // ... w after x: w replaced x only if Rect
 }
 
 // ConstantMedium::hit, hittable.rs:453-493 (draws ONE number inside traversal)
@@ -501,6 +508,50 @@ VK_HD bool prim_is_heavy(uint32_t ref) {
     return ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE) ? (ref - ((uint32_t)DK_LIST << 28) < (3u << 28)) : (VKD_KIND(ref) >= DK_LIST);
 }
 
+// ------------------------------------------------------------------ exact re-treeing (DScene::t_pad > 0; scenes of spheres only)
+// items[] is then a tree REBUILT over the reference's leaf units (vk_linearize.cpp rt_collect): every object is gated by the box the
+// reference gates it with, and boxes are nested, so the closest hit of a segment does not depend on the tree or on the visiting order —
+// except through objects whose computed hit distance is not behind their unit's computed box entry (rounding: a far, tiny or grazing
+// sphere).  Such an "early" object is accepted only by a walk that reaches its unit while the closest hit so far is still beyond
+// that entry, which depends on the order.  Two measures make the rebuilt walk agree with the reference's all the same:
+//  * the gate is padded: boxes are tested against T * (1 + t_pad) — by scaling the lane's reciprocals once per ray (set_space), not
+//    by a multiplication per step — so that this walk tests every unit in which the reference's walk can have accepted an early
+//    object (one that precedes its box entry by less than t_pad, relatively);
+//  * a segment whose WINNER is early (DREF_EARLY, set by accept_exact) is not trusted: the sample is dropped and queued, and a second
+//    launch renders the queued samples on the tree as handed over (vk_kernels.h), whose answer is the reference's by construction.
+// A winner that is not early is the closest of all gated objects in any order: every walk tests its unit (T >= t* > entry) and
+// accepts it.  tests/test_retree.py compares per sample with the oracle on the handed-over tree.
+template <uint32_t F>
+VK_HD float gate_of(const Lane &L, const DScene &S) {
+    return ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && S.t_pad > 0.0f && L.i >= S.walk_start) ? L.T * (1.0f + S.t_pad) : L.T;
+}
+VK_HD bool winner_is_early(const Lane &L, const DScene &S) { return S.t_pad > 0.0f && (L.best_prim & DREF_EARLY) != 0u; }
+
+// accept() under exact re-treeing.  The lane has just left the leaf item of this object's unit: its cursor is one past it.  Early =
+// not (t > entry distance of the unit's box), decided on the scaled fast-path quantities with the box test's own margin on the
+// side of "early" (a false positive costs one sample rendered twice).
+template <uint32_t F, class Mem>
+VK_HD void accept_exact(Lane &L, const DScene &S, const Mem &M, float t, uint32_t prim) {
+    uint32_t early = 0u;
+    if (S.t_pad > 0.0f && L.i > (S.walk_start << Mem::ISHIFT)) {      // (t_pad: wave-uniform; not a lane on the tree as handed over)
+        DItem n = M.item(L.i - (1u << Mem::ISHIFT));
+        float x0, x1, y0, y1, z0, z1;
+        if constexpr (fused_box<F, Mem>()) {
+            x0 = __builtin_fmaf(n.mnx, L.inv.x, -L.oi.x); x1 = __builtin_fmaf(n.mxx, L.inv.x, -L.oi.x);
+            y0 = __builtin_fmaf(n.mny, L.inv.y, -L.oi.y); y1 = __builtin_fmaf(n.mxy, L.inv.y, -L.oi.y);
+            z0 = __builtin_fmaf(n.mnz, L.inv.z, -L.oi.z); z1 = __builtin_fmaf(n.mxz, L.inv.z, -L.oi.z);
+        } else {
+            x0 = (n.mnx - L.o.x) * L.inv.x; x1 = (n.mxx - L.o.x) * L.inv.x;
+            y0 = (n.mny - L.o.y) * L.inv.y; y1 = (n.mxy - L.o.y) * L.inv.y;
+            z0 = (n.mnz - L.o.z) * L.inv.z; z1 = (n.mxz - L.o.z) * L.inv.z;
+        }
+        const float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));      // entry into the box (scaled; < 0: origin inside)
+        const bool behind = t * S.gate_scale > __builtin_fmaf(fabsf(lo), 4.0e-6f, lo) + L.xnan;   // false for NaN margins: early
+        early = behind ? 0u : DREF_EARLY;
+    }
+    L.T = t; L.best_prim = prim | early; L.best_inst = L.cur_inst; L.best_aux = 0.0f;
+}
+
 // One box step of a lane that HAS box work and is inside its range (pend == 0, i < end).
 // The wave runs it under the EXEC mask of exactly those lanes (box_steps below): a lane that queues
 // objects or reaches the end of its range drops out of the mask and costs nothing more, and the
@@ -517,8 +568,13 @@ VK_HD float min_with_tmax(float a, float t) {
 }
 
 template <uint32_t F, class Mem>
-VK_HD bool box_step_core(Lane &L, const Mem &M) {      // returns: a leaf's box was hit (objects queued in pend)
+VK_HD bool box_step_core(Lane &L, const DScene &S, const Mem &M) {      // returns: a leaf's box was hit (objects queued in pend)
     DItem n = M.item(L.i);
+    // sphere-only variants: tmin on the scale the lane's reciprocals are on (exact re-treeing, below; T_MIN itself otherwise)
+    float tmin = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? S.tmin_gate : T_MIN;
+    if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && Mem::ISHIFT == 0u) {
+        if (S.walk_start != 0u) tmin = L.i < S.walk_start ? T_MIN : tmin;      // a lane on the tree as handed over: the reference's own test
+    }
     // AxisBB::hit decided from reciprocal multiplies; same boolean as the reference's (see slab_exact):
     // both forms compute fl(b-o) identically and q~ = fl(fl(b-o)*fl(1/d)) differs from the reference's
     // fl(fl(b-o)/d) by < 3*2^-24 relative; the three per-axis early-outs equal one test
@@ -536,7 +592,7 @@ VK_HD bool box_step_core(Lane &L, const Mem &M) {      // returns: a leaf's box 
         y0 = (n.mny - L.o.y) * L.inv.y; y1 = (n.mxy - L.o.y) * L.inv.y;
         z0 = (n.mnz - L.o.z) * L.inv.z; z1 = (n.mxz - L.o.z) * L.inv.z;
     }
-    float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), T_MIN));   // >= T_MIN > 0, never NaN
+    float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));    // >= tmin > 0, never NaN
     float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), min_with_tmax(fmaxf(z0, z1), L.T));    // <= T, never NaN
     // lo >= T_MIN > 0, so with e = 3*2^-24 the sign of the exact (hi - lo) equals the sign of this one whenever
     // |hi - lo| > 2e*hi/(1-e) ~ 3.6e-7*hi (also for hi <= 0: a certain miss).  The test below asks for 2e-6*hi,
@@ -551,11 +607,11 @@ VK_HD bool box_step_core(Lane &L, const Mem &M) {      // returns: a leaf's box 
     // (The empty asm keeps the compiler from folding the two tests back into one region.)
     if (__builtin_amdgcn_fcmpf(fabsf(dlt), margin, 12 /* unordered or less than: !(a >= b) */) != 0ull) {
         asm volatile("");
-        if (!(fabsf(dlt) >= margin)) h = slab_exact(n, L.o, L.d, T_MIN, L.T);
+        if (!(fabsf(dlt) >= margin)) h = slab_exact(n, L.o, L.d, T_MIN, gate_of<F>(L, S));
     }
 #else
     if (!(fabsf(dlt) >= margin))
-        h = slab_exact(n, L.o, L.d, T_MIN, L.T);         // within rounding distance: the reference's divisions
+        h = slab_exact(n, L.o, L.d, T_MIN, gate_of<F>(L, S));         // within rounding distance: the reference's divisions
 #endif
     bool inner = (n.w0 >> 28) == 0u;
     bool leaf_hit = h && !inner;
@@ -573,7 +629,7 @@ VK_HD uint32_t range_end(const Lane &L, const DScene &S) { return (F & VKF_INSTA
 template <uint32_t F, class Mem, int N>
 VK_HD void box_steps(Lane &L, const DScene &S, const Mem &M, bool go) {
     if (go) {
-        bool queued = box_step_core<F, Mem>(L, M);      // (the mask is at hand: cheaper than comparing pend with 0 again)
+        bool queued = box_step_core<F, Mem>(L, S, M);   // (the mask is at hand: cheaper than comparing pend with 0 again)
         // (&: one mask, one branch)
         if (N > 1) box_steps<F, Mem, (N > 1 ? N - 1 : 1)>(L, S, M, (!queued) & (L.i < range_end<F, Mem>(L, S)));
     }
@@ -586,7 +642,7 @@ VK_HD void box_step(Lane &L, const DScene &S, const Mem &M, bool on) {
     if (F & VKF_INSTANCE) {
         if (on && at_end) { if (L.cur_inst >= 0) leave_instance<F, Mem>(L, S); return; }   // rare
     }
-    if (on && !at_end) box_step_core<F, Mem>(L, M);
+    if (on && !at_end) box_step_core<F, Mem>(L, S, M);
 }
 
 template <uint32_t F, class Mem>
@@ -602,11 +658,11 @@ VK_HD void prim_step(Lane &L, const DScene &S, const Mem &M) {
         DSphere sb = M.sphere(VKD_INDEX(ref2 ? ref2 : ref));
         float t; bool tie;
         if (sphere_t_tie(sa.cx, sa.cy, sa.cz, sa.r, L.o, L.d, L.a, T_MIN, L.T, t, tie)) {
-            if (!tie || tie_replaces(L, S, ref)) accept<F, Mem>(L, t, ref, 0.0f);
+            if (!tie || tie_replaces<true>(L, S, ref)) accept_exact<F, Mem>(L, S, M, t, ref);
         }
         if (ref2) {
             if (sphere_t_tie(sb.cx, sb.cy, sb.cz, sb.r, L.o, L.d, L.a, T_MIN, L.T, t, tie)) {
-                if (!tie || tie_replaces(L, S, ref2)) accept<F, Mem>(L, t, ref2, 0.0f);
+                if (!tie || tie_replaces<true>(L, S, ref2)) accept_exact<F, Mem>(L, S, M, t, ref2);
             }
         }
         return;

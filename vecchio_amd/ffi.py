@@ -26,6 +26,7 @@ VK_INTEGRATOR_PDF, VK_INTEGRATOR_SCATTER = 0, 1
 VK_BACKGROUND_SOLID, VK_BACKGROUND_SKY = 0, 1
 VK_OUTPUT_F32, VK_OUTPUT_RGB8 = 0, 1
 VK_SCENE_FAST_ACCEL = 1
+VK_SCENE_REFERENCE_TREE = 2
 
 
 def make_ref(kind, index, flip=False):
@@ -184,7 +185,7 @@ def load_host_lib():
 DEVICE_SYMBOLS = [
     "vk_abi_version", "vk_device_count", "vk_last_error", "vk_scene_create", "vk_scene_destroy",
     "vk_render", "vk_render_device", "vk_to_color_device", "vk_scene_get_info", "vk_scene_create_multi",
-    "vk_scene_last_kernel_ms", "vk_scene_last_clamped_samples",
+    "vk_scene_last_kernel_ms", "vk_scene_last_clamped_samples", "vk_scene_last_requeued_samples",
 ]
 
 
@@ -219,6 +220,8 @@ def load_device_lib():
     lib.vk_scene_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.vk_scene_last_clamped_samples.restype = C.c_int
     lib.vk_scene_last_clamped_samples.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.vk_scene_last_requeued_samples.restype = C.c_int
+    lib.vk_scene_last_requeued_samples.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.vk_render.restype = C.c_int
     lib.vk_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
     lib.vk_render_device.restype = C.c_int
