@@ -59,14 +59,18 @@ static void trace_one(const DScene &S, const GlobalMem &M0, const RenderConsts &
     Mem M; static_cast<GlobalMem &>(M) = M0;
     Lane L;
     start_sample<F, Mem>(L, S, C, pixel % C.width, pixel / C.width, sample);
+    bool on_ref = false;      // the segment just walked was walked on the tree as handed over
     for (;;) {
         while (traversing(L)) { traverse_step<F, Mem>(L, S, M); if (steps) (*steps)++; }
-        if (S.walk_start != 0u && winner_is_early(L, S)) {      // exact re-treeing, both trees in items[] (the device's global-memory
+        const bool early = !on_ref && winner_is_early<F, Mem>(L, S, M);
+        on_ref = false;
+        if (S.walk_start != 0u && early) {                      // exact re-treeing, both trees in items[] (the device's global-memory
             g_redo++;                                           // scenes): this segment again, on the tree as handed over
             begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, L.o, L.d, L.time, true);
+            on_ref = true;
             continue;
         }
-        if (winner_is_early(L, S)) {       // exact re-treeing: the whole sample again on the tree as handed over (the device's LDS scenes)
+        if (early) {                       // exact re-treeing: the whole sample again on the tree as handed over (the device's LDS scenes)
             DScene Sr = reference_view(S);
             GlobalMem Mr = M0; Mr.items = Sr.items;
             g_redo++;

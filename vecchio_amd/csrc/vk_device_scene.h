@@ -29,7 +29,6 @@ enum : uint32_t {
 };
 constexpr uint32_t DREF_FLIP = 0x08000000u;
 constexpr uint32_t DREF_INDEX = 0x07FFFFFFu;
-constexpr uint32_t DREF_EARLY = 0x04000000u;   // in Lane::best_prim under exact re-treeing (scenes of < 2^26 spheres): see vk_trace.h accept_exact
 #define VKD_KIND(r) ((r) >> 28)
 #define VKD_INDEX(r) ((r) & 0x07FFFFFFu)
 #define VKD_MAKE(kind, idx) (((uint32_t)(kind) << 28) | ((uint32_t)(idx) & 0x07FFFFFFu))

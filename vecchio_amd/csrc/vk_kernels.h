@@ -200,7 +200,7 @@ template <uint32_t F>
 __device__ __forceinline__ void cold_load_path(const float *c, uint32_t lane, Lane &L) {
     L.thr = v3(c[(CF_THR + 0) * 64 + lane], c[(CF_THR + 1) * 64 + lane], c[(CF_THR + 2) * 64 + lane]);
     L.acc = v3s(0.0f);
-    L.depth = __float_as_uint(c[CF_DEPTH * 64 + lane]);
+    L.depth = __float_as_uint(c[CF_DEPTH * 64 + lane]) & 0x7FFFFFFFu;      // (bit 31: shade_refill_body's rearm mark)
     L.rng.key = (uint64_t)__float_as_uint(c[CF_KEY * 64 + lane]) | ((uint64_t)__float_as_uint(c[(CF_KEY + 1) * 64 + lane]) << 32);
     L.rng.ctr = __float_as_uint(c[CF_CTR * 64 + lane]);
     L.pixel = 0; L.sample = 0;
@@ -309,7 +309,7 @@ __device__ __forceinline__ PreTurb cooperative_turb(const Lane &L, const DScene 
 // through shade_refill_call (below) by the everything-variants.
 struct PhaseClocks { unsigned long long mat = 0, refill = 0, t1 = 0; };
 template <uint32_t F, bool LDS_SCENE, bool STATS, bool COST>
-__device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &active, bool &need, bool &fresh, bool &touched, bool &rearm,
+__device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool early, bool &active, bool &need, bool &fresh, bool &touched, bool &rearm,
                                                   uint32_t &cost_t0, KArgsC P, float *cold, unsigned long long *tile_sum,
                                                   uint32_t *wstate, uint32_t lane, uint32_t lds_items, PhaseClocks &clk) {
     using Mem = typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type;
@@ -322,19 +322,22 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &
                                   // (dead) world-ray fields L.wo / L.wd / L.time, so it costs no registers
     const PreTurb pre_turb = cooperative_turb<F, Mem>(L, S, M, is_shade, lane);
     rearm = false;
+    // `early` (exact re-treeing): the winner of this lane's segment may depend on the visiting order (vk_trace.h winner_is_early,
+    // asked by the caller, which holds the segment's reciprocals)
     if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && !LDS_SCENE) {
-        // exact re-treeing, scene in global memory (both trees in items[], DScene::walk_start): a segment won by an "early" object
-        // (vk_trace.h accept_exact) is walked again, now on the tree as handed over; the caller re-installs the same ray for that
-        if (S.walk_start != 0u && is_shade && winner_is_early(L, S)) {
+        // scene in global memory (both trees in items[], DScene::walk_start): the segment is walked again, now on the tree as handed
+        // over — the caller re-installs the same ray for that; bit 31 of the lane's depth word says so until the segment is shaded
+        if (S.walk_start != 0u && is_shade && early) {
             rearm = true; is_shade = false;
             L.wo = L.o; L.wd = L.d;      // (L.time is the segment's)
+            cold[CF_DEPTH * 64 + lane] = __uint_as_float(__float_as_uint(cold[CF_DEPTH * 64 + lane]) | 0x80000000u);
         }
     }
     if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && LDS_SCENE) {
-        // exact re-treeing, scene in LDS (the rebuilt tree only): the sample of such a segment is dropped here and rendered by the second
-        // launch on the tree as handed over.  One counter update per wave and phase, prefix sums over the dropping lanes.
+        // scene in LDS (the rebuilt tree only): the sample of such a segment is dropped here and rendered by the second launch on the
+        // tree as handed over.  One counter update per wave and phase, prefix sums over the dropping lanes.
         uint2 *rl = KARG(P, redo_list);
-        const unsigned long long m_drop = __builtin_amdgcn_ballot_w64(is_shade && rl != nullptr && winner_is_early(L, S));
+        const unsigned long long m_drop = __builtin_amdgcn_ballot_w64(is_shade && early && rl != nullptr);
         if (m_drop != 0ull) {
             const uint32_t region = (blockIdx.x + (blockDim.x == 1024u ? 0u : gridDim.x)) & (REDO_REGIONS - 1u);      // (dual launch: 0..255 | 256..511)
             uint32_t base = 0;
@@ -349,8 +352,6 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &
                 is_shade = false; active = false; need = true;
             }
         }
-        // (the probe launch shades such a segment like any other; lanes still traversing keep their flag)
-        if (S.t_pad > 0.0f && is_shade) L.best_prim &= ~DREF_EARLY;
     }
     touched = is_shade;
     if (is_shade) {
@@ -480,7 +481,7 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool &
 // traversal state inside the box and primitive loops as soon as anything in the kernel changed: C3 moved between 330 and 520
 // Msamples/s with the spill placement).  Only what shading reads of the traversal state crosses, by value.
 struct ShadeIo {
-    uint32_t flags;            // in: 1 is_shade, 2 active, 4 need;   out: 2 active, 4 need, 8 fresh, 16 touched, 32 rearm (same ray again)
+    uint32_t flags;            // in: 1 is_shade, 2 active, 4 need, 64 early (winner_is_early);   out: 2 active, 4 need, 8 fresh, 16 touched, 32 rearm (same ray again)
     float T; uint32_t best_prim; int32_t best_inst; float best_aux;
     V3 o, d; float time;       // in: the segment's ray (world ray when the scene has no instances); out: the new ray of fresh lanes
     uint32_t cost_t0;
@@ -507,7 +508,7 @@ __device__ __attribute__((noinline)) ShadeIo shade_refill_call(ShadeIo io, uint3
     bool active = (io.flags & 2u) != 0u, need = (io.flags & 4u) != 0u, fresh = false, touched = false, rearm = false;
     uint32_t cost_t0 = io.cost_t0;
     PhaseClocks clk;
-    shade_refill_body<F, LDS_SCENE, false, COST>(L, (io.flags & 1u) != 0u, active, need, fresh, touched, rearm, cost_t0, P, cold, tile_sum,
+    shade_refill_body<F, LDS_SCENE, false, COST>(L, (io.flags & 1u) != 0u, (io.flags & 64u) != 0u, active, need, fresh, touched, rearm, cost_t0, P, cold, tile_sum,
         wstate, lane, lds_items, clk);
     // fresh lanes: L.wo / L.wd hold the NEW ray, which is what the world-ray slots want
     if (active && touched) cold_store_path<F>(cold, lane, L);
@@ -713,9 +714,20 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             constexpr bool SPLIT = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE || MINW == 8) && !STATS;
             const bool is_shade = __builtin_amdgcn_inverse_ballot_w64(m_shade);
             bool touched = false, fresh = false;
+            bool early = false;       // exact re-treeing: this segment's winner may depend on the visiting order
+            if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) {
+                KArgsC P = kargs_fresh();
+                DScene S = KARG(P, S);
+                if (S.t_pad > 0.0f) {      // (wave-uniform)
+                    Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
+                    bool on_ref = false;   // the lane has just walked the tree as handed over: its answer stands
+                    if constexpr (!LDS_SCENE) on_ref = (__float_as_uint(cold[CF_DEPTH * 64 + lane]) >> 31) != 0u;
+                    if (is_shade && !on_ref) early = winner_is_early<F, Mem>(L, S, M);
+                }
+            }
             if constexpr (SPLIT) {
                 ShadeIo io;
-                io.flags = (is_shade ? 1u : 0u) | (active ? 2u : 0u) | (need ? 4u : 0u);
+                io.flags = (is_shade ? 1u : 0u) | (active ? 2u : 0u) | (need ? 4u : 0u) | (early ? 64u : 0u);
                 io.T = L.T; io.best_prim = L.best_prim; io.best_inst = L.best_inst; io.best_aux = L.best_aux;
                 io.o = L.o; io.d = L.d; io.time = L.time; io.cost_t0 = cost_t0;
                 io = shade_refill_call<F, LDS_SCENE, COST>(io, lds_items, wave_block);
@@ -731,7 +743,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             } else {
                 PhaseClocks clk;
                 bool rearm = false;
-                shade_refill_body<F, LDS_SCENE, STATS, COST>(L, is_shade, active, need, fresh, touched, rearm, cost_t0, kargs_fresh(), cold,
+                shade_refill_body<F, LDS_SCENE, STATS, COST>(L, is_shade, early, active, need, fresh, touched, rearm, cost_t0, kargs_fresh(), cold,
                     tile_sum, wstate, lane, lds_items, clk);
                 if (STATS) { st_t_mat += clk.mat; st_t_refill += clk.refill; st_t1 = clock64(); }
                 if (fresh | rearm) {

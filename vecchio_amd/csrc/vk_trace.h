@@ -361,11 +361,10 @@ VK_HD uint32_t tie_entry(const DScene &S, uint32_t ref) {
     return (k == DK_SPHERE || k == DK_RECT || k == DK_BOX || k == DK_LIST) ? S.tie_rank[id] : 0u;
 }
 // x was just hit at exactly L.T, the t of the current best w: does x replace it?
-template <bool EXACT_CAPABLE = false>       // true: the sphere-only variants, whose best_prim may carry DREF_EARLY
 VK_HD bool tie_replaces(const Lane &L, const DScene &S, uint32_t x) {
     bool x_inclusive = VKD_KIND(x) == DK_RECT;
     if (!S.tie_rank || L.best_prim == 0u || L.best_inst != L.cur_inst) return x_inclusive;      // x is visited after w, as in the reference
-    const uint32_t w = (EXACT_CAPABLE && S.t_pad > 0.0f) ? (L.best_prim & ~DREF_EARLY) : L.best_prim;
+    const uint32_t w = L.best_prim;
     uint32_t ex = tie_entry(S, x), ew = tie_entry(S, w);
     if ((ex >> 20) == 0u || (ex >> 20) != (ew >> 20)) return x_inclusive;                      // not both in one rebuilt block: ditto
     if (ex == ew) return false;                                                                // the same object again
@@ -517,39 +516,38 @@ VK_HD bool prim_is_heavy(uint32_t ref) {
 //  * the gate is padded: boxes are tested against T * (1 + t_pad) — by scaling the lane's reciprocals once per ray (set_space), not
 //    by a multiplication per step — so that this walk tests every unit in which the reference's walk can have accepted an early
 //    object (one that precedes its box entry by less than t_pad, relatively);
-//  * a segment whose WINNER is early (DREF_EARLY, set by accept_exact) is not trusted: the sample is dropped and queued, and a second
-//    launch renders the queued samples on the tree as handed over (vk_kernels.h), whose answer is the reference's by construction.
+//  * a segment whose WINNER is early (winner_is_early, asked once when the segment's walk has ended) is not trusted: the tree as
+//    handed over decides — for that segment, walked again in place, where items[] holds both trees (DScene::walk_start, scenes in global
+//    memory), or for the whole sample, dropped and rendered by a second launch (vk_kernels.h, scenes staged in LDS).
 // A winner that is not early is the closest of all gated objects in any order: every walk tests its unit (T >= t* > entry) and
 // accepts it.  tests/test_retree.py compares per sample with the oracle on the handed-over tree.
 template <uint32_t F>
 VK_HD float gate_of(const Lane &L, const DScene &S) {
     return ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && S.t_pad > 0.0f && L.i >= S.walk_start) ? L.T * (1.0f + S.t_pad) : L.T;
 }
-VK_HD bool winner_is_early(const Lane &L, const DScene &S) { return S.t_pad > 0.0f && (L.best_prim & DREF_EARLY) != 0u; }
-
-// accept() under exact re-treeing.  The lane has just left the leaf item of this object's unit: its cursor is one past it.  Early =
-// not (t > entry distance of the unit's box), decided on the scaled fast-path quantities with the box test's own margin on the
-// side of "early" (a false positive costs one sample rendered twice).
+// Is the segment's winner early?  Asked of a lane whose reciprocals are the scaled ones (not of one on the tree as handed over).
+// The test uses the sphere's OWN box (center -+ radius, as Sphere::bounding_box computes it, hittable.rs:97-102) instead of its unit's:
+// the unit's box contains it, so its entry is no later, and "not behind the own box's entry" holds whenever "not behind the unit's"
+// does.  Decided on the scaled fast-path quantities with the box test's own margin on the side of "early": a false positive costs one
+// walk (or one sample) done twice.  A negative radius (an inverted own box) counts as early.
 template <uint32_t F, class Mem>
-VK_HD void accept_exact(Lane &L, const DScene &S, const Mem &M, float t, uint32_t prim) {
-    uint32_t early = 0u;
-    if (S.t_pad > 0.0f && L.i > (S.walk_start << Mem::ISHIFT)) {      // (t_pad: wave-uniform; not a lane on the tree as handed over)
-        DItem n = M.item(L.i - (1u << Mem::ISHIFT));
-        float x0, x1, y0, y1, z0, z1;
-        if constexpr (fused_box<F, Mem>()) {
-            x0 = __builtin_fmaf(n.mnx, L.inv.x, -L.oi.x); x1 = __builtin_fmaf(n.mxx, L.inv.x, -L.oi.x);
-            y0 = __builtin_fmaf(n.mny, L.inv.y, -L.oi.y); y1 = __builtin_fmaf(n.mxy, L.inv.y, -L.oi.y);
-            z0 = __builtin_fmaf(n.mnz, L.inv.z, -L.oi.z); z1 = __builtin_fmaf(n.mxz, L.inv.z, -L.oi.z);
-        } else {
-            x0 = (n.mnx - L.o.x) * L.inv.x; x1 = (n.mxx - L.o.x) * L.inv.x;
-            y0 = (n.mny - L.o.y) * L.inv.y; y1 = (n.mxy - L.o.y) * L.inv.y;
-            z0 = (n.mnz - L.o.z) * L.inv.z; z1 = (n.mxz - L.o.z) * L.inv.z;
-        }
-        const float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));      // entry into the box (scaled; < 0: origin inside)
-        const bool behind = t * S.gate_scale > __builtin_fmaf(fabsf(lo), 4.0e-6f, lo) + L.xnan;   // false for NaN margins: early
-        early = behind ? 0u : DREF_EARLY;
+VK_HD bool winner_is_early(const Lane &L, const DScene &S, const Mem &M) {
+    if (!(S.t_pad > 0.0f) || L.best_prim == 0u) return false;
+    const DSphere sp = M.sphere(VKD_INDEX(L.best_prim));
+    const float bx0 = sp.cx - sp.r, bx1 = sp.cx + sp.r, by0 = sp.cy - sp.r, by1 = sp.cy + sp.r, bz0 = sp.cz - sp.r, bz1 = sp.cz + sp.r;
+    float x0, x1, y0, y1, z0, z1;
+    if constexpr (fused_box<F, Mem>()) {
+        x0 = __builtin_fmaf(bx0, L.inv.x, -L.oi.x); x1 = __builtin_fmaf(bx1, L.inv.x, -L.oi.x);
+        y0 = __builtin_fmaf(by0, L.inv.y, -L.oi.y); y1 = __builtin_fmaf(by1, L.inv.y, -L.oi.y);
+        z0 = __builtin_fmaf(bz0, L.inv.z, -L.oi.z); z1 = __builtin_fmaf(bz1, L.inv.z, -L.oi.z);
+    } else {
+        x0 = (bx0 - L.o.x) * L.inv.x; x1 = (bx1 - L.o.x) * L.inv.x;
+        y0 = (by0 - L.o.y) * L.inv.y; y1 = (by1 - L.o.y) * L.inv.y;
+        z0 = (bz0 - L.o.z) * L.inv.z; z1 = (bz1 - L.o.z) * L.inv.z;
     }
-    L.T = t; L.best_prim = prim | early; L.best_inst = L.cur_inst; L.best_aux = 0.0f;
+    const float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));      // entry into the own box (scaled; < 0: origin inside)
+    const bool behind = L.T * S.gate_scale > __builtin_fmaf(fabsf(lo), 4.0e-6f, lo) + L.xnan;   // false for NaN margins: early
+    return !behind || !(sp.r > 0.0f);
 }
 
 // One box step of a lane that HAS box work and is inside its range (pend == 0, i < end).
@@ -658,11 +656,11 @@ VK_HD void prim_step(Lane &L, const DScene &S, const Mem &M) {
         DSphere sb = M.sphere(VKD_INDEX(ref2 ? ref2 : ref));
         float t; bool tie;
         if (sphere_t_tie(sa.cx, sa.cy, sa.cz, sa.r, L.o, L.d, L.a, T_MIN, L.T, t, tie)) {
-            if (!tie || tie_replaces<true>(L, S, ref)) accept_exact<F, Mem>(L, S, M, t, ref);
+            if (!tie || tie_replaces(L, S, ref)) accept<F, Mem>(L, t, ref, 0.0f);
         }
         if (ref2) {
             if (sphere_t_tie(sb.cx, sb.cy, sb.cz, sb.r, L.o, L.d, L.a, T_MIN, L.T, t, tie)) {
-                if (!tie || tie_replaces<true>(L, S, ref2)) accept_exact<F, Mem>(L, S, M, t, ref2);
+                if (!tie || tie_replaces(L, S, ref2)) accept<F, Mem>(L, t, ref2, 0.0f);
             }
         }
         return;
