@@ -1,0 +1,97 @@
+"""-m gpu: exact re-treeing (vk_trace.h winner_is_early; include/vecchio_amd.h vk_scene_desc.flags) through the C ABI.  A scene of spheres
+only is rendered on a tree rebuilt over the reference's leaf units (accel.rs:98-136 builds the units, accel.rs:58-83 gates each object
+by its unit's box); the tree as handed over decides wherever the winner of a segment could depend on the visiting order.  The image
+must be the handed-over tree's bit for bit: pixel sums are order independent, so it is unless some SAMPLE took another path."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from vecchio_amd import DeviceScene, HostScene, ffi
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def render(name, w, spp, flags, tile=None):
+    hs = HostScene(name, 1)
+    hs.desc.contents.flags = flags
+    cam = hs.next_camera()
+    kw = {} if tile is None else dict(tile_rank=tile[0], tile_world=tile[1])
+    p = hs.params(w, spp, 50, seed=3, **kw)
+    ds = DeviceScene(hs.desc)
+    img, st = ds.render(cam, p)
+    rq = C.c_uint64(0)
+    assert ffi.load_device_lib().vk_scene_last_requeued_samples(ds._h, C.byref(rq)) == 0
+    info = ds.info()
+    ds.close(); hs.close()
+    return img, st, rq.value, info
+
+
+@pytest.mark.parametrize("name,w,spp,in_lds", [("random_spheres_iow", 640, 96, True), ("stress_spheres:150", 512, 12, False),
+                                               ("stress_spheres:30", 384, 24, False)])
+def test_exact_retree_image_is_the_handed_over_trees(name, w, spp, in_lds, device):
+    ref, st_r, rq_r, info_r = render(name, w, spp, ffi.VK_SCENE_REFERENCE_TREE)
+    img, st, rq, info = render(name, w, spp, 0)
+    assert rq_r == 0
+    assert bool(st.scene_in_lds) == in_lds
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), int((img != ref).any(axis=2).sum())
+    if in_lds:
+        # scenes staged in LDS: the samples the rebuilt tree cannot vouch for go through a second launch
+        assert 0 < rq < 0.01 * st.samples, (rq, st.samples)
+    else:
+        assert rq == 0          # both trees in one array: such segments are walked again in place
+    # a tile partition of the frame: the second launch covers this rank's samples only
+    part, st_p, rq_p, _ = render(name, w, spp, 0, tile=(1, 3))
+    tiles_x = (w + 7) // 8
+    yy, xx = np.mgrid[0:ref.shape[0], 0:w]
+    mine = ((yy // 8) * tiles_x + xx // 8) % 3 == 1
+    assert np.array_equal(part[mine].view(np.uint32), ref[mine].view(np.uint32))
+    assert rq_p <= rq
+
+
+def test_a_full_redo_queue_never_yields_an_incomplete_frame(device):
+    """VK_REDO_REGION_CAP=1 (a test switch) leaves one entry per queue between the two launches: samples that do not fit would be
+    missing from the frame.  vk_scene_last_requeued_samples reports it (VK_ERR_OOM), and vk_render renders the frame again on the tree
+    as handed over instead of returning it."""
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from vecchio_amd import DeviceScene, HostScene, ffi\n"
+            "def frame(flags):\n"
+            "    hs = HostScene('random_spheres_iow', 1); hs.desc.contents.flags = flags; cam = hs.next_camera(); ds = DeviceScene(hs.desc)\n"
+            "    return ds.render(cam, hs.params(640, 96, 50))[0]\n"
+            "print('EQUAL', np.array_equal(frame(0).view(np.uint32), frame(ffi.VK_SCENE_REFERENCE_TREE).view(np.uint32)))\n") % ROOT
+    env = dict(os.environ, VK_REDO_REGION_CAP="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "EQUAL True" in r.stdout, r.stdout + r.stderr
+
+
+def test_scene_with_mostly_early_winners_falls_back_to_the_handed_over_tree(device):
+    """A small field on a ground sphere of radius 1e5, seen from above: most primary hits land on the ground, whose f32 quadratic is
+    off by more than the depth of the ground below its box's top — "early" winners everywhere.  The frame is still exact (every such
+    sample goes through the second launch), and the library then stops rebuilding for this scene (stderr says so)."""
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from vecchio_amd import DeviceScene, HostScene, ffi\n"
+            "lib = ffi.load_device_lib()\n"
+            "def frames(flags):\n"
+            "    hs = HostScene('stress_spheres:12', 1); hs.desc.contents.flags = flags; cam = hs.next_camera(); ds = DeviceScene(hs.desc)\n"
+            "    out = []\n"
+            "    for k in range(2):\n"
+            "        img, st = ds.render(cam, hs.params(512, 8, 50, seed=4))\n"
+            "        rq = C.c_uint64(0); assert lib.vk_scene_last_requeued_samples(ds._h, C.byref(rq)) == 0\n"
+            "        out.append((img, rq.value, st.samples, st.scene_in_lds))\n"
+            "    return out\n"
+            "ref = frames(ffi.VK_SCENE_REFERENCE_TREE); x = frames(0)\n"
+            "print('LDS', x[0][3], 'REQUEUED', x[0][1], x[1][1], 'OF', x[0][2])\n"
+            "print('EQUAL', all(np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) for a, b in zip(ref, x)))\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "EQUAL True" in r.stdout, r.stdout + r.stderr
+    words = r.stdout.split()
+    first, second, total = int(words[words.index("REQUEUED") + 1]), int(words[words.index("REQUEUED") + 2]), int(words[words.index("OF") + 1])
+    assert words[words.index("LDS") + 1] == "1"
+    assert second == 0, r.stdout          # (the first frame either went through the second launch or, its queues full, was rendered again)
+    assert "renders on the tree as handed over from now on" in r.stderr, r.stderr

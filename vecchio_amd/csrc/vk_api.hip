@@ -85,7 +85,8 @@ struct EnvSwitches {
     bool order_reuse = true;           // VK_ORDER_REUSE=0: probe the tile costs in every frame of a partition
     bool dual_same_stream = false;     // VK_DUAL_SAME_STREAM=1 (tests): see launch_dual
     bool dual_debug = false;           // VK_DUAL_DEBUG=1: print each checked frame's unit split
-    int retree = -1;                   // VK_RETREE=0/1: force the SAH rebuild of draw-free subtrees off / on (default: vk_scene_desc.flags)
+    int retree = -1;                   // VK_RETREE=0/1/2: nothing rebuilt / every draw-free subtree / exact re-treeing (default: vk_scene_desc.flags)
+    int redo_region_cap = 0;           // VK_REDO_REGION_CAP=n (tests): entries per queue between the two launches of exact re-treeing
     static int int_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
     static EnvSwitches read() {
         EnvSwitches v;
@@ -102,6 +103,7 @@ struct EnvSwitches {
         v.probe_spp = int_env("VK_PROBE_SPP");
         v.probe_depth = int_env("VK_PROBE_DEPTH");
         v.prim_weight = int_env("VK_PRIM_WEIGHT");
+        v.redo_region_cap = int_env("VK_REDO_REGION_CAP");
         return v;
     }
 };
@@ -149,6 +151,9 @@ struct vk_scene {
     uint2 *redo_list = nullptr; size_t redo_bytes = 0;
     uint32_t *redo_count = nullptr;
     bool redo_last = false;        // the last render had a second launch
+    bool exact_off = false;        // the second launch took more than a quarter of a frame's samples: the scene renders on the tree as
+                                   // handed over from then on (vk_scene_last_requeued_samples)
+    uint64_t redo_last_samples = 0;    // samples of the partition the last render covered
     unsigned long long *phase_stats = nullptr;   // device, 16 counters (diagnostic kernel build)
     bool want_phase_stats = false;
     // heavy-first tile order: per-tile times of the probe launch and the order derived from them
@@ -398,7 +403,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     KArgs A;
     memset(&A, 0, sizeof(A));
     A.S = s->dev;
-    const bool exact = s->exact && !s->want_phase_stats;     // (the diagnostic builds render on the rebuilt tree alone)
+    const bool exact = s->exact && !s->want_phase_stats && !s->exact_off;     // (the diagnostic builds have no second launch)
     A.C.cam = *cam;
     A.C.width = p->width; A.C.height = p->height; A.C.spp = p->samples_per_pixel; A.C.max_depth = p->max_depth;
     A.C.seed = p->seed; A.C.integrator = p->integrator; A.C.background = p->background;
@@ -468,7 +473,9 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         // queues for the samples the first launch drops: an eighth of the partition's samples, spread over REDO_REGIONS (a scene of a
         // million pixel-sized spheres drops 5 %; a full queue is reported where the caller synchronises, vk_scene_last_kernel_ms)
         const uint64_t samples = partition_samples(p, g);
-        const uint64_t per_region = samples / 8u / REDO_REGIONS + 4096u;
+        s->redo_last_samples = samples;
+        uint64_t per_region = samples / 8u / REDO_REGIONS + 4096u;
+        if (s->env.redo_region_cap >= 1) per_region = (uint64_t)s->env.redo_region_cap;      // tests
         if (per_region * REDO_REGIONS >= 0xFFFFFFFFull) return fail(VK_ERR_UNSUPPORTED, "frame too large for the redo queues of exact re-treeing (VK_EXACT_RETREE=0 renders it on the tree handed over)");
         int rc = ensure(s->redo_list, s->redo_bytes, (size_t)per_region * REDO_REGIONS * sizeof(uint2));
         if (rc != VK_OK) return rc;
@@ -980,13 +987,14 @@ int vk_scene_last_requeued_samples(vk_scene *s, uint64_t *out) {
     if (!s->last_timed) return fail(VK_ERR_BAD_ARG, "no render enqueued yet");
     *out = 0;
     if (!s->parts.empty()) {
-        for (vk_scene *q : s->parts) {
+        int worst = VK_OK;
+        for (vk_scene *q : s->parts) {       // (every part is asked: each one switches itself off after an overflow)
             uint64_t v = 0;
             int rc = vk_scene_last_requeued_samples(q, &v);
-            if (rc != VK_OK) return rc;
+            if (rc != VK_OK) worst = rc;
             *out += v;
         }
-        return VK_OK;
+        return worst;
     }
     if (!s->redo_last) return VK_OK;
     HIP_TRY(hipSetDevice(s->device));
@@ -994,9 +1002,22 @@ int vk_scene_last_requeued_samples(vk_scene *s, uint64_t *out) {
     uint32_t plan[3] = {0, 0, 0};
     HIP_TRY(hipMemcpy(plan, s->redo_count + REDO_REGIONS * REDO_COUNT_STRIDE, sizeof(plan), hipMemcpyDeviceToHost));
     *out = plan[1];
+    if (!s->exact_off && (uint64_t)plan[1] * 4u > s->redo_last_samples && s->redo_last_samples >= (1u << 20)) {
+        // (e.g. a field of spheres on a ground sphere of radius 1e5 seen from above: most hits on the ground are "early")
+        s->exact_off = true;
+        fprintf(stderr, "vecchio_amd: exact re-treeing sent %u of %llu samples through the second launch; this scene renders on the tree "
+            "as handed over from now on\n", plan[1], (unsigned long long)s->redo_last_samples);
+    }
+    if (plan[2] != 0u) s->exact_off = true;      // (later frames render on the tree as handed over; vk_render repeats this one)
     if (plan[2] != 0u) return fail(VK_ERR_OOM, "exact re-treeing: " + std::to_string(plan[2]) + " samples did not fit the redo queues, the frame is "
         "incomplete (VK_RETREE=0 or VK_SCENE_REFERENCE_TREE renders on the tree handed over)");
     return VK_OK;
+}
+
+// did the last frame's redo queues overflow and has every part been switched off exact re-treeing since?
+static bool redo_overflow_handled(const vk_scene *s) {
+    if (!s->parts.empty()) { bool any = false; for (const vk_scene *q : s->parts) any |= q->exact_off; return any; }
+    return s->exact_off;
 }
 
 static int render_host(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, void *out_host, vk_stats *stats_out,
@@ -1015,17 +1036,24 @@ static int render_host(vk_scene *scene, const vk_camera *cam, const vk_render_pa
     else { rc = ensure(scene->fb, scene->fb_bytes, bytes); d_img = scene->fb; }
     if (rc != VK_OK) return rc;
     vk_stats st;
-    memset(&st, 0, sizeof(st));
-    rc = enqueue_render(scene, cam, params, d_img, nullptr, debug_out != nullptr, &st);
-    if (rc != VK_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(nullptr));
     double ms = 0.0;
+    for (int attempt = 0; ; attempt++) {
+        memset(&st, 0, sizeof(st));
+        rc = enqueue_render(scene, cam, params, d_img, nullptr, debug_out != nullptr, &st);
+        if (rc != VK_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        uint64_t requeued = 0;
+        rc = vk_scene_last_requeued_samples(scene, &requeued);
+        // exact re-treeing's queues overflowed: the scene has just been switched to the tree as handed over, render the frame again
+        if (rc == VK_ERR_OOM && attempt == 0 && redo_overflow_handled(scene)) continue;
+        if (rc != VK_OK) return rc;
+        break;
+    }
     rc = vk_scene_last_kernel_ms(scene, &ms);
     if (rc != VK_OK) return rc;
     st.kernel_ms = ms;
     rc = vk_scene_last_clamped_samples(scene, &st.clamped_samples);
     if (rc != VK_OK) return rc;
-    { uint64_t requeued = 0; rc = vk_scene_last_requeued_samples(scene, &requeued); if (rc != VK_OK) return rc; }
     HIP_TRY(hipSetDevice(scene->device));
     uint32_t world = params->tile_world ? params->tile_world : 1;
     if (world == 1) {
