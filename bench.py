@@ -19,8 +19,9 @@ Also reported in the same JSON line:
                rocprofv3 PMC pass of this command, 2 cycles each on a SIMD-32, 1024 SIMDs x 2.4 GHz)
   cpu_baseline the oracle (restated CPU path, "port") timed on this box's host cores on a bounded sample of the
                same workload (N = 1 only)
-  config.also  one step each of the other BASELINE configs at full size (C4, C3, C5) and of C2 with VK_SCENE_FAST_ACCEL,
-               each verified the same way (N = 1 only; --no-also skips them)
+  config.also  one step each of the other BASELINE configs at full size (C4, C3, C5), of C2 and C5 on the tree handed over alone
+               (VK_SCENE_REFERENCE_TREE: no exact re-treeing) and of C2 with VK_SCENE_FAST_ACCEL, each verified the same way
+               (N = 1 only; --no-also skips them)
 """
 import argparse
 import ctypes as C
@@ -84,7 +85,9 @@ def physical_bounds(c, samples, seconds, scene_in_lds, issue):
     out = {"bound": "valu_issue", "unit": "wave-instr/s", "achieved": None, "peak": VALU_WAVE_INSTR_PER_S, "frac": None,
            "lane_fill": None, "useful_lane_frac": None,
            "memory": {"level": "lds" if scene_in_lds else "l2", "record_bytes_per_sample": round(rec / n, 1), "achieved_Bps": round(rate, 1),
-                      "peak_Bps": LDS_PEAK_BPS if scene_in_lds else L2_PEAK_BPS, "frac": round(rate / (LDS_PEAK_BPS if scene_in_lds else L2_PEAK_BPS), 4)}}
+                      "peak_Bps": LDS_PEAK_BPS if scene_in_lds else L2_PEAK_BPS, "frac": round(rate / (LDS_PEAK_BPS if scene_in_lds else L2_PEAK_BPS), 4),
+                      "note": "record bytes from the oracle's visit counts on the tree as handed over: an upper bound where the device walks "
+                              "a rebuilt tree (exact re-treeing of scenes of spheres only: about 0.7x the box tests on C2, 0.5x on C5)"}}
     if issue:
         out.update(achieved=issue["achieved_wave_instr_per_s"], frac=issue["frac"], lane_fill=issue["lane_fill"],
                    useful_lane_frac=round(issue["frac"] * issue["lane_fill"], 4), counters=issue.get("note"))
@@ -225,6 +228,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run check of the timed framebuffer against the oracle")
     ap.add_argument("--no-also", action="store_true", help="skip the single steps of the other BASELINE configs")
+    ap.add_argument("--reference-tree", action="store_true", help="set VK_SCENE_REFERENCE_TREE: walk only the tree handed over (no exact "
+                    "re-treeing of scenes of spheres only)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not measure the HBM traffic of a launch now (two one-step child runs under rocprofv3 --pmc); "
                          "roofline.traffic then comes from the committed profile")
@@ -278,7 +283,8 @@ def main():
     import oracle_ffi as O
     cores = usable_cpus()          # threads for the oracle: affinity mask capped by the cgroup quota
 
-    def run_workload(name, steps, warmup, spp_override=0, want_cpu=False, bvh="reference", fast_accel=False, live_traffic=False):
+    def run_workload(name, steps, warmup, spp_override=0, want_cpu=False, bvh="reference", fast_accel=False, live_traffic=False,
+                     handed_over_tree=False):
         scene_name, width, spp, depth, label = WORKLOADS[name]
         if spp_override:
             spp = spp_override
@@ -291,6 +297,12 @@ def main():
             from vecchio_amd import ffi
             hs.desc.contents.flags = ffi.VK_SCENE_FAST_ACCEL
             label += " [VK_SCENE_FAST_ACCEL: draw-free subtrees rebuilt by the library]"
+        if handed_over_tree:
+            # the default for a scene of spheres only is exact re-treeing (vk_trace.h winner_is_early); this walks the tree as built by
+            # the host mirror of BVHNode::new and nothing else
+            from vecchio_amd import ffi
+            hs.desc.contents.flags = ffi.VK_SCENE_REFERENCE_TREE
+            label += " [VK_SCENE_REFERENCE_TREE: only the tree handed over]"
         cam = hs.next_camera()
         params = hs.params(width, spp, depth, seed=2, tile_rank=rank, tile_world=world)   # render seed 2
         height = params.height
@@ -439,7 +451,7 @@ def main():
                         "issue": issue}
             physical = physical_bounds(c, local_samples, k_ms * 1e-3, bool(info.lds_bytes), issue) if k_ms else None
             res = {"value": round(value, 2), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
-                   "physical": physical, "kernel_ms": k_ms,
+                   "physical": physical, "kernel_ms": k_ms, "requeued_samples": ds.last_requeued_samples(),
                    "label": label, "integrator": "scatter" if hs.integrator else "pdf", "bvh_items": info.n_items,
                    "scene_in_lds": bool(info.lds_bytes), "verified": verified, "roofline": roof, "cpu_baseline": cpu}
         if world > 1:
@@ -465,14 +477,17 @@ def main():
         return res
 
     main_res = run_workload(args.workload, args.steps, args.warmup, args.spp, want_cpu=(n_gpus == 1 and not args.no_cpu), bvh=args.bvh,
-                            fast_accel=args.fast_accel, live_traffic=(n_gpus == 1 and world == 1 and not args.no_traffic and not rehearsal))
+                            fast_accel=args.fast_accel, live_traffic=(n_gpus == 1 and world == 1 and not args.no_traffic and not rehearsal),
+                            handed_over_tree=args.reference_tree)
     also = []
     if n_gpus == 1 and not args.no_also and args.workload == "C2" and not args.spp:
-        for name, spp_o, fa in (("C4", 0, False), ("C3", 0, False), ("C5", 0, False), ("C2", 0, True)):
-            r = run_workload(name, 1, 0, spp_o, fast_accel=fa)
+        for name, spp_o, fa, ho in (("C4", 0, False, False), ("C3", 0, False, False), ("C5", 0, False, False), ("C2", 0, False, True),
+                                    ("C5", 0, False, True), ("C2", 0, True, False)):
+            r = run_workload(name, 1, 0, spp_o, fast_accel=fa, handed_over_tree=ho)
             also.append({"workload": r["label"], "Msamples_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": 1,
                          # one step, no warm-up: `Msamples_per_s` includes the variant's first-use costs (code-object load, buffer
                          # allocation); the kernel-time rate does not and is the one comparable with the headline
+                         "requeued_samples": r["requeued_samples"],
                          "kernel_ms": r["kernel_ms"], "kernel_Msamples_per_s": round(WORKLOAD_SAMPLES(name) / r["kernel_ms"] / 1e3, 2) if r["kernel_ms"] else None,
                          "physical": r["physical"],
                          "verified": r["verified"], "roofline_frac": r["roofline"]["frac"] if r["roofline"] else None,
@@ -487,7 +502,12 @@ def main():
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
             "config": {"workload": r["label"], "scene_seed": 1, "render_seed": 2,
                        "integrator": r["integrator"], "tiles": "8x8 round-robin over ranks", "multi_gpu": mode,
-                       "bvh_builder": args.bvh, "bvh_items": r["bvh_items"], "scene_in_lds": r["scene_in_lds"], "also": also},
+                       "bvh_builder": args.bvh, "bvh_items": r["bvh_items"], "scene_in_lds": r["scene_in_lds"],
+                       # scenes of spheres only are walked on a tree rebuilt over the reference's leaf units; where a segment's winner could
+                       # depend on the visiting order the tree handed over decides (vk_trace.h winner_is_early).  `requeued_samples`: the
+                       # samples of the last step that went through the second launch for that (scenes staged in LDS)
+                       "tree": "handed over" if args.reference_tree else ("VK_SCENE_FAST_ACCEL" if args.fast_accel else "exact re-treeing (default)"),
+                       "requeued_samples": r["requeued_samples"], "also": also},
             "verified": r["verified"], "roofline": r["roofline"], "physical": r["physical"], "cpu_baseline": r["cpu_baseline"],
         }
         if r.get("distributed"):

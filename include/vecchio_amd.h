@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 3
+#define VK_ABI_VERSION 4   /* 4: exact re-treeing by default (vk_scene_desc.flags), VK_SCENE_REFERENCE_TREE, vk_scene_last_requeued_samples */
 
 /* ---- status codes (reference convention is panic!/unwrap, main.rs:166,202) ---------- */
 enum {
@@ -174,10 +174,16 @@ typedef struct vk_scene_desc {
     uint32_t n_perlins;        const vk_perlin *perlins;
     vk_ref world;              /* main.rs:168 world_bvh */
     uint32_t n_lights;         const vk_ref *lights;  /* main.rs:169 config.lights */
-    uint32_t flags;            /* VK_SCENE_* (ABI 2); 0 = traverse exactly the tree handed over */
+    uint32_t flags;            /* VK_SCENE_* (ABI 2); 0 = results of the tree handed over (see below) */
 } vk_scene_desc;
 
 /* vk_scene_desc.flags.
+ * 0 (default): every result is the one BVHNode::hit (accel.rs:58-83) gives on the tree handed over.  The library walks that tree,
+ * with one exception: a world of spheres only is walked on a tree REBUILT over the reference's leaf units (every object stays gated by
+ * its parent node's box, exactly as handed over), and every segment whose closest hit could depend on the visiting order — a hit
+ * computed to lie before its box entry — is decided on the tree as handed over (walked again, or its sample rendered by a second
+ * launch): "exact re-treeing", DESIGN.md §5.  Frames are bit-identical to VK_SCENE_REFERENCE_TREE's.
+ * VK_SCENE_REFERENCE_TREE: walk the tree handed over and nothing else (no exact re-treeing).
  * VK_SCENE_FAST_ACCEL: the library may rebuild the acceleration structure over subtrees whose objects are all
  * Sphere / Rect / Boxy / lists of those (no ConstantMedium, no transform, no negative-radius sphere): BVHNode::hit's result
  * (accel.rs:58-83) does not depend on the tree over such objects, and exact ties in t are resolved as the reference resolves
@@ -186,7 +192,7 @@ typedef struct vk_scene_desc {
  * have — in the reference as much as here, whose own tree is random (accel.rs:99-100).  Measured: the InOneWeekend scene's full
  * 1920x1080x1024-spp frame (2.1 G samples) is bit-identical with and without the flag (+28 % throughput); on the 1 M-sphere
  * stress scene 0.19 % of the samples differ — exactly as many as between two reference-style trees over the same world
- * (profiles/r03/tree_variation.log).  Off by default: only the tree handed over matches a seeded reference run sample for sample. */
+ * (profiles/r03/tree_variation.log).  Off by default: it does not match a seeded reference run sample for sample. */
 enum { VK_SCENE_FAST_ACCEL = 1, VK_SCENE_REFERENCE_TREE = 2 };
 
 /* ---- camera: the ten fields of main.rs:57-68, computed by Camera::new on the host --- */

@@ -17,7 +17,9 @@ for f in sorted(glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv")):
         # the production build of the megakernel only (..., false, false>): not the probe (COST) launch that precedes it
         if "render_kernel" in r["Kernel_Name"] and ", true>(" not in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            out["dispatch"] = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+            # (the first dispatch of the file: a frame's first launch, not the short second launch of exact re-treeing)
+            if "dispatch" not in out:
+                out["dispatch"] = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
     for k, v in agg.items():
         # per frame: a frame may be more than one dispatch of the production kernel (the dual launch of sphere-only LDS scenes)
         out["counters_per_dispatch"][k] = sum(v) / (frames if frames else len(v))

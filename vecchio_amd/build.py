@@ -178,7 +178,8 @@ def build_emu(force=False):
     edir = os.path.join(ROOT, "tests", "emu")
     out = os.path.join(edir, "_build", "libemu.so")
     srcs = [os.path.join(edir, "emu.cpp"), os.path.join(CSRC, "vk_linearize.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("vk_trace.h", "vk_math.h", "vk_device_scene.h", "vk_linearize.h")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("vk_trace.h", "vk_math.h", "vk_device_scene.h", "vk_linearize.h")] + \
+        [os.path.join(ROOT, "include", "vecchio_amd.h")]
     if force or _newer(out, deps, CXXFLAGS):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         _run([CXX] + CXXFLAGS + ["-shared", "-o", out] + srcs + ["-lpthread"])

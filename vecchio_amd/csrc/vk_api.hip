@@ -588,8 +588,8 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     if (exact) {
         // the second launch: the queued samples on the scene as handed over, in the single-launch shape
         uint32_t *plan = s->redo_count + REDO_REGIONS * REDO_COUNT_STRIDE;
-        hipLaunchKernelGGL(redo_plan_kernel, dim3((REDO_REGIONS + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)s->redo_count,
-            A.redo_region_cap, plan);
+        hipLaunchKernelGGL(redo_plan_kernel, dim3(1), dim3(REDO_REGIONS), 0, st, (const uint32_t *)s->redo_count, A.redo_region_cap, plan,
+            (uint32_t)s->num_cus * s->wgs_per_cu * waves_per_wg);
         HIP_TRY(hipMemsetAsync(s->counter, 0, sizeof(uint32_t), st));      // the unit counter only: clamped samples and unit counts add up
         KArgs B = A;
         B.S = s->ref_view; B.list_mode = 1u; B.tile_order = nullptr;
@@ -999,7 +999,7 @@ int vk_scene_last_requeued_samples(vk_scene *s, uint64_t *out) {
     if (!s->redo_last) return VK_OK;
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipEventSynchronize(s->ev1));
-    uint32_t plan[3] = {0, 0, 0};
+    uint32_t plan[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(plan, s->redo_count + REDO_REGIONS * REDO_COUNT_STRIDE, sizeof(plan), hipMemcpyDeviceToHost));
     *out = plan[1];
     if (!s->exact_off && (uint64_t)plan[1] * 4u > s->redo_last_samples && s->redo_last_samples >= (1u << 20)) {

@@ -56,14 +56,14 @@ struct KArgs {
     // Exact re-treeing (vk_trace.h): samples dropped by the first launch (the winner of one of their segments may depend on the visiting
     // order) are queued here, REDO_REGIONS queues of redo_region_cap entries {x | y << 16, sample}, one counter per region (64 bytes
     // apart); a workgroup appends to the region of its block index.  The second launch (list_mode = 1, S = the scene as handed over)
-    // takes its units from these queues instead of from the tiles: unit u = entries [2048 k, 2048 (k + 1)) of region u % REDO_REGIONS,
-    // k = u / REDO_REGIONS, for k below the slice count redo_plan_kernel leaves in redo_plan[0].  redo_list == null: nothing is dropped
+    // takes its units from these queues instead of from the tiles: unit u = entries [n k, n (k + 1)) of region u % REDO_REGIONS,
+    // k = u / REDO_REGIONS, for k below the slice count redo_plan_kernel leaves in redo_plan[0] and n = redo_plan[3] entries per unit.  redo_list == null: nothing is dropped
     // (the probe launch, scenes without a rebuilt tree).
     uint2 *redo_list; uint32_t *redo_count; const uint32_t *redo_plan; uint32_t redo_region_cap; uint32_t list_mode;
 };
 constexpr uint32_t REDO_REGIONS = 512u;
 constexpr uint32_t REDO_COUNT_STRIDE = 16u;        // uint32 words between two regions' counters
-constexpr uint32_t REDO_UNIT = 256u;               // queue entries per work unit of the second launch (small: a short list must reach every wave)
+constexpr uint32_t REDO_UNIT = 256u;               // most queue entries per work unit of the second launch (redo_plan_kernel picks 64..this)
 
 // LDS-resident hot records
 struct LdsMem {
@@ -419,14 +419,16 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool e
             unit = __builtin_amdgcn_readfirstlane(unit);
             if (list_mode) {
                 const uint32_t cap = KARG(P, redo_region_cap);
-                if (unit >= REDO_REGIONS * KARG(P, redo_plan)[0]) { need = false; break; }
+                const uint32_t *plan = KARG(P, redo_plan);
+                const uint32_t usize = plan[3];                 // entries per unit (redo_plan_kernel)
+                if (unit >= REDO_REGIONS * plan[0]) { need = false; break; }
                 flush_tile_sums(tile_sum, KARG(P, accum), txy, lane, C.width, C.height);      // (nothing after the first unit)
-                const uint32_t region = unit % REDO_REGIONS, first = (unit / REDO_REGIONS) * REDO_UNIT;
+                const uint32_t region = unit % REDO_REGIONS, first = (unit / REDO_REGIONS) * usize;
                 uint32_t cnt = KARG(P, redo_count)[region * REDO_COUNT_STRIDE];
                 cnt = __builtin_amdgcn_readfirstlane(cnt < cap ? cnt : cap);
                 txy = 0xFFFFFFFEu;                              // no tile: every sample goes to the frame's sums directly
                 s0 = region * cap + first;                      // (here: the unit's first queue entry)
-                next = 0u; total = first < cnt ? (cnt - first < REDO_UNIT ? cnt - first : REDO_UNIT) : 0u;
+                next = 0u; total = first < cnt ? (cnt - first < usize ? cnt - first : usize) : 0u;
                 if (lane == 0) { wstate[WS_TXY] = txy; wstate[WS_S0] = s0; wstate[WS_TOTAL] = total; wstate[WS_NEXT] = 0u; }
                 if (total == 0u) continue;                      // an empty slice: the next unit
             } else {
@@ -779,16 +781,25 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
     }
 }
 
-// Between the two launches of exact re-treeing: plan[0] = slices of REDO_UNIT entries in the fullest queue (the second launch's units
-// are REDO_REGIONS x that), plan[1] = samples queued (vk_stats), plan[2] = entries that did not fit their queue (must be 0).
-__global__ void redo_plan_kernel(const uint32_t *count, uint32_t cap, uint32_t *plan) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= REDO_REGIONS) return;
-    const uint32_t c = count[r * REDO_COUNT_STRIDE];
+// Between the two launches of exact re-treeing (ONE block of REDO_REGIONS threads): plan[1] = samples queued (vk_stats), plan[2] = entries
+// that did not fit their queue (must be 0), plan[3] = entries per work unit of the second launch — 64 (one sample per lane: a short list
+// then reaches every wave and the launch lasts about as long as its longest path) up to REDO_UNIT for long lists — and plan[0] = units of
+// that size in the fullest queue (the second launch's units are REDO_REGIONS x that).
+__global__ void redo_plan_kernel(const uint32_t *count, uint32_t cap, uint32_t *plan, uint32_t n_waves) {
+    __shared__ uint32_t s_total, s_max, s_lost;
+    const uint32_t r = threadIdx.x;
+    if (r == 0) { s_total = 0; s_max = 0; s_lost = 0; }
+    __syncthreads();
+    const uint32_t c = r < REDO_REGIONS ? count[r * REDO_COUNT_STRIDE] : 0u;
     const uint32_t kept = c < cap ? c : cap;
-    atomicMax(&plan[0], (kept + REDO_UNIT - 1u) / REDO_UNIT);
-    atomicAdd(&plan[1], kept);
-    if (c > cap) atomicAdd(&plan[2], c - cap);
+    atomicAdd(&s_total, kept); atomicMax(&s_max, kept);
+    if (c > cap) atomicAdd(&s_lost, c - cap);
+    __syncthreads();
+    if (r == 0) {
+        uint32_t unit = 64u;
+        while (unit < REDO_UNIT && (uint64_t)s_total > (uint64_t)unit * n_waves * 2u) unit *= 2u;
+        plan[0] = (s_max + unit - 1u) / unit; plan[1] = s_total; plan[2] = s_lost; plan[3] = unit;
+    }
 }
 
 // ---- heavy-first tile order (bucket sort of the probe's per-tile times, dearest first).

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 ASSETS_DIR = os.path.join(os.path.dirname(_HERE), "tests", "golden", "assets")
 
-VK_ABI_VERSION = 3
+VK_ABI_VERSION = 4
 VK_OK, VK_ERR_BAD_ARG, VK_ERR_UNSUPPORTED, VK_ERR_HIP, VK_ERR_NO_DEVICE, VK_ERR_OOM = range(6)
 
 (VK_KIND_NONE, VK_KIND_BVH, VK_KIND_SPHERE, VK_KIND_MOVING_SPHERE, VK_KIND_RECT, VK_KIND_LIST,

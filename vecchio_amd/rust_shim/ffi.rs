@@ -11,7 +11,9 @@ use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
 pub type vk_ref = u32;
-pub const VK_ABI_VERSION: u32 = 3;
+pub const VK_ABI_VERSION: u32 = 4;
+pub const VK_SCENE_FAST_ACCEL: u32 = 1;
+pub const VK_SCENE_REFERENCE_TREE: u32 = 2;
 pub const VK_REF_FLIP: u32 = 0x0800_0000;
 pub const VK_KIND_BVH: u32 = 1;
 pub const VK_KIND_SPHERE: u32 = 2;
@@ -54,7 +56,7 @@ pub struct vk_scene_desc {
     pub n_perlins: u32, pub perlins: *const vk_perlin,
     pub world: vk_ref,
     pub n_lights: u32, pub lights: *const vk_ref,
-    pub flags: u32,             // VK_SCENE_FAST_ACCEL = 1: let the library rebuild draw-free subtrees (see vecchio_amd.h); 0 = exact tree
+    pub flags: u32,             // 0 = the handed-over tree's results (exact re-treeing of sphere-only worlds, see vecchio_amd.h); VK_SCENE_*
 }
 
 #[repr(C)] #[derive(Copy, Clone)]
@@ -87,6 +89,7 @@ extern "C" {
     pub fn vk_render_device(scene: *mut vk_scene, cam: *const vk_camera, params: *const vk_render_params, d_rgb: *mut c_void, stream: *mut c_void, stats: *mut vk_stats) -> c_int;
     pub fn vk_scene_last_kernel_ms(scene: *mut vk_scene, ms_out: *mut f64) -> c_int;
     pub fn vk_scene_last_clamped_samples(scene: *mut vk_scene, count_out: *mut u64) -> c_int;
+    pub fn vk_scene_last_requeued_samples(scene: *mut vk_scene, count_out: *mut u64) -> c_int;
 }
 
 /// What `flatten()` pushes into (flatten.rs).  One record per Arc; shared Arcs are de-duplicated

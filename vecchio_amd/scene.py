@@ -111,6 +111,12 @@ class DeviceScene:
         check(self._lib, self._lib.vk_scene_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def last_requeued_samples(self):
+        """Exact re-treeing: samples of the last render that went through the second launch, on the tree as handed over (waits)."""
+        n = C.c_uint64()
+        check(self._lib, self._lib.vk_scene_last_requeued_samples(self._h, C.byref(n)))
+        return n.value
+
     def to_color_device(self, d_rgb, width, height, d_rgb8, stream=None):
         check(self._lib, self._lib.vk_to_color_device(self._h, C.c_void_p(d_rgb), width, height, C.c_void_p(d_rgb8), C.c_void_p(stream or 0)))
 
