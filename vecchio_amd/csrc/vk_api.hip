@@ -577,7 +577,8 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         if (dual) {
             // seven waves per SIMD hide more of a parked lane's wait: shading deferred 5x, pending sphere tests served at 2x weight
             // (C2 at 256 spp, (defer, weight): (4,1) 6 098, (5,1) 6 166, (5,2) 6 230, (6,2) 6 208, (8,2) 6 230, (5,3) 6 071 Msamples/s)
-            if (!(s->env.shade_defer >= 1 && s->env.shade_defer <= 64)) A.shade_defer = 5u;
+            // (on the rebuilt tree of exact re-treeing, 256 spp: (4,1) 7 295, (5,2) 7 395, (6,2) 7 445, (8,2) 7 435, (6,3) 7 444)
+            if (!(s->env.shade_defer >= 1 && s->env.shade_defer <= 64)) A.shade_defer = 6u;
             if (!(s->env.prim_weight >= 1 && s->env.prim_weight <= 64)) A.prim_weight = 2u;
         }
         if (dual && F == 0u) rc = launch_dual<0u>(s, A, per_wave_lds_bytes(0u), st);

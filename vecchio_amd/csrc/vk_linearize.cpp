@@ -449,11 +449,11 @@ struct Builder {
                 }
                 fr.item = (uint32_t)L.items.size();
                 L.items.push_back(it);
-                // ---- choose the split: 16 centroid bins per axis, cost = A(left) n(left) + A(right) n(right)
+                // ---- choose the split: 32 centroid bins per axis (16: 5 % more steps on C2; 64 and a full sweep of small nodes: no fewer), cost = A(left) n(left) + A(right) n(right)
                 float cmin[3], cmax[3];
                 memcpy(cmin, objs[fr.begin].c, 12); memcpy(cmax, objs[fr.begin].c, 12);
                 for (size_t i = fr.begin + 1; i < fr.end; i++) rt_grow(cmin, cmax, objs[i].c, objs[i].c);
-                const int NB = 16;
+                const int NB = 32;
                 int best_axis = -1, best_split = 0; double best_cost = 1e300;
                 if (fr.depth < 64) {
                     for (int ax = 0; ax < 3; ax++) {
