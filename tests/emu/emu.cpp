@@ -63,6 +63,8 @@ static void trace_one(const DScene &S, const GlobalMem &M0, const RenderConsts &
     for (;;) {
         while (traversing(L)) { traverse_step<F, Mem>(L, S, M); if (steps) (*steps)++; }
         const bool early = !on_ref && winner_is_early<F, Mem>(L, S, M);
+        if (getenv("EMU_TRACE")) fprintf(stderr, "  seg depth %u o (%.9g %.9g %.9g) d (%.9g %.9g %.9g) T %.9g prim %08x early %d on_ref %d t_pad %g\n", L.depth,
+            L.o.x, L.o.y, L.o.z, L.d.x, L.d.y, L.d.z, L.T, L.best_prim, (int)early, (int)on_ref, S.t_pad);
         on_ref = false;
         if (S.walk_start != 0u && early) {                      // exact re-treeing, both trees in items[] (the device's global-memory
             g_redo++;                                           // scenes): this segment again, on the tree as handed over

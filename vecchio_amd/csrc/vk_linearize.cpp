@@ -822,7 +822,11 @@ int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, con
         if (ref.spheres.size() != out.spheres.size() || memcmp(ref.spheres.data(), out.spheres.data(), ref.spheres.size() * sizeof(DSphere)) != 0 ||
             ref.sphere_mat != out.sphere_mat) { err = "exact re-tree: the two linearisations number the spheres differently"; return VK_ERR_UNSUPPORTED; }
         out.ref_items = ref.items;
-        out.t_pad = 1.0f / 256.0f;
+        // 1/16: a computed hit point can lie outside its sphere's box (a grazing or false hit of a far sphere), and a ray nearly parallel
+        // to that face enters the box later than it "hits" by that distance over a small direction component.  1/256 lost one sample
+        // in 1.9 G that way (stress_spheres:200, a ray 0.5 degrees off a box face); the padding costs 0.8 % more steps at 1/16 (growing
+        // the unit boxes instead — by 1/32 of their smallest extent — costs 4-10 %)
+        out.t_pad = 1.0f / 16.0f;
         if (const char *e = getenv("VK_T_PAD")) out.t_pad = (float)atof(e);
     }
     return VK_OK;
