@@ -113,7 +113,7 @@ def test_retree_cuts_the_box_tests_of_the_headline_scene(emu, built):
 @pytest.mark.parametrize("variant", ["lds", "global"])
 @pytest.mark.parametrize("grid_half", [40, 130])
 def test_exact_retree_gives_the_handed_over_trees_samples_on_far_small_spheres(grid_half, variant, oracle, emu, built, monkeypatch):
-    """The default for a scene of spheres only (vk_trace.h accept_exact): a tree rebuilt over the reference's leaf units; where the
+    """The default for a scene of spheres only (vk_trace.h winner_is_early): a tree rebuilt over the reference's leaf units; where the
     winner of a segment could depend on the visiting order, the tree as handed over decides — for the whole sample (scenes the device
     stages in LDS: a second launch) or for that segment (scenes it traverses from global memory: both trees in one array).  Thousands
     of pixel-sized spheres on a ground sphere of radius 1e5 are where computed hits precede their box entries: every sample must still

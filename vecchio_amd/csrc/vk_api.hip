@@ -18,6 +18,10 @@
 //   * traversal is the stack-free threaded walk of vk_trace.h; when the linear BVH + spheres + boxes
 //     fit next to that per-wave state WITHOUT costing occupancy, every workgroup stages them into its
 //     LDS (160 KB/CU) once and item fetches are ds_read_b128; otherwise they are L1/L2 gathers;
+//   * scenes of spheres only are walked on a tree REBUILT over the reference's leaf units (vk_linearize.cpp), and the tree as handed
+//     over decides every segment whose winner could depend on the visiting order (vk_trace.h winner_is_early): walked again in place
+//     where both trees sit in one array (global-memory scenes), or the sample is queued and rendered by a second launch of the same
+//     kernel in list mode (LDS scenes: enqueue_render_f32);
 //   * no MFMA: there is no dense contraction in a path tracer.
 //
 // Host side: one vk_scene per device (scene upload, per-launch scratch); vk_scene_create_multi = a group of

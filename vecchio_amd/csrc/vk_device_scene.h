@@ -115,7 +115,7 @@ struct DScene {
     // by comparing their hit with this list instead of chasing sphere -> material -> texture): sphere index, texture, perlin table.
     // n_noise_spheres = ~0: more than fit here, look the material up.
     uint32_t n_noise_spheres; uint32_t noise_sphere[4], noise_tex[4], noise_perlin[4];
-    // Exact re-treeing (vk_linearize.cpp rt_collect, vk_trace.h accept_exact): t_pad > 0 says that items[0, n_world_items) is a tree
+    // Exact re-treeing (vk_linearize.cpp rt_collect, vk_trace.h winner_is_early): t_pad > 0 says that items[0, n_world_items) is a tree
     // REBUILT over the reference's leaf units, walked with the closest hit so far padded by (1 + t_pad); ref_items[0, n_ref_items) is
     // the tree as handed over, on which the rare sample whose result may depend on the visiting order is rendered again.
     // gate_scale = 1 / (1 + t_pad) and tmin_gate = T_MIN * gate_scale (rounded down); 1 and T_MIN when t_pad == 0.

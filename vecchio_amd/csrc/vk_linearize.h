@@ -50,7 +50,7 @@ struct LinearizeOptions {
     //   1  every draw-free subtree, object by object (VK_SCENE_FAST_ACCEL: results may differ where a hit lies a rounding error
     //      outside its box)
     //   2  EXACT re-treeing: the world tree of a scene of spheres only, over the reference's leaf units, with the tree as handed
-    //      over riding along for the samples that need it (vk_trace.h accept_exact): results are the reference's
+    //      over riding along for the samples that need it (vk_trace.h winner_is_early): results are the reference's
     //  -1  as vk_scene_desc.flags says: VK_SCENE_FAST_ACCEL -> 1, VK_SCENE_REFERENCE_TREE -> 0, else 2
     int retree = -1;
 };
