@@ -407,7 +407,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     KArgs A;
     memset(&A, 0, sizeof(A));
     A.S = s->dev;
-    const bool exact = s->exact && !s->want_phase_stats && !s->exact_off;     // (the diagnostic builds have no second launch)
+    bool exact = s->exact && !s->want_phase_stats && !s->exact_off;     // (the diagnostic builds have no second launch)
     A.C.cam = *cam;
     A.C.width = p->width; A.C.height = p->height; A.C.spp = p->samples_per_pixel; A.C.max_depth = p->max_depth;
     A.C.seed = p->seed; A.C.integrator = p->integrator; A.C.background = p->background;
@@ -474,20 +474,24 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     }
     s->redo_last = false;
     if (exact) {
-        // queues for the samples the first launch drops: an eighth of the partition's samples, spread over REDO_REGIONS (a scene of a
-        // million pixel-sized spheres drops 5 %; a full queue is reported where the caller synchronises, vk_scene_last_kernel_ms)
+        // queues for the samples the first launch drops: room for 1/32 of the partition's samples (C2 drops 0.05 %; 8 bytes each: 0.5 GB
+        // for C2's 2.1 G samples), spread over REDO_REGIONS; a full queue is reported where the caller synchronises
+        // (vk_scene_last_requeued_samples), vk_render then renders the frame again on the tree as handed over
         const uint64_t samples = partition_samples(p, g);
         s->redo_last_samples = samples;
-        uint64_t per_region = samples / 8u / REDO_REGIONS + 4096u;
+        uint64_t per_region = samples / 32u / REDO_REGIONS + 4096u;
         if (s->env.redo_region_cap >= 1) per_region = (uint64_t)s->env.redo_region_cap;      // tests
-        if (per_region * REDO_REGIONS >= 0xFFFFFFFFull) return fail(VK_ERR_UNSUPPORTED, "frame too large for the redo queues of exact re-treeing (VK_EXACT_RETREE=0 renders it on the tree handed over)");
-        int rc = ensure(s->redo_list, s->redo_bytes, (size_t)per_region * REDO_REGIONS * sizeof(uint2));
+        if (per_region * REDO_REGIONS >= 0xFFFFFFFFull) exact = false;      // (a frame of > 10^11 samples: on the tree as handed over)
+    }
+    if (exact) {
+        const uint64_t per_region_ = s->env.redo_region_cap >= 1 ? (uint64_t)s->env.redo_region_cap : s->redo_last_samples / 32u / REDO_REGIONS + 4096u;
+        int rc = ensure(s->redo_list, s->redo_bytes, (size_t)per_region_ * REDO_REGIONS * sizeof(uint2));
         if (rc != VK_OK) return rc;
         HIP_TRY(hipMemsetAsync(s->redo_count, 0, (REDO_REGIONS * REDO_COUNT_STRIDE + 16) * sizeof(uint32_t), st));
         A.redo_list = s->redo_list; A.redo_count = s->redo_count; A.redo_plan = s->redo_count + REDO_REGIONS * REDO_COUNT_STRIDE;
-        A.redo_region_cap = (uint32_t)per_region;
+        A.redo_region_cap = (uint32_t)per_region_;
     } else if (s->exact) {
-        A.S = s->ref_view;      // the diagnostic builds have no second launch: they render on the tree as handed over
+        A.S = s->ref_view;      // no second launch (diagnostic builds, a scene switched off, an oversized frame): the tree as handed over
     }
     // LDS residency of the hot records
     bool lds = s->lds_bytes != 0;
