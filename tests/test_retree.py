@@ -139,6 +139,91 @@ def test_exact_retree_gives_the_handed_over_trees_samples_on_far_small_spheres(g
         assert redone < 0.1 * segments and steps_x < 0.9 * steps_r
 
 
+class SphereCrowd(Gen):
+    """Worlds of spheres only, solid materials — what exact re-treeing rebuilds (vk_linearize.cpp rt_collect) — in the shapes that make
+    computed hits precede their box entries: pixel-sized spheres far from the camera, a ground sphere of radius 1e3..1e5, grazing
+    views; plus coincident copies (every hit an exact tie), hollow spheres (inverted boxes), objects beside subtrees and `len == 1`
+    nodes in random tree shapes, sphere lights for the PDF integrator."""
+    def __init__(self, seed):
+        self.r = np.random.default_rng(seed)
+        self.d = Desc()                                      # (no image / checker / noise texture anywhere: the scene must stay sphere-only)
+        self.lights = []
+        self.use_pdf = bool(self.r.integers(0, 2))
+        self.emit = self.d.light(6, 6, 6)
+        self.surface = [self.d.lambertian(*self.r.uniform(0.2, 0.9, 3)), self.d.lambertian(*self.r.uniform(0.2, 0.9, 3)),
+                        self.d.mat(ffi.VK_MAT_METAL, self.d.solid(0.8, 0.7, 0.6), float(self.r.uniform(0.0, 0.6))),
+                        self.d.mat(ffi.VK_MAT_DIELECTRIC, 0, 1.5)]
+
+    def one(self, c, rad, m=None):
+        c = np.asarray(c, np.float32); rad = np.float32(rad)
+        ref = self.d.sphere(tuple(float(x) for x in c), float(rad), self.mat() if m is None else m)
+        return ref, (c - rad, c + rad)                       # Sphere::bounding_box as the reference computes it (inverted when rad < 0)
+
+    def build(self, far=None):
+        r = self.r
+        far = float(r.choice([1.0, 8.0, 40.0])) if far is None else far
+        hollow = r.uniform() < 0.25
+        objs = []
+        for _ in range(int(r.integers(20, 160))):
+            k = r.uniform()
+            if k < 0.5:
+                objs.append(self.one(self.pos(), r.uniform(0.1, 1.0)))
+            elif k < 0.9:                                    # small spheres spread far out: seen from hundreds of radii away
+                objs.append(self.one(r.uniform(-20, 30, 3) * far / 8.0 + 5.0, r.uniform(0.02, 0.3)))
+            elif k < 0.95 and hollow:
+                objs.append(self.one(self.pos(), -r.uniform(0.2, 0.8)))          # hollow (a scene with one keeps the tree handed over)
+            else:
+                c, rad = self.pos(), r.uniform(0.2, 0.9)                             # two materials on the same sphere: exact ties
+                objs.append(self.one(c, rad)); objs.append(self.one(c, rad))
+        if r.uniform() < 0.6:
+            R = float(r.choice([1.0e3, 1.0e4, 1.0e5]))
+            objs.append(self.one((5.0, -R, 5.0), R))                                # the ground
+        if self.use_pdf:
+            lref, lbb = self.one(self.pos() + np.array([0, 6, 0]), r.uniform(0.5, 1.5), m=self.emit)
+            objs.append((lref, lbb)); self.lights.append(lref)
+        order = r.permutation(len(objs))
+        world, _ = self.tree([objs[i] for i in order])
+        desc = self.d.finish(world, self.lights if self.use_pdf else [])
+        ang = r.uniform(0, 6.28)
+        dist = float(r.choice([14.0, 60.0, 250.0])) * max(1.0, far / 8.0)
+        cam = camera((5 + dist * np.cos(ang), r.uniform(0.3, 0.6) * dist, 5 + dist * np.sin(ang)), (5, 3, 5), vfov=float(r.choice([8.0, 25.0, 50.0])))
+        kw = {} if self.use_pdf else dict(integrator=ffi.VK_INTEGRATOR_SCATTER, background=ffi.VK_BACKGROUND_SKY)
+        return desc, cam, params(32, 24, 3, max_depth=int(r.choice([3, 12, 50])), seed=int(r.integers(1, 1000)), **kw)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_exact_retree_on_sphere_crowds_is_the_handed_over_tree_per_sample(seed, oracle, emu, built, monkeypatch):
+    import emu_ffi
+    desc, cam, p = SphereCrowd(7000 + seed).build()
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    desc.contents.flags = ffi.VK_SCENE_REFERENCE_TREE
+    img_r, ps_r, steps_r, info_r = emu.render_samples(desc, cam, p)
+    compare(ps_o, ps_r, img_o, img_r)
+    desc.contents.flags = 0
+    for variant in ("0", "1"):                               # the device's LDS form (whole samples again) and its global-memory form
+        monkeypatch.setenv("EMU_GLOBAL_VARIANT", variant)
+        img_x, ps_x, steps_x, info_x = emu.render_samples(desc, cam, p)
+        assert np.array_equal(ps_x.view(np.uint32), ps_r.view(np.uint32)), (variant, int((ps_x.view(np.uint32) != ps_r.view(np.uint32)).any(axis=1).sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(16))
+def test_exact_retree_on_sphere_crowds_on_the_gpu(seed, device, oracle):
+    from test_gpu_parity import compare_samples, device_samples
+    from vecchio_amd import DeviceScene
+    desc, cam, p = SphereCrowd(7100 + seed).build()
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    imgs = []
+    for flags in (0, ffi.VK_SCENE_REFERENCE_TREE):
+        desc.contents.flags = flags
+        ds = DeviceScene(desc)
+        img_d, ps_d = device_samples(ds, cam, p)
+        compare_samples(ps_o, ps_d, img_o, img_d)
+        imgs.append(ps_d)
+        ds.close()
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(8))
 def test_retreed_crowd_on_the_gpu(seed, device, oracle):
