@@ -385,7 +385,7 @@ def main():
             # WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950: FETCH_SIZE counts half the bytes of wide reads -> upper bound)
             traffic, issue, prof_path = None, None, None
             t_read = t_write = scratch_share = scratch_detail = None
-            if n_gpus == 1 and not spp_override and bvh == "reference" and not fast_accel:
+            if n_gpus == 1 and not spp_override and bvh == "reference" and not fast_accel and not handed_over_tree:
                 prof, prof_path = pmc_summary(name)
                 if prof:
                     d = prof.get("derived", {})
@@ -405,7 +405,7 @@ def main():
                                          "kernel time; frac x lane_fill = share of the 78.6 T lane-instr/s the kernel's useful lanes occupy"}
             traffic_note = (f"HBM bytes per launch from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command ({prof_path}), "
                             "not re-measured in this run")
-            if live_traffic and not spp_override and bvh == "reference" and not fast_accel:
+            if live_traffic and not spp_override and bvh == "reference" and not fast_accel and not handed_over_tree:
                 live, why = measure_counters_live(name)
                 if live is not None:
                     traffic_note = ("HBM bytes of one launch MEASURED IN THIS RUN: one-step child runs of this script under rocprofv3 --pmc "
