@@ -776,7 +776,7 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
     }
     UP(spheres, spheres); UP(sphere_mat, sphere_mat); UP(moving, moving); UP(rects, rects); UP(boxes, boxes);
     UP(lists, lists); UP(list_refs, list_refs); UP(media, media); UP(instances, instances);
-    UP(materials, materials); UP(textures, textures); UP(images, images); UP(image_bytes, image_bytes);
+    UP(materials, materials); UP(sphere_material, sphere_material); UP(textures, textures); UP(images, images); UP(image_bytes, image_bytes);
     UP(perlins, perlins); UP(lights, lights);
     if (!H.tie_rank.empty()) UP(tie_rank, tie_rank);
 #undef UP

@@ -101,6 +101,7 @@ struct DScene {
     const DMedium *media;
     const DInstance *instances;
     const DMaterial *materials;
+    const DMaterial *sphere_material;   // materials[sphere_mat[i]] for every sphere i (read by the sphere-only kernel variants)
     const DTexture *textures;
     const DImage *images; const uint8_t *image_bytes;
     const DPerlin *perlins;

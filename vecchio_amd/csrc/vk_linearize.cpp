@@ -20,6 +20,7 @@ DScene LinearScene::host_view() const {
     s.lists = lists.data(); s.list_refs = list_refs.data();
     s.media = media.data(); s.instances = instances.data();
     s.materials = materials.data(); s.textures = textures.data();
+    s.sphere_material = sphere_material.empty() ? nullptr : sphere_material.data();
     s.images = images.data(); s.image_bytes = image_bytes.data();
     s.perlins = perlins.data();
     s.lights = lights.data(); s.n_lights = (uint32_t)lights.size();
@@ -806,6 +807,10 @@ int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, con
     b.retree_units = mode == 2;
     if (!b.run()) return b.status == VK_OK ? VK_ERR_BAD_ARG : b.status;
     out.world_items = b.world_items;
+    if (out.features == 0u) {            // what the sphere-only kernel variants shade from
+        out.sphere_material.resize(out.spheres.size());
+        for (size_t i = 0; i < out.spheres.size(); i++) out.sphere_material[i] = out.materials[out.sphere_mat[i]];
+    }
     if (b.retree_units && b.n_blocks != 0 && !(b.n_blocks == 1 && b.world_rebuilt && out.features == 0u && out.instances.empty() &&
         out.spheres.size() < (1u << 26))) {
         // (cannot happen for a world of spheres only; never leave a unit-mode tree without its second pass)

@@ -24,6 +24,7 @@ struct LinearScene {
     std::vector<DMedium> media;
     std::vector<DInstance> instances;
     std::vector<DMaterial> materials;
+    std::vector<DMaterial> sphere_material;   // see DScene (filled for scenes of spheres only)
     std::vector<DTexture> textures;
     std::vector<DImage> images;
     std::vector<uint8_t> image_bytes;

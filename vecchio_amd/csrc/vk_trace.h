@@ -1065,7 +1065,10 @@ VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts
     uint32_t k0 = VK_MAT_LAMBERTIAN;
     if (!miss) {
         build_record<F, Mem>(L, S, M, R);
-        m = &S.materials[R.mat];
+        // sphere-only variants: the material record by SPHERE index (DScene::sphere_material), one gather instead of two dependent ones
+        // (sphere -> material index -> record): the 1 M-sphere scene +1.5 %, C2 +-0
+        if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) m = &S.sphere_material[VKD_INDEX(L.best_prim)];
+        else m = &S.materials[R.mat];
         k0 = m->kind;
     }
     V3 rd = L.wd;                                             // `r` of ray_color is the world-space ray
