@@ -625,15 +625,19 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             if (STATS) st_t0 = clock64();
             const uint32_t live = n_box + n_heavy + n_light + n_sn;   // lanes only change state here, none appear or vanish
             // steps between two exit tests (compile time: a run-time trip count costs 4-13 %).  With shading deferred the optimum is 3
-            // for scenes traversed from LDS (C2: 2 -> -4 %, 4 -> -0.5 %; C4 the same), 4 for sphere-only scenes traversed from global
-            // memory (C5: 3 / 4 / 5 / 7 -> 706 / 724 / 722 / 703 Msamples/s) and 5 for the everything-variants (C3: 4 / 5 / 6 / 8 ->
+            // for scenes traversed from LDS (C2: 2 -> -4 %, 4 -> -0.5 %; C4 the same), 2 for sphere-only scenes traversed from global
+            // memory (C5 on the tree handed over: 3 / 4 / 5 / 7 -> 706 / 724 / 722 / 703 Msamples/s; on the shorter walks of the rebuilt
+            // tree: VK_GLOBAL_SPHERE_UNROLL below) and 5 for the everything-variants (C3: 4 / 5 / 6 / 8 ->
             // 617 / 627 / 622 / 616): the longer a step waits for its item, the less an exit test per step group is worth
             constexpr bool SPHERES = (F & ~(uint32_t)VKF_INTEG_PDF) == 0u;
 #ifndef VK_CORNELL_UNROLL
 #define VK_CORNELL_UNROLL 3
 #endif
+#ifndef VK_GLOBAL_SPHERE_UNROLL
+#define VK_GLOBAL_SPHERE_UNROLL 2     // (on the rebuilt trees of exact re-treeing, 1 M spheres, 1 / 2 / 3 / 4 steps per exit test: 1 046 / 1 080 / 1 066 / 1 038 Msamples/s)
+#endif
             constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE)
-                ? BOX_UNROLL + 1 : (SPHERES ? (LDS_SCENE ? BOX_UNROLL - 1 : BOX_UNROLL) : VK_CORNELL_UNROLL);
+                ? BOX_UNROLL + 1 : (SPHERES ? (LDS_SCENE ? BOX_UNROLL - 1 : VK_GLOBAL_SPHERE_UNROLL) : VK_CORNELL_UNROLL);
             // The lane masks of the states come straight out of compares (uicmp = v_cmp into an SGPR pair) and are combined and
             // counted with scalar instructions; a ballot of a compound lane boolean goes through a VGPR (v_cndmask 0/1 + v_cmp_ne)
             // for every term.  The lanes that step are the box lanes of the last exit test: their mask is at hand in SGPRs and
