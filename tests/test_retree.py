@@ -206,6 +206,28 @@ def test_exact_retree_on_sphere_crowds_is_the_handed_over_tree_per_sample(seed, 
         assert np.array_equal(ps_x.view(np.uint32), ps_r.view(np.uint32)), (variant, int((ps_x.view(np.uint32) != ps_r.view(np.uint32)).any(axis=1).sum()))
 
 
+def test_a_tree_whose_boxes_do_not_hold_their_spheres_is_walked_as_handed_over(oracle, emu, built):
+    """The tree is the caller's: a node box that cuts into one of its spheres (which no BVHNode::new tree has) changes which hits the
+    reference finds.  Exact re-treeing assumes a sphere's own box inside its unit's, so such a tree must be left alone — same items,
+    same samples as with VK_SCENE_REFERENCE_TREE, and the oracle's."""
+    g = SphereCrowd(7001)                                   # (a world that IS rebuilt when its boxes are right)
+    desc, cam, p = g.build()
+    d = desc.contents
+    cut = 0
+    for i in range(d.n_bvh):                                 # shrink the box of every node that holds a sphere directly
+        n = d.bvh[i]
+        if (n.left >> 28) == ffi.VK_KIND_SPHERE and n.bb_max[0] - n.bb_min[0] > 0.05:
+            n.bb_max[0] -= 0.02; cut += 1
+    assert cut > 10
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    desc.contents.flags = ffi.VK_SCENE_REFERENCE_TREE
+    img_r, ps_r, steps_r, info_r = emu.render_samples(desc, cam, p)
+    compare(ps_o, ps_r, img_o, img_r)
+    desc.contents.flags = 0
+    img_x, ps_x, steps_x, info_x = emu.render_samples(desc, cam, p)
+    assert steps_x == steps_r and np.array_equal(ps_x.view(np.uint32), ps_r.view(np.uint32))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(16))
 def test_exact_retree_on_sphere_crowds_on_the_gpu(seed, device, oracle):

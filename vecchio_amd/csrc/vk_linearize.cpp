@@ -392,7 +392,11 @@ struct Builder {
             if (retree_units && VK_REF_KIND(fr.ref) != VK_KIND_SPHERE) { ok = false; return true; }      // exact re-treeing: spheres only
             if (!rt_bounds(fr.ref, o.mn, o.mx)) { ok = false; return status == VK_OK; }
             if (retree_units) {
+                // the early-winner test (vk_trace.h winner_is_early) takes the sphere's own box for a subset of its unit's: true of any
+                // tree BVHNode::new builds, checked because the tree is the caller's
                 const vk_bvh_node &pn = d->bvh[fr.parent];
+                for (int a = 0; a < 3; a++)
+                    if (!(pn.bb_min[a] <= o.mn[a] && o.mx[a] <= pn.bb_max[a]) && o.mn[a] <= o.mx[a]) { ok = false; return true; }
                 memcpy(o.mn, pn.bb_min, 12); memcpy(o.mx, pn.bb_max, 12);
             }
             for (int a = 0; a < 3; a++) {
