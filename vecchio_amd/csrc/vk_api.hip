@@ -89,7 +89,8 @@ struct EnvSwitches {
     bool order_reuse = true;           // VK_ORDER_REUSE=0: probe the tile costs in every frame of a partition
     bool dual_same_stream = false;     // VK_DUAL_SAME_STREAM=1 (tests): see launch_dual
     bool dual_debug = false;           // VK_DUAL_DEBUG=1: print each checked frame's unit split
-    int retree = -1;                   // VK_RETREE=0/1/2: nothing rebuilt / every draw-free subtree / exact re-treeing (default: vk_scene_desc.flags)
+    // VK_RETREE=0/1/2: nothing rebuilt / every draw-free subtree / exact re-treeing (default: vk_scene_desc.flags)
+    int retree = -1;
     int redo_region_cap = 0;           // VK_REDO_REGION_CAP=n (tests): entries per queue between the two launches of exact re-treeing
     static int int_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
     static EnvSwitches read() {
@@ -167,7 +168,11 @@ struct vk_scene {
     // so the order found for a partition is kept while the partition's geometry is the same, the camera has hardly moved and the
     // order is younger than ORDER_MAX_AGE frames; then the probe launch and the three sorting kernels are skipped (~1.7 ms of a
     // 1/8 share of C2's 42 ms).  The order never changes a pixel, so a stale one only costs balance.
-    struct { uint32_t width = 0, height = 0, rank = 0, world = 0, depth = 0, age = 0; float org[3] = {0, 0, 0}, llc[3] = {0, 0, 0}; bool valid = false; } order_for;
+    struct {
+        uint32_t width = 0, height = 0, rank = 0, world = 0, depth = 0, age = 0;
+        float org[3] = {0, 0, 0}, llc[3] = {0, 0, 0};
+        bool valid = false;
+    } order_for;
     // ---- multi-device group (empty for an ordinary scene)
     std::vector<vk_scene *> parts;
     // a part's own stream, its slab (on its device), the slab's landing buffer on devices[0] and the event that says it landed
@@ -245,7 +250,8 @@ void plan_residency(vk_scene *s, size_t hot) {
     // 4+4+3+3 on the four SIMDs and the second workgroup does not fit beside the first — but they can be 16 + 12: a 1024-thread
     // workgroup (4 per SIMD) and a 768-thread one (3 per SIMD), from two concurrent launches.  Needs two LDS copies of the scene.
     s->dual_launch = false;
-    if (spheres_only && !s->env.no_lds_scene && s->env.max_waves_per_cu == 0 && !getenv("VK_NO_DUAL_LAUNCH") && 2 * hot + 28 * pw <= LDS_PER_CU) {
+    if (spheres_only && !s->env.no_lds_scene && s->env.max_waves_per_cu == 0 && !getenv("VK_NO_DUAL_LAUNCH") &&
+        2 * hot + 28 * pw <= LDS_PER_CU) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = 768; s->wgs_per_cu = 2;      // (the single-launch shape: probe, STATS, tiny frames)
         s->dual_launch = true;
         return;
@@ -473,23 +479,22 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         A.accum = s->accum;
     }
     s->redo_last = false;
+    uint64_t per_region = 0;
     if (exact) {
         // queues for the samples the first launch drops: room for 1/32 of the partition's samples (C2 drops 0.05 %; 8 bytes each: 0.5 GB
         // for C2's 2.1 G samples), spread over REDO_REGIONS; a full queue is reported where the caller synchronises
         // (vk_scene_last_requeued_samples), vk_render then renders the frame again on the tree as handed over
-        const uint64_t samples = partition_samples(p, g);
-        s->redo_last_samples = samples;
-        uint64_t per_region = samples / 32u / REDO_REGIONS + 4096u;
+        s->redo_last_samples = partition_samples(p, g);
+        per_region = s->redo_last_samples / 32u / REDO_REGIONS + 4096u;
         if (s->env.redo_region_cap >= 1) per_region = (uint64_t)s->env.redo_region_cap;      // tests
         if (per_region * REDO_REGIONS >= 0xFFFFFFFFull) exact = false;      // (a frame of > 10^11 samples: on the tree as handed over)
     }
     if (exact) {
-        const uint64_t per_region_ = s->env.redo_region_cap >= 1 ? (uint64_t)s->env.redo_region_cap : s->redo_last_samples / 32u / REDO_REGIONS + 4096u;
-        int rc = ensure(s->redo_list, s->redo_bytes, (size_t)per_region_ * REDO_REGIONS * sizeof(uint2));
+        int rc = ensure(s->redo_list, s->redo_bytes, (size_t)per_region * REDO_REGIONS * sizeof(uint2));
         if (rc != VK_OK) return rc;
         HIP_TRY(hipMemsetAsync(s->redo_count, 0, (REDO_REGIONS * REDO_COUNT_STRIDE + 16) * sizeof(uint32_t), st));
         A.redo_list = s->redo_list; A.redo_count = s->redo_count; A.redo_plan = s->redo_count + REDO_REGIONS * REDO_COUNT_STRIDE;
-        A.redo_region_cap = (uint32_t)per_region_;
+        A.redo_region_cap = (uint32_t)per_region;
     } else if (s->exact) {
         A.S = s->ref_view;      // no second launch (diagnostic builds, a scene switched off, an oversized frame): the tree as handed over
     }
@@ -521,7 +526,8 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         const float hscale = fabsf(cam->horizontal[0]) + fabsf(cam->horizontal[1]) + fabsf(cam->horizontal[2]) +
                              fabsf(cam->vertical[0]) + fabsf(cam->vertical[1]) + fabsf(cam->vertical[2]);      // size of the view plane
         reuse_order = o.valid && o.width == p->width && o.height == p->height && o.rank == g.rank && o.world == g.world &&
-                      o.depth == p->max_depth && o.age < 16u && close3(o.org, cam->origin, hscale) && close3(o.llc, cam->lower_left_corner, hscale);
+                      o.depth == p->max_depth && o.age < 16u && close3(o.org, cam->origin, hscale) &&
+                      close3(o.llc, cam->lower_left_corner, hscale);
         if (reuse_order) { o.age++; A.tile_order = s->tile_order; }
     }
     if (use_order && !s->want_phase_stats && !reuse_order) {
@@ -750,7 +756,8 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
 #define UP(vec, field) do { rc = upload(s.get(), H.vec, D.field); if (rc != VK_OK) return rc; } while (0)
     // LDS residency: items + spheres + accumulators must leave room for >= 2 workgroups per CU
     // (exact re-treeing: the second launch stages the tree as handed over instead of the rebuilt one, whichever is larger counts)
-    size_t hot = std::max(H.items.size(), H.ref_items.size()) * sizeof(DItem) + H.spheres.size() * sizeof(DSphere) + H.boxes.size() * sizeof(DBox);
+    size_t hot = std::max(H.items.size(), H.ref_items.size()) * sizeof(DItem) + H.spheres.size() * sizeof(DSphere) +
+                 H.boxes.size() * sizeof(DBox);
     s->hot_bytes = hot;
     plan_residency(s.get(), hot);
     D.gate_scale = 1.0f; D.tmin_gate = T_MIN;
@@ -776,7 +783,8 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
     }
     UP(spheres, spheres); UP(sphere_mat, sphere_mat); UP(moving, moving); UP(rects, rects); UP(boxes, boxes);
     UP(lists, lists); UP(list_refs, list_refs); UP(media, media); UP(instances, instances);
-    UP(materials, materials); UP(sphere_material, sphere_material); UP(textures, textures); UP(images, images); UP(image_bytes, image_bytes);
+    UP(materials, materials); UP(sphere_material, sphere_material); UP(textures, textures); UP(images, images);
+    UP(image_bytes, image_bytes);
     UP(perlins, perlins); UP(lights, lights);
     if (!H.tie_rank.empty()) UP(tie_rank, tie_rank);
 #undef UP
@@ -953,7 +961,9 @@ int vk_scene_last_kernel_ms(vk_scene *s, double *ms_out) {
             const double share = (double)u[1] / (double)(u[0] + u[1]);       // ~12 / 28 when both run side by side
             const bool lopsided = share < 0.10 || share > 0.90;
             s->dual_strikes = lopsided ? s->dual_strikes + 1 : 0;
-            if (s->env.dual_debug) fprintf(stderr, "vecchio_amd: dual launch: 1024-thread launch %u units, 768-thread launch %u units (%.2f)\n", u[0], u[1], share);
+            if (s->env.dual_debug)
+                fprintf(stderr, "vecchio_amd: dual launch: 1024-thread launch %u units, 768-thread launch %u units (%.2f)\n", u[0], u[1],
+                    share);
             if (s->dual_strikes >= 2) {
                 s->dual_launch = false;
                 fprintf(stderr, "vecchio_amd: the two launches of the 7-waves-per-SIMD shape do not run side by side on this runtime "
@@ -1018,7 +1028,8 @@ int vk_scene_last_requeued_samples(vk_scene *s, uint64_t *out) {
             "as handed over from now on\n", plan[1], (unsigned long long)s->redo_last_samples);
     }
     if (plan[2] != 0u) s->exact_off = true;      // (later frames render on the tree as handed over; vk_render repeats this one)
-    if (plan[2] != 0u) return fail(VK_ERR_OOM, "exact re-treeing: " + std::to_string(plan[2]) + " samples did not fit the redo queues, the frame is "
+    if (plan[2] != 0u) return fail(VK_ERR_OOM, "exact re-treeing: " + std::to_string(plan[2]) +
+        " samples did not fit the redo queues, the frame is "
         "incomplete (VK_RETREE=0 or VK_SCENE_REFERENCE_TREE renders on the tree handed over)");
     return VK_OK;
 }

@@ -57,13 +57,15 @@ struct KArgs {
     // order) are queued here, REDO_REGIONS queues of redo_region_cap entries {x | y << 16, sample}, one counter per region (64 bytes
     // apart); a workgroup appends to the region of its block index.  The second launch (list_mode = 1, S = the scene as handed over)
     // takes its units from these queues instead of from the tiles: unit u = entries [n k, n (k + 1)) of region u % REDO_REGIONS,
-    // k = u / REDO_REGIONS, for k below the slice count redo_plan_kernel leaves in redo_plan[0] and n = redo_plan[3] entries per unit.  redo_list == null: nothing is dropped
+    // k = u / REDO_REGIONS, for k below the slice count redo_plan_kernel leaves in redo_plan[0] and n = redo_plan[3] entries per unit.
+    // redo_list == null: nothing is dropped
     // (the probe launch, scenes without a rebuilt tree).
     uint2 *redo_list; uint32_t *redo_count; const uint32_t *redo_plan; uint32_t redo_region_cap; uint32_t list_mode;
 };
 constexpr uint32_t REDO_REGIONS = 512u;
 constexpr uint32_t REDO_COUNT_STRIDE = 16u;        // uint32 words between two regions' counters
-constexpr uint32_t REDO_UNIT = 256u;               // most queue entries per work unit of the second launch (redo_plan_kernel picks 64..this)
+// most queue entries per work unit of the second launch (redo_plan_kernel picks 64..this)
+constexpr uint32_t REDO_UNIT = 256u;
 
 // LDS-resident hot records
 struct LdsMem {
@@ -309,7 +311,8 @@ __device__ __forceinline__ PreTurb cooperative_turb(const Lane &L, const DScene 
 // through shade_refill_call (below) by the everything-variants.
 struct PhaseClocks { unsigned long long mat = 0, refill = 0, t1 = 0; };
 template <uint32_t F, bool LDS_SCENE, bool STATS, bool COST>
-__device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool early, bool &active, bool &need, bool &fresh, bool &touched, bool &rearm,
+__device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool early, bool &active, bool &need, bool &fresh, bool &touched,
+                                                  bool &rearm,
                                                   uint32_t &cost_t0, KArgsC P, float *cold, unsigned long long *tile_sum,
                                                   uint32_t *wstate, uint32_t lane, uint32_t lds_items, PhaseClocks &clk) {
     using Mem = typename std::conditional<LDS_SCENE, LdsMem, GlobalMem>::type;
@@ -339,7 +342,8 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool e
         uint2 *rl = KARG(P, redo_list);
         const unsigned long long m_drop = __builtin_amdgcn_ballot_w64(is_shade && early && rl != nullptr);
         if (m_drop != 0ull) {
-            const uint32_t region = (blockIdx.x + (blockDim.x == 1024u ? 0u : gridDim.x)) & (REDO_REGIONS - 1u);      // (dual launch: 0..255 | 256..511)
+            // (dual launch: 0..255 | 256..511)
+            const uint32_t region = (blockIdx.x + (blockDim.x == 1024u ? 0u : gridDim.x)) & (REDO_REGIONS - 1u);
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(KARG(P, redo_count) + region * REDO_COUNT_STRIDE, (uint32_t)__popcll(m_drop));
             base = __builtin_amdgcn_readfirstlane(base);
@@ -483,7 +487,9 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool e
 // traversal state inside the box and primitive loops as soon as anything in the kernel changed: C3 moved between 330 and 520
 // Msamples/s with the spill placement).  Only what shading reads of the traversal state crosses, by value.
 struct ShadeIo {
-    uint32_t flags;            // in: 1 is_shade, 2 active, 4 need, 64 early (winner_is_early);   out: 2 active, 4 need, 8 fresh, 16 touched, 32 rearm (same ray again)
+    // in: 1 is_shade, 2 active, 4 need, 64 early (winner_is_early);   out: 2 active, 4 need, 8 fresh, 16 touched, 32 rearm (same ray
+    // again)
+    uint32_t flags;
     float T; uint32_t best_prim; int32_t best_inst; float best_aux;
     V3 o, d; float time;       // in: the segment's ray (world ray when the scene has no instances); out: the new ray of fresh lanes
     uint32_t cost_t0;
@@ -510,7 +516,8 @@ __device__ __attribute__((noinline)) ShadeIo shade_refill_call(ShadeIo io, uint3
     bool active = (io.flags & 2u) != 0u, need = (io.flags & 4u) != 0u, fresh = false, touched = false, rearm = false;
     uint32_t cost_t0 = io.cost_t0;
     PhaseClocks clk;
-    shade_refill_body<F, LDS_SCENE, false, COST>(L, (io.flags & 1u) != 0u, (io.flags & 64u) != 0u, active, need, fresh, touched, rearm, cost_t0, P, cold, tile_sum,
+    shade_refill_body<F, LDS_SCENE, false, COST>(L, (io.flags & 1u) != 0u, (io.flags & 64u) != 0u, active, need, fresh, touched, rearm,
+        cost_t0, P, cold, tile_sum,
         wstate, lane, lds_items, clk);
     // fresh lanes: L.wo / L.wd hold the NEW ray, which is what the world-ray slots want
     if (active && touched) cold_store_path<F>(cold, lane, L);
@@ -634,7 +641,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
 #define VK_CORNELL_UNROLL 3
 #endif
 #ifndef VK_GLOBAL_SPHERE_UNROLL
-#define VK_GLOBAL_SPHERE_UNROLL 2     // (on the rebuilt trees of exact re-treeing, 1 M spheres, 1 / 2 / 3 / 4 steps per exit test: 1 046 / 1 080 / 1 066 / 1 038 Msamples/s)
+// (on the rebuilt trees of exact re-treeing, 1 M spheres, 1 / 2 / 3 / 4 steps per exit test: 1 046 / 1 080 / 1 066 / 1 038 Msamples/s)
+#define VK_GLOBAL_SPHERE_UNROLL 2
 #endif
             constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE)
                 ? BOX_UNROLL + 1 : (SPHERES ? (LDS_SCENE ? BOX_UNROLL - 1 : VK_GLOBAL_SPHERE_UNROLL) : VK_CORNELL_UNROLL);
@@ -749,7 +757,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             } else {
                 PhaseClocks clk;
                 bool rearm = false;
-                shade_refill_body<F, LDS_SCENE, STATS, COST>(L, is_shade, early, active, need, fresh, touched, rearm, cost_t0, kargs_fresh(), cold,
+                shade_refill_body<F, LDS_SCENE, STATS, COST>(L, is_shade, early, active, need, fresh, touched, rearm, cost_t0,
+                    kargs_fresh(), cold,
                     tile_sum, wstate, lane, lds_items, clk);
                 if (STATS) { st_t_mat += clk.mat; st_t_refill += clk.refill; st_t1 = clock64(); }
                 if (fresh | rearm) {

@@ -305,7 +305,11 @@ struct Builder {
         return true;
     }
 
-    struct RtObj { float mn[3], mx[3], c[3]; uint32_t dref; uint32_t dref2 = 0; uint32_t parent = 0xFFFFFFFFu; uint32_t rank = 0, rank2 = 0; };
+    // (dref2, rank2: the unit's second object; parent: the BVH node whose box gates the unit — exact re-treeing, rt_collect)
+    struct RtObj {
+        float mn[3], mx[3], c[3];
+        uint32_t dref; uint32_t dref2 = 0; uint32_t parent = 0xFFFFFFFFu; uint32_t rank = 0, rank2 = 0;
+    };
     bool retree_units = false;              // LinearizeOptions::retree == 2 (see rt_collect)
     static float rt_half_area(const float *mn, const float *mx) {
         float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
@@ -374,7 +378,9 @@ struct Builder {
                 const vk_bvh_node &n = d->bvh[ni];
                 if (retree_units) {
                     for (int a = 0; a < 3; a++) {
-                        if (!(n.bb_min[a] <= n.bb_max[a]) || !std::isfinite(n.bb_min[a]) || !std::isfinite(n.bb_max[a])) { ok = false; return true; }
+                        if (!(n.bb_min[a] <= n.bb_max[a]) || !std::isfinite(n.bb_min[a]) || !std::isfinite(n.bb_max[a])) {
+                            ok = false; return true;
+                        }
                         if (fr.parent != 0xFFFFFFFFu) {
                             const vk_bvh_node &pn = d->bvh[fr.parent];
                             if (!(pn.bb_min[a] <= n.bb_min[a] && n.bb_max[a] <= pn.bb_max[a])) { ok = false; return true; }
@@ -454,7 +460,8 @@ struct Builder {
                 }
                 fr.item = (uint32_t)L.items.size();
                 L.items.push_back(it);
-                // ---- choose the split: 32 centroid bins per axis (16: 5 % more steps on C2; 64 and a full sweep of small nodes: no fewer), cost = A(left) n(left) + A(right) n(right)
+                // ---- choose the split: 32 centroid bins per axis (16: 5 % more steps on C2; 64 and a full sweep of small nodes: no
+                // fewer), cost = A(left) n(left) + A(right) n(right)
                 float cmin[3], cmax[3];
                 memcpy(cmin, objs[fr.begin].c, 12); memcpy(cmax, objs[fr.begin].c, 12);
                 for (size_t i = fr.begin + 1; i < fr.end; i++) rt_grow(cmin, cmax, objs[i].c, objs[i].c);
@@ -557,14 +564,17 @@ struct Builder {
         if (simple_count.empty() || simple_count[root] == -2) { if (!classify(root)) return false; }
         if (simple_count[root] < (int32_t)RETREE_MIN || n_blocks >= 4095u) return true;
         // exact re-treeing is for the world tree as a whole (the second render pass walks the whole tree as handed over)
-        if (retree_units && !(inst < 0 && VK_REF_KIND(d->world) == VK_KIND_BVH && root == VK_REF_INDEX(d->world))) { retree = false; return true; }
+        if (retree_units && !(inst < 0 && VK_REF_KIND(d->world) == VK_KIND_BVH && root == VK_REF_INDEX(d->world))) {
+            retree = false; return true;
+        }
         const size_t items0 = L.items.size(), boxes0 = L.boxes.size(), lists0 = L.lists.size(), refs0 = L.list_refs.size();
         const uint32_t prims0 = L.n_prims, feat0 = L.features;
         std::vector<RtObj> objs;
         objs.reserve((size_t)simple_count[root]);
         bool ok = true;
         if (!rt_collect(root, flip, inst, objs, ok)) return false;
-        if (!ok || objs.size() < RETREE_MIN || objs.size() >= (1u << 20) || (!objs.empty() && (objs.back().rank | objs.back().rank2) >= (1u << 20))) {
+        if (!ok || objs.size() < RETREE_MIN || objs.size() >= (1u << 20) ||
+            (!objs.empty() && (objs.back().rank | objs.back().rank2) >= (1u << 20))) {
             // keep the reference's tree for this subtree: undo what collecting converted (memo entries past the old sizes)
             L.items.resize(items0); L.boxes.resize(boxes0); L.lists.resize(lists0); L.list_refs.resize(refs0); L.n_prims = prims0;
             L.features = feat0;
@@ -828,8 +838,9 @@ int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, con
         LinearizeOptions o2; o2.retree = 0;
         int st = linearize(desc, ref, e2, o2);
         if (st != VK_OK) { err = e2; return st; }
-        if (ref.spheres.size() != out.spheres.size() || memcmp(ref.spheres.data(), out.spheres.data(), ref.spheres.size() * sizeof(DSphere)) != 0 ||
-            ref.sphere_mat != out.sphere_mat) { err = "exact re-tree: the two linearisations number the spheres differently"; return VK_ERR_UNSUPPORTED; }
+        const bool same = ref.spheres.size() == out.spheres.size() && ref.sphere_mat == out.sphere_mat &&
+            memcmp(ref.spheres.data(), out.spheres.data(), ref.spheres.size() * sizeof(DSphere)) == 0;
+        if (!same) { err = "exact re-tree: the two linearisations number the spheres differently"; return VK_ERR_UNSUPPORTED; }
         out.ref_items = ref.items;
         // 1/16: a computed hit point can lie outside its sphere's box (a grazing or false hit of a far sphere), and a ray nearly parallel
         // to that face enters the box later than it "hits" by that distance over a small direction component.  1/256 lost one sample

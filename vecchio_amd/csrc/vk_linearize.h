@@ -29,7 +29,8 @@ struct LinearScene {
     std::vector<DImage> images;
     std::vector<uint8_t> image_bytes;
     std::vector<DPerlin> perlins;
-    uint32_t n_noise_spheres = 0; uint32_t noise_sphere[4] = {0, 0, 0, 0}, noise_tex[4] = {0, 0, 0, 0}, noise_perlin[4] = {0, 0, 0, 0};   // see DScene
+    // see DScene
+    uint32_t n_noise_spheres = 0; uint32_t noise_sphere[4] = {0, 0, 0, 0}, noise_tex[4] = {0, 0, 0, 0}, noise_perlin[4] = {0, 0, 0, 0};
     std::vector<uint32_t> lights;
     // tie table (empty when no subtree was rebuilt): per object id ([spheres][rects][boxes][lists]) its block (bits 31..20, 0 = not
     // in a rebuilt subtree) and its position in the reference's visiting order inside the block (bits 19..0)

@@ -571,7 +571,8 @@ VK_HD bool box_step_core(Lane &L, const DScene &S, const Mem &M) {      // retur
     // sphere-only variants: tmin on the scale the lane's reciprocals are on (exact re-treeing, below; T_MIN itself otherwise)
     float tmin = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? S.tmin_gate : T_MIN;
     if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && Mem::ISHIFT == 0u) {
-        if (S.walk_start != 0u) tmin = L.i < S.walk_start ? T_MIN : tmin;      // a lane on the tree as handed over: the reference's own test
+        // a lane on the tree as handed over: the reference's own test
+        if (S.walk_start != 0u) tmin = L.i < S.walk_start ? T_MIN : tmin;
     }
     // AxisBB::hit decided from reciprocal multiplies; same boolean as the reference's (see slab_exact):
     // both forms compute fl(b-o) identically and q~ = fl(fl(b-o)*fl(1/d)) differs from the reference's
