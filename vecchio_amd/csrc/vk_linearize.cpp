@@ -396,6 +396,9 @@ struct Builder {
             }
             RtObj o;
             if (retree_units && VK_REF_KIND(fr.ref) != VK_KIND_SPHERE) { ok = false; return true; }      // exact re-treeing: spheres only
+            // ... of positive radius: a hollow sphere (negative radius, scene.rs:123-127) has an inverted box, which its unit's box need
+            // not contain, so its hits can precede the unit's entry by the sphere's whole size — beyond any padding of the gate
+            if (retree_units && !(d->spheres[VK_REF_INDEX(fr.ref)].radius > 0.0f)) { ok = false; return true; }
             if (!rt_bounds(fr.ref, o.mn, o.mx)) { ok = false; return status == VK_OK; }
             if (retree_units) {
                 // the early-winner test (vk_trace.h winner_is_early) takes the sphere's own box for a subset of its unit's: true of any
