@@ -20,7 +20,7 @@ n_spheres = int(sys.argv[3]) if len(sys.argv) > 3 else 0       # worlds of spher
 bad = 0
 for kind, n, base, cls in (("graph", n_graphs, 7000, Gen), ("crowd", n_crowds, 8000, Crowd), ("spheres", n_spheres, 9000, SphereCrowd)):
     for seed in range(base, base + n):
-        desc, cam, p = cls(seed).build()
+        desc, cam, p = (cls(seed, nasty=seed % 2 == 1) if cls is SphereCrowd else cls(seed)).build()
         ds = DeviceScene(desc)
         img_d, ps_d = device_samples(ds, cam, p)
         img_o, ps_o = O.render_samples(desc, cam, p)

@@ -144,7 +144,8 @@ class SphereCrowd(Gen):
     computed hits precede their box entries: pixel-sized spheres far from the camera, a ground sphere of radius 1e3..1e5, grazing
     views; plus coincident copies (every hit an exact tie), hollow spheres (inverted boxes), objects beside subtrees and `len == 1`
     nodes in random tree shapes, sphere lights for the PDF integrator."""
-    def __init__(self, seed):
+    def __init__(self, seed, nasty=False):
+        self.nasty = nasty
         self.r = np.random.default_rng(seed)
         self.d = Desc()                                      # (no image / checker / noise texture anywhere: the scene must stay sphere-only)
         self.lights = []
@@ -175,6 +176,19 @@ class SphereCrowd(Gen):
             else:
                 c, rad = self.pos(), r.uniform(0.2, 0.9)                             # two materials on the same sphere: exact ties
                 objs.append(self.one(c, rad)); objs.append(self.one(c, rad))
+        if self.nasty:
+            # overlapping clusters (final_scene's 1 000-sphere box), shells inside shells, concentric spheres, specks, a sphere around
+            # everything (the camera inside glass)
+            c0 = self.pos()
+            for _ in range(int(r.integers(8, 60))):
+                objs.append(self.one(c0 + r.uniform(-1.5, 1.5, 3), r.uniform(0.4, 1.4)))
+            c1 = self.pos()
+            for k in range(int(r.integers(2, 6))):
+                objs.append(self.one(c1, 0.3 + 0.25 * k, m=self.surface[3]))
+            for _ in range(int(r.integers(0, 12))):
+                objs.append(self.one(self.pos(), float(r.choice([1e-6, 1e-4, 1e-3]))))
+            if r.uniform() < 0.3:
+                objs.append(self.one((5.0, 5.0, 5.0), float(r.choice([40.0, 400.0, 4000.0])), m=self.surface[3]))
         if r.uniform() < 0.6:
             R = float(r.choice([1.0e3, 1.0e4, 1.0e5]))
             objs.append(self.one((5.0, -R, 5.0), R))                                # the ground
@@ -191,10 +205,10 @@ class SphereCrowd(Gen):
         return desc, cam, params(32, 24, 3, max_depth=int(r.choice([3, 12, 50])), seed=int(r.integers(1, 1000)), **kw)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(60))
 def test_exact_retree_on_sphere_crowds_is_the_handed_over_tree_per_sample(seed, oracle, emu, built, monkeypatch):
     import emu_ffi
-    desc, cam, p = SphereCrowd(7000 + seed).build()
+    desc, cam, p = SphereCrowd(7000 + seed, nasty=seed >= 40).build()
     img_o, ps_o = oracle.render_samples(desc, cam, p)
     desc.contents.flags = ffi.VK_SCENE_REFERENCE_TREE
     img_r, ps_r, steps_r, info_r = emu.render_samples(desc, cam, p)
