@@ -33,6 +33,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -156,6 +157,7 @@ struct vk_scene {
     uint2 *redo_list = nullptr; size_t redo_bytes = 0;
     uint32_t *redo_count = nullptr;
     bool redo_last = false;        // the last render had a second launch
+    unsigned long long *wave_times = nullptr;      // VK_WAVE_TIMES=1 (diagnostics)
     bool exact_off = false;        // the second launch took more than a quarter of a frame's samples: the scene renders on the tree as
                                    // handed over from then on (vk_scene_last_requeued_samples)
     uint64_t redo_last_samples = 0;    // samples of the partition the last render covered
@@ -424,6 +426,13 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     A.tile_rank = g.rank; A.tile_world = g.world;
     A.n_local_tiles = g.n_local;
     A.n_chunks = choose_chunks(s, p);
+#ifdef VK_WAVE_TIMES
+    if (getenv("VK_WAVE_TIMES")) {
+        if (!s->wave_times) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->wave_times), 3u * 1024u * 16u * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(s->wave_times, 0, 3u * 1024u * 16u * sizeof(unsigned long long), st));
+        A.wave_times = s->wave_times;
+    }
+#endif
     A.counter = s->counter;
     A.clamped = reinterpret_cast<unsigned long long *>(s->counter) + 1;     // bytes 8..15 of the counter block
     A.launch_units = s->counter + 4;                                         // bytes 16..23: units pulled by each launch of a dual launch
@@ -607,7 +616,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
             (uint32_t)s->num_cus * s->wgs_per_cu * waves_per_wg);
         HIP_TRY(hipMemsetAsync(s->counter, 0, sizeof(uint32_t), st));      // the unit counter only: clamped samples and unit counts add up
         KArgs B = A;
-        B.S = s->ref_view; B.list_mode = 1u; B.tile_order = nullptr;
+        B.S = s->ref_view; B.list_mode = 1u; B.tile_order = nullptr; B.wave_times = nullptr;
         if (lds) B.lds_items = B.S.n_items;
         B.shade_defer = SHADE_DEFER; B.prim_weight = s->hot_bytes > (4u << 20) ? 3u : 1u;
         rc = launch_by_features(s, F, B, lds, dim3((uint32_t)s->num_cus * s->wgs_per_cu), shmem, st, false);
@@ -952,6 +961,19 @@ int vk_scene_last_kernel_ms(vk_scene *s, double *ms_out) {
     }
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipEventSynchronize(s->ev1));
+    if (s->wave_times && s->parts.empty()) {      // diagnostics: when the waves of the last render's FIRST launch started, pulled their last unit and ended
+        std::vector<unsigned long long> w(3u * 1024u * 16u);
+        HIP_TRY(hipMemcpy(w.data(), s->wave_times, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0; std::vector<double> ends, lasts;
+        for (size_t k = 0; k < w.size(); k += 3) if (w[k]) { t0 = std::min(t0, w[k]); t1 = std::max(t1, w[k + 2]); }
+        for (size_t k = 0; k < w.size(); k += 3) if (w[k]) { ends.push_back((double)(w[k + 2] - t0) * 1e-5); lasts.push_back((double)(w[k + 1] - t0) * 1e-5); }
+        std::sort(ends.begin(), ends.end()); std::sort(lasts.begin(), lasts.end());
+        if (!ends.empty()) {
+            auto q = [&](const std::vector<double> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+            fprintf(stderr, "vecchio_amd: %zu waves, span %.2f ms; wave ends (ms): 1%% %.2f 10%% %.2f 50%% %.2f 90%% %.2f 99%% %.2f max %.2f; last unit pull: 50%% %.2f 99%% %.2f max %.2f\n",
+                ends.size(), (double)(t1 - t0) * 1e-5, q(ends, 0.01), q(ends, 0.1), q(ends, 0.5), q(ends, 0.9), q(ends, 0.99), ends.back(), q(lasts, 0.5), q(lasts, 0.99), lasts.back());
+        }
+    }
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     *ms_out = (double)ms;

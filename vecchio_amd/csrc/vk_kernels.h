@@ -61,6 +61,8 @@ struct KArgs {
     // redo_list == null: nothing is dropped
     // (the probe launch, scenes without a rebuilt tree).
     uint2 *redo_list; uint32_t *redo_count; const uint32_t *redo_plan; uint32_t redo_region_cap; uint32_t list_mode;
+    // diagnostic builds (-DVK_WAVE_TIMES, with the environment's VK_WAVE_TIMES=1): per wave {start, last unit pull, end}, 100 MHz ticks
+    unsigned long long *wave_times;
 };
 constexpr uint32_t REDO_REGIONS = 512u;
 constexpr uint32_t REDO_COUNT_STRIDE = 16u;        // uint32 words between two regions' counters
@@ -437,6 +439,10 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool e
                 if (total == 0u) continue;                      // an empty slice: the next unit
             } else {
             const uint32_t n_chunks = KARG(P, n_chunks);
+#ifdef VK_WAVE_TIMES
+            { unsigned long long *wt = KARG(P, wave_times);
+              if (wt && lane == 0) wt[3u * ((blockIdx.x + (blockDim.x == 1024u ? 0u : gridDim.x)) * 16u + (threadIdx.x >> 6)) + 1u] = wall_clock64(); }
+#endif
             if (unit >= KARG(P, n_local_tiles) * n_chunks) {                      // the launch's units are all handed out:
                 need = false;                                                     // these lanes idle until the wave's last path ends
                 break;
@@ -580,6 +586,10 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             __syncthreads();
         }
     }
+#ifdef VK_WAVE_TIMES          // (diagnostic builds only, tests/build_exp.sh -DVK_WAVE_TIMES: the stores cost the production kernels 1 %)
+    { KArgsC P = kargs_fresh(); unsigned long long *wt = KARG(P, wave_times);
+      if (wt && lane == 0) wt[3u * ((blockIdx.x + (blockDim.x == 1024u ? 0u : gridDim.x)) * 16u + wave)] = wall_clock64(); }
+#endif
     // the wave has no unit yet: the first SHADE + REFILL phase pulls one
     tile_sum[lane * 3 + 0] = 0ull; tile_sum[lane * 3 + 1] = 0ull; tile_sum[lane * 3 + 2] = 0ull;
     if (lane == 0) { wstate[WS_TXY] = 0xFFFFFFFFu; wstate[WS_NEXT] = 0u; wstate[WS_TOTAL] = 0u; }
@@ -776,6 +786,10 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
     }
     {   // the last unit's sums
         KArgsC P = kargs_fresh();
+#ifdef VK_WAVE_TIMES
+        unsigned long long *wt = KARG(P, wave_times);
+        if (wt && lane == 0) wt[3u * ((blockIdx.x + (blockDim.x == 1024u ? 0u : gridDim.x)) * 16u + wave) + 2u] = wall_clock64();
+#endif
         flush_tile_sums(tile_sum, KARG(P, accum), __builtin_amdgcn_readfirstlane(wstate[WS_TXY]), lane, KARG(P, C.width),
             KARG(P, C.height));
     }
