@@ -261,8 +261,8 @@ void plan_residency(vk_scene *s, size_t hot) {
     if (best_waves >= cap && !s->env.no_lds_scene) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = best_wg * 64; s->wgs_per_cu = best_n;
     } else {
-        // 32 (sphere-only, 8 waves/SIMD) or 24 waves per CU
-        s->lds_bytes = 0; s->wg_threads = spheres_only ? 512 : 256; s->wgs_per_cu = spheres_only ? 4 : 6;
+        // 28 (sphere-only: seven 4-wave workgroups, 7 waves/SIMD) or 24 waves per CU
+        s->lds_bytes = 0; s->wg_threads = 256; s->wgs_per_cu = spheres_only ? 7 : 6;
     }
 }
 
@@ -276,10 +276,12 @@ int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shme
     // 5 / 6
     // (13 spilled registers, 25 scratch instructions outside the box loop, shading out of line) and 695 at 7 (27 registers, 154).
     constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? MINW_SPHERES : 6;
-    // Sphere-only scenes traversed from GLOBAL memory (C5, 49 MB of items and spheres) run at 8 waves per SIMD / 64 VGPRs with the
-    // shading phase out of line: every box step is a dependent gather there, and once no NaN ray walks the whole tree any more
-    // (vk_trace.h begin_segment) more waves in flight are worth 9 % (629 -> 685 Msamples/s; with the NaN walks it was -5 %).
-    constexpr int MINW_G = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? 8 : MINW;
+    // Sphere-only scenes traversed from GLOBAL memory (C5, 49 MB of items and spheres): every box step is a dependent gather there, so
+    // waves in flight pay.  On the tree handed over 8 waves per SIMD / 64 VGPRs with the shading phase out of line were best (629 -> 685
+    // Msamples/s over 6); on the rebuilt tree of exact re-treeing the walks are half as long and the 64-VGPR build's spills (72 B of
+    // scratch per lane, 2 TB per frame) weigh more than the eighth wave: 6 / 7 / 8 waves per SIMD -> 1 112 / 1 163 / 1 076 Msamples/s.
+    // Seven: 72 VGPRs, shading inline, seven 256-thread workgroups per CU.
+    constexpr int MINW_G = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? 7 : MINW;
     auto go = [&](auto kernel) -> int {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL(kernel, grid, dim3(s->wg_threads), shmem, st, A);
