@@ -732,9 +732,9 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             // ---- SHADE + REFILL
             if (STATS) { st_shade_execs++; st_shade_lanes += n_sn; st_t0 = clock64(); }
             // out of line for the everything-variants (see shade_refill_call); one begin_segment for both kinds of new ray
-            // ... and for the 8-waves-per-SIMD build of the sphere-only variants (scenes traversed from global memory: every box step a
-            // dependent gather, so more waves in flight pay — C5 629 -> 685 Msamples/s — and 64 VGPRs hold the traversal loops but not
-            // shading)
+            // ... and for an 8-waves-per-SIMD build of the sphere-only variants (64 VGPRs hold the traversal loops but not shading), which
+            // global-memory scenes ran until exact re-treeing halved their walks: now seven waves with the phase inline (vk_api.hip
+            // launch_variant), and no instance of the kernel has MINW == 8
             constexpr bool SPLIT = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE || MINW == 8) && !STATS;
             const bool is_shade = __builtin_amdgcn_inverse_ballot_w64(m_shade);
             bool touched = false, fresh = false;
