@@ -4,7 +4,11 @@ the tree over such objects — except for EXACT ties in t, where the reference's
 hittable.rs:232, Sphere::hit's strict one :75, the list scan's strict one :386, BVHNode::hit's `l.t < r.t` accel.rs:73)
 is reproduced from the objects' positions in the reference's visiting order.  These scenes are crowds of such objects with
 deliberately coincident geometry (every hit of a duplicated object is an exact tie between two materials), in random tree
-shapes, and the kernel's formulation must agree with the recursive oracle on every sample — with and without re-treeing."""
+shapes, and the kernel's formulation must agree with the recursive oracle on every sample — with and without re-treeing.
+
+Exact re-treeing (the default for worlds of spheres only; vk_trace.h winner_is_early) is tested further down:
+SphereCrowd worlds, the stress scenes, the headline scene — every sample must be the handed-over tree's, bit for bit, in both of the
+device's forms (whole samples rendered again for scenes staged in LDS, segments walked again in place for scenes in global memory)."""
 import os
 
 import numpy as np
