@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 4   /* 4: exact re-treeing by default (vk_scene_desc.flags), VK_SCENE_REFERENCE_TREE, vk_scene_last_requeued_samples */
+#define VK_ABI_VERSION 5   /* 5: rebuilt trees by default only where their exactness is proven; VK_SCENE_EMPIRICAL_TREES; vk_scene_info.tree */
 
 /* ---- status codes (reference convention is panic!/unwrap, main.rs:166,202) ---------- */
 enum {
@@ -179,21 +179,32 @@ typedef struct vk_scene_desc {
 
 /* vk_scene_desc.flags.
  * 0 (default): every result is the one BVHNode::hit (accel.rs:58-83) gives on the tree handed over.  The library walks that tree,
- * with one exception: a world of spheres only is walked on a tree REBUILT over the reference's leaf units (every object stays gated by
- * its parent node's box, exactly as handed over), and every segment whose closest hit could depend on the visiting order — a hit
- * computed to lie before its box entry — is decided on the tree as handed over (walked again, or its sample rendered by a second
- * launch): "exact re-treeing", DESIGN.md §5.  Frames are bit-identical to VK_SCENE_REFERENCE_TREE's.
- * VK_SCENE_REFERENCE_TREE: walk the tree handed over and nothing else (no exact re-treeing).
+ * with one exception: a world of spheres only may be walked on a tree REBUILT over the reference's leaf units, "exact re-treeing"
+ * (DESIGN.md section 5).  Every object stays gated by the box the reference gates it with, grown by a bound on how far off its sphere
+ * an f32 Sphere::hit (hittable.rs:65-95) can report a hit; the rebuilt walk then finds every hit the reference's walk can accept,
+ * and whenever its winner is not certain to be the reference's too — a hit not safely behind its own box's entry, a ray from outside
+ * the region the bound was derived for — the tree as handed over decides (the segment is walked again, or its sample is rendered by
+ * a second launch).  That this reproduces BVHNode::hit is a THEOREM given the bound (the "gate lemma"; forward error analysis, K < 30
+ * against the 32 used; tests/test_gate_lemma.py attacks it with 10^7 adversarial rays).  The grown boxes are used only where they are
+ * cheap (vk_scene_info.tree == VK_TREE_REBUILT_PROVEN: the InOneWeekend scene, +28 % throughput); a world whose reference tree has
+ * very long leaf boxes (BVHNode::new's random axes on the 1 M-sphere stress scene) is walked as handed over.
+ * VK_SCENE_REFERENCE_TREE: walk the tree handed over and nothing else.
+ * VK_SCENE_EMPIRICAL_TREES: allow the rebuilt tree also where the grown boxes would be too dear — with the units' boxes as handed
+ * over and the closest hit so far padded by 1/16 instead.  NOT proven: a hit that precedes its unit's box entry by more than 1/16 and,
+ * in the reference's visiting order only, wins against a hit inside that gap is missed.  It takes a ray that grazes a sphere where the
+ * sphere touches its box, within ~1e-5 of parallel to that face of a long box; tests/test_gate_lemma.py constructs one and shows the
+ * wrong result.  Measured on natural frames: 0 differing pixels in 12.6 G samples (40 worlds, profiles/r03/exact_retree_seeds.log);
+ * the 1 M-sphere stress scene runs 1.7x faster than on the tree handed over.
  * VK_SCENE_FAST_ACCEL: the library may rebuild the acceleration structure over subtrees whose objects are all
- * Sphere / Rect / Boxy / lists of those (no ConstantMedium, no transform, no negative-radius sphere): BVHNode::hit's result
- * (accel.rs:58-83) does not depend on the tree over such objects, and exact ties in t are resolved as the reference resolves
- * them.  What it cannot reproduce is floating-point noise: a Sphere::hit quadratic that reports a hit a hair OUTSIDE the
- * sphere's own bounding box (small far spheres in f32) is found or not depending on which enclosing boxes a tree happens to
- * have — in the reference as much as here, whose own tree is random (accel.rs:99-100).  Measured: the InOneWeekend scene's full
- * 1920x1080x1024-spp frame (2.1 G samples) is bit-identical with and without the flag (+28 % throughput); on the 1 M-sphere
- * stress scene 0.19 % of the samples differ — exactly as many as between two reference-style trees over the same world
- * (profiles/r03/tree_variation.log).  Off by default: it does not match a seeded reference run sample for sample. */
-enum { VK_SCENE_FAST_ACCEL = 1, VK_SCENE_REFERENCE_TREE = 2 };
+ * Sphere / Rect / Boxy / lists of those (no ConstantMedium, no transform, no negative-radius sphere), object by object:
+ * BVHNode::hit's result does not depend on the tree over such objects in exact arithmetic, and exact ties in t are resolved as the
+ * reference resolves them.  What it cannot reproduce is floating-point noise: an f32 Sphere::hit that reports a hit OUTSIDE the
+ * sphere's own bounding box is found or not depending on which enclosing boxes a tree happens to have — in the reference as much
+ * as here, whose own tree is random (accel.rs:99-100).  Measured: the InOneWeekend scene's full 1920x1080x1024-spp frame is
+ * bit-identical with and without the flag; on the 1 M-sphere stress scene 0.19 % of the samples differ — as many as between two
+ * reference-style trees over the same world (profiles/r03/tree_variation.log).  Does not match a seeded reference run sample for
+ * sample. */
+enum { VK_SCENE_FAST_ACCEL = 1, VK_SCENE_REFERENCE_TREE = 2, VK_SCENE_EMPIRICAL_TREES = 4 };
 
 /* ---- camera: the ten fields of main.rs:57-68, computed by Camera::new on the host --- */
 typedef struct vk_camera {
@@ -307,7 +318,14 @@ typedef struct vk_scene_info {
     uint64_t device_bytes;
     uint32_t lds_bytes;        /* bytes staged into LDS per workgroup (0 = not resident) */
     uint32_t features;         /* VKF_* mask of the kernel variant selected */
+    uint32_t tree;             /* VK_TREE_*: what the world is walked on (ABI 5; see vk_scene_desc.flags) */
 } vk_scene_info;
+enum {
+    VK_TREE_HANDED_OVER = 0,        /* the tree of the description, item for item */
+    VK_TREE_REBUILT_PROVEN = 1,     /* exact re-treeing with grown gates: results proven to be the handed-over tree's */
+    VK_TREE_REBUILT_EMPIRICAL = 2,  /* exact re-treeing without them (VK_SCENE_EMPIRICAL_TREES): measured, not proven */
+    VK_TREE_REBUILT_FAST = 3        /* VK_SCENE_FAST_ACCEL */
+};
 int vk_scene_get_info(const vk_scene *scene, vk_scene_info *out);
 
 /* HIP-event time (ms) of the launches enqueued by the last vk_render / vk_render_device on
@@ -318,8 +336,7 @@ int vk_scene_last_kernel_ms(vk_scene *scene, double *ms_out);
 /* see vk_stats.clamped_samples; waits for the end of the last render enqueued on this scene */
 int vk_scene_last_clamped_samples(vk_scene *scene, uint64_t *count_out);
 /* Exact re-treeing (see vk_scene_desc.flags): samples of the last render that were rendered by the second launch, on the tree as
- * handed over; waits for the render's end.  Returns VK_ERR_OOM when the queues between the two launches overflowed: that frame is
- * incomplete (vk_render reports the same). */
+ * handed over; waits for the render's end. */
 int vk_scene_last_requeued_samples(vk_scene *scene, uint64_t *count_out);
 
 /* test/diagnostic entry points (vk_debug_*) are declared in vecchio_amd_debug.h */

@@ -25,6 +25,10 @@ static std::atomic<uint64_t> g_redo(0), g_segments(0);      // exact re-treeing:
 static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string &err) {
     LinearizeOptions opt;
     if (const char *e = getenv("VK_RETREE")) opt.retree = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+    if (const char *e = getenv("VK_GATE_GROW")) opt.gate_grow = e[0] != '0';
+    if (const char *e = getenv("VK_T_PAD")) opt.t_pad = (float)atof(e);
+    if (const char *e = getenv("VK_GATE_PROOF")) { opt.want_proof = e[0] != '0'; if (!opt.want_proof) opt.allow_empirical = true; }
+    if (const char *e = getenv("VK_EMPIRICAL_TREES")) opt.allow_empirical = e[0] == '1';
     return linearize(desc, LS, err, opt);
 }
 // EMU_GLOBAL_VARIANT=1: scenes of spheres only as the device runs them from GLOBAL memory (unfused box test; exact re-treeing with both
@@ -62,7 +66,7 @@ static void trace_one(const DScene &S, const GlobalMem &M0, const RenderConsts &
     bool on_ref = false;      // the segment just walked was walked on the tree as handed over
     for (;;) {
         while (traversing(L)) { traverse_step<F, Mem>(L, S, M); if (steps) (*steps)++; }
-        const bool early = !on_ref && winner_is_early<F, Mem>(L, S, M);
+        const bool early = !on_ref && segment_unsafe<F, Mem>(L, S, M);
         if (getenv("EMU_TRACE")) fprintf(stderr, "  seg depth %u o (%.9g %.9g %.9g) d (%.9g %.9g %.9g) T %.9g prim %08x early %d on_ref %d t_pad %g\n", L.depth,
             L.o.x, L.o.y, L.o.z, L.d.x, L.d.y, L.d.z, L.T, L.best_prim, (int)early, (int)on_ref, S.t_pad);
         on_ref = false;
@@ -271,6 +275,222 @@ void emu_box_decisions(const float *boxes, const float *rays, size_t n, uint8_t 
 void emu_box_decisions_rcp(const float *boxes, const float *rays, size_t n, uint8_t *decisions, int fused, uint32_t perturb) {
     if (fused) box_decisions<0u, true>(boxes, rays, n, decisions, perturb);
     else box_decisions<VKF_ALL_SCENE, false>(boxes, rays, n, decisions, perturb);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ the gate lemma of exact re-treeing, attacked
+// with the kernel's own arithmetic (vk_trace.h sphere_t_tie, slab_exact) and the lineariser's own bound (vk_linearize.h rt_eta,
+// rt_unit_growth).  tests/test_gate_lemma.py drives these.
+namespace {
+struct Lcg {        // splitmix-style stream: reproducible, no <random> distributions whose output differs between libraries
+    uint64_t s;
+    explicit Lcg(uint64_t seed) : s(vk::mix64(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull)) {}
+    uint64_t next() { return vk::mix64(s += 0x9E3779B97F4A7C15ull); }
+    double uni() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+    double log_uni(double lo, double hi) { return std::exp(std::log(lo) + uni() * (std::log(hi) - std::log(lo))); }
+};
+// the candidate of Sphere::hit (hittable.rs:65-95): the root it reports when tmax = +inf
+bool candidate(const float c[3], float r, V3 o, V3 d, float &t) {
+    bool tie;
+    return sphere_t_tie(c[0], c[1], c[2], r, o, d, length2(d), T_MIN, INFINITY, t, tie);
+}
+typedef long double LD;
+}  // namespace
+
+extern "C" {
+
+// Part A.  K = |dist(H, centre) - R| * R / (u (rho + R)^2) of both roots, H = o + t d in extended precision: the largest over n
+// pseudo-random configurations (near, far, inside, grazing, axis-parallel) followed by `climb` steps of bit-level hill climbing from the
+// worst one.  The lemma's constant is RT_KAPPA / u = 32.
+double emu_lemma_residual(uint64_t n, uint64_t seed, uint64_t climb) {
+    const LD U = ldexpl(1.0L, -24);
+    struct Case { float c[3], r, o[3], d[3]; };
+    auto keff = [&](const Case &k) -> LD {
+        V3 o = v3(k.o[0], k.o[1], k.o[2]), d = v3(k.d[0], k.d[1], k.d[2]);
+        const float a = length2(d);
+        V3 oc = o - v3(k.c[0], k.c[1], k.c[2]);
+        const float half_b = dot(oc, d), c = length2(oc) - k.r * k.r, disc = half_b * half_b - a * c;
+        if (!(disc > 0.0f)) return 0;
+        const float root = sqrtf(disc);
+        const float ts[2] = {(-half_b - root) / a, (-half_b + root) / a};
+        const LD ocx = (LD)k.o[0] - k.c[0], ocy = (LD)k.o[1] - k.c[1], ocz = (LD)k.o[2] - k.c[2];
+        const LD rho = sqrtl(ocx * ocx + ocy * ocy + ocz * ocz);
+        LD best = 0;
+        for (float t : ts) {
+            if (!(t > T_MIN) || !std::isfinite(t)) continue;
+            const LD hx = ocx + (LD)t * k.d[0], hy = ocy + (LD)t * k.d[1], hz = ocz + (LD)t * k.d[2];
+            const LD q = fabsl(sqrtl(hx * hx + hy * hy + hz * hz) - k.r) * k.r / (U * (rho + k.r) * (rho + k.r));
+            if (q > best) best = q;
+        }
+        return best;
+    };
+    Lcg g(seed);
+    LD worst = 0; Case wc{};
+    for (uint64_t it = 0; it < n; it++) {
+        Case k;
+        const double R = g.log_uni(1e-3, 1e5);
+        const double cm = g.uni() < 0.3 ? 0.0 : g.log_uni(1e-2, 1e5);
+        double cd[3] = {g.uni() - .5, g.uni() - .5, g.uni() - .5};
+        const double cn = std::sqrt(cd[0] * cd[0] + cd[1] * cd[1] + cd[2] * cd[2]) + 1e-30;
+        for (int a = 0; a < 3; a++) k.c[a] = (float)(cd[a] / cn * cm);
+        k.r = (float)R;
+        const int mode = (int)(g.uni() * 5);
+        double m = mode == 0 ? g.log_uni(1.0 + 1e-7, 1.01) : (mode == 1 ? g.log_uni(1e-3, 1.0) : (mode == 2 ? g.log_uni(1.0, 100.0) : g.log_uni(1.0, 1e4)));
+        if (mode == 4) m = 1.0;
+        double od[3] = {g.uni() - .5, g.uni() - .5, g.uni() - .5};
+        if (g.uni() < 0.2) od[(int)(g.uni() * 3) % 3] = 0.0;
+        const double on = std::sqrt(od[0] * od[0] + od[1] * od[1] + od[2] * od[2]) + 1e-30;
+        for (int a = 0; a < 3; a++) k.o[a] = (float)((double)k.c[a] + od[a] / on * m * R);
+        const double p = g.uni() < 0.5 ? (1.0 + (g.uni() - 0.5) * g.log_uni(1e-9, 1e-1)) : g.uni() * 1.05;      // perpendicular offset / R
+        double e1[3] = {g.uni() - .5, g.uni() - .5, g.uni() - .5};
+        const double dp = (e1[0] * od[0] + e1[1] * od[1] + e1[2] * od[2]) / (on * on);
+        for (int a = 0; a < 3; a++) e1[a] -= dp * od[a];
+        const double en = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) + 1e-30;
+        double dd[3];
+        for (int a = 0; a < 3; a++) dd[a] = (double)k.c[a] + e1[a] / en * p * R - k.o[a];
+        const double dn = std::sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]) + 1e-30, dl = g.log_uni(1e-3, 1e3);
+        for (int a = 0; a < 3; a++) k.d[a] = (float)(dd[a] / dn * dl);
+        const LD q = keff(k);
+        if (q > worst) { worst = q; wc = k; }
+    }
+    for (uint64_t it = 0; it < climb; it++) {
+        Case nx = wc;
+        float *f = reinterpret_cast<float *>(&nx);
+        const int idx = (int)(g.uni() * 10);
+        uint32_t b; memcpy(&b, &f[idx], 4);
+        int step = (int)(g.uni() * 64) - 32; if (g.uni() < 0.3) step *= 1000;
+        b += (uint32_t)step; memcpy(&f[idx], &b, 4);
+        if (!std::isfinite(f[idx]) || !(nx.r > 0.0f)) continue;
+        const LD q = keff(nx);
+        if (q > worst) { worst = q; wc = nx; }
+    }
+    return (double)worst;
+}
+
+// Part B.  Units of two spheres of radius 0.2 (the second one `len` away: long units are what strains the gate), their box as
+// BVHNode::new computes it; rays from inside the trusted ball (centre = the first sphere's, radius ball_r0) aimed to GRAZE the first
+// sphere near the top face of its box, nearly parallel to it (the configuration in which a hit can precede the box entry by the most),
+// and rays aimed anywhere at the unit.  For every ray that passes the unit's box as handed over and has a candidate on the first
+// sphere — i.e. that BVHNode::hit can accept — the gate must pass with tmax = next(t) (1 + pad): counts = {such rays, gates that
+// failed}.  grow != 0: the gate's box is the unit's grown by rt_unit_growth (the proven form), else the unit's own (the empirical form).
+// viol = the failing case with the largest relative earliness: c1(3) r1 c2(3) r2 o(3) d(3) t entry llc(3).
+int emu_gate_soundness(uint64_t n, uint64_t seed, int grow, float pad, double ball_r0, uint64_t counts[2], float viol[19]) {
+    Lcg g(seed);
+    counts[0] = counts[1] = 0;
+    double worst = 0.0;
+    for (uint64_t it = 0; it < n; it++) {
+        const float R = 0.2f;
+        const double len = g.log_uni(0.5, 120.0);
+        float c[2][3] = {{0.0f, 0.2f, 0.0f}, {(float)len, 0.2f, (float)((g.uni() - 0.5) * 2.0)}};
+        float r[2] = {R, R};
+        DItem U; memset(&U, 0, sizeof(U));
+        U.mnx = fminf(c[0][0] - R, c[1][0] - R); U.mxx = fmaxf(c[0][0] + R, c[1][0] + R);
+        U.mny = fminf(c[0][1] - R, c[1][1] - R); U.mxy = fmaxf(c[0][1] + R, c[1][1] + R);
+        U.mnz = fminf(c[0][2] - R, c[1][2] - R); U.mxz = fmaxf(c[0][2] + R, c[1][2] + R);
+        RtDomain dom; dom.c0[0] = c[0][0]; dom.c0[1] = c[0][1]; dom.c0[2] = c[0][2]; dom.r0 = ball_r0;
+        DItem G = U;
+        if (grow) {
+            const float mn[3] = {U.mnx, U.mny, U.mnz}, mx[3] = {U.mxx, U.mxy, U.mxz};
+            const double gd = rt_unit_growth(mn, mx, 2, c, r, dom, pad);
+            if (gd < 0.0) continue;                        // (the lineariser would shrink the ball)
+            const float gg = std::nextafter((float)gd, INFINITY);
+            G.mnx = std::nextafter(U.mnx - gg, -INFINITY); G.mxx = std::nextafter(U.mxx + gg, INFINITY);
+            G.mny = std::nextafter(U.mny - gg, -INFINITY); G.mxy = std::nextafter(U.mxy + gg, INFINITY);
+            G.mnz = std::nextafter(U.mnz - gg, -INFINITY); G.mxz = std::nextafter(U.mxz + gg, INFINITY);
+        }
+        // the ray
+        V3 o, d;
+        const double rho = g.log_uni(1.0, ball_r0 * 0.999);
+        if (g.uni() < 0.8) {
+            // through P, just above (or below) the top of the first sphere, descending slowly along +x
+            const double delta = (g.uni() < 0.5 ? 1.0 : -1.0) * g.log_uni(1e-8, 0.5) * R;
+            const double P[3] = {(g.uni() - 0.5) * 0.4, 0.4 + delta, (g.uni() - 0.5) * 0.4};
+            const double theta = g.log_uni(1e-7, 0.3), zs = (g.uni() - 0.5) * g.log_uni(1e-6, 0.1);
+            double dir[3] = {1.0, -theta, zs};
+            const double dn = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+            const double dl = g.log_uni(1e-2, 1e2);
+            o = v3((float)(P[0] - dir[0] / dn * rho), (float)(P[1] - dir[1] / dn * rho), (float)(P[2] - dir[2] / dn * rho));
+            d = v3((float)(dir[0] / dn * dl), (float)(dir[1] / dn * dl), (float)(dir[2] / dn * dl));
+        } else {
+            double od[3] = {g.uni() - .5, g.uni() - .5, g.uni() - .5};
+            const double on = std::sqrt(od[0] * od[0] + od[1] * od[1] + od[2] * od[2]) + 1e-30;
+            o = v3((float)(c[0][0] + od[0] / on * rho), (float)(c[0][1] + od[1] / on * rho), (float)(c[0][2] + od[2] / on * rho));
+            const double tgt[3] = {c[0][0] + (g.uni() - .5) * 0.44, c[0][1] + (g.uni() - .5) * 0.44, c[0][2] + (g.uni() - .5) * 0.44};
+            const double dl = g.log_uni(1e-2, 1e2);
+            double dd[3] = {tgt[0] - o.x, tgt[1] - o.y, tgt[2] - o.z};
+            const double dn = std::sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]) + 1e-30;
+            d = v3((float)(dd[0] / dn * dl), (float)(dd[1] / dn * dl), (float)(dd[2] / dn * dl));
+        }
+        // (a direction a camera can produce: lower_left_corner - origin in f32, main.rs:115-119 — so that a failing ray can be rendered)
+        const V3 llc = v3(o.x + d.x, o.y + d.y, o.z + d.z);
+        d = v3(llc.x - o.x, llc.y - o.y, llc.z - o.z);
+        {   // inside the trusted ball (after the rounding of o)
+            const double ox = o.x - dom.c0[0], oy = o.y - dom.c0[1], oz = o.z - dom.c0[2];
+            if (!(ox * ox + oy * oy + oz * oz <= ball_r0 * ball_r0 * 0.998)) continue;
+        }
+        float t;
+        if (!candidate(c[0], R, o, d, t)) continue;
+        if (!slab_exact(U, o, d, T_MIN, INFINITY)) continue;          // BVHNode::hit never tests the unit for this ray
+        counts[0]++;
+        const float T = nextafter_up(t);
+        if (slab_exact(G, o, d, T_MIN, T * (1.0f + pad))) continue;
+        counts[1]++;
+        // how early: the entry into the unit's box against t
+        float lo = T_MIN;
+        { const float q0 = (U.mnx - o.x) / d.x, q1 = (U.mxx - o.x) / d.x; lo = fmaxf(fminf(q0, q1), lo); }
+        { const float q0 = (U.mny - o.y) / d.y, q1 = (U.mxy - o.y) / d.y; lo = fmaxf(fminf(q0, q1), lo); }
+        { const float q0 = (U.mnz - o.z) / d.z, q1 = (U.mxz - o.z) / d.z; lo = fmaxf(fminf(q0, q1), lo); }
+        double early = (double)lo / (double)t - 1.0;
+        // (preferred for rendering: ordinary magnitudes — a direction of length 1..10, a hit a few units away, early by a factor of 3+)
+        if (length2(d) > 1.0f && length2(d) < 100.0f && t > 1.0f && t < 6.0f && early > 3.0 && early < 50.0) early += 1.0e6;
+        if (early > worst && viol) {
+            worst = early;
+            const float v[19] = {c[0][0], c[0][1], c[0][2], R, c[1][0], c[1][1], c[1][2], R, o.x, o.y, o.z, d.x, d.y, d.z, t, lo,
+                llc.x, llc.y, llc.z};
+            memcpy(viol, v, sizeof(v));
+        }
+    }
+    return 0;
+}
+
+// closest hit of ONE segment as the device decides it (rebuilt walk, segment_unsafe, the tree as handed over where needed):
+// out = {T, best_prim (bits), 1 if the tree as handed over decided}
+int emu_hit(const vk_scene_desc *desc, const float o[3], const float d[3], float out[3]) {
+    LinearScene LS;
+    int st = linearize_env(desc, LS, g_err);
+    if (st != VK_OK) return st;
+    if (LS.features != 0u) { g_err = "emu_hit: scenes of spheres only"; return VK_ERR_UNSUPPORTED; }
+    std::vector<DItem> both;
+    DScene S = scene_view(LS, both);
+    const bool glob = global_variant();
+    auto run = [&](auto mem_tag) {
+        using Mem = decltype(mem_tag);
+        Mem M; static_cast<GlobalMem &>(M) = GlobalMem{S.items, S.spheres, S.sphere_mat, S.boxes};
+        Lane L; memset(&L, 0, sizeof(L));
+        begin_segment<Mem::ISHIFT, fused_box<0u, Mem>()>(L, S, v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), 0.0f);
+        while (traversing(L)) {
+            const uint32_t before = L.pend; const float Tb = L.T;
+            traverse_step<0u, Mem>(L, S, M);
+            if (getenv("EMU_TRACE") && before != 0u) fprintf(stderr, "  leaf objects %08x: T %.9g -> %.9g\n", before, Tb, L.T);
+        }
+        float redo = 0.0f;
+        if (segment_unsafe<0u, Mem>(L, S, M)) {
+            redo = 1.0f;
+            if (S.walk_start != 0u) {
+                begin_segment<Mem::ISHIFT, fused_box<0u, Mem>()>(L, S, L.o, L.d, L.time, true);
+                while (traversing(L)) traverse_step<0u, Mem>(L, S, M);
+            } else {
+                DScene Sr = reference_view(S);
+                Mem Mr; static_cast<GlobalMem &>(Mr) = GlobalMem{Sr.items, Sr.spheres, Sr.sphere_mat, Sr.boxes};
+                begin_segment<Mem::ISHIFT, fused_box<0u, Mem>()>(L, Sr, v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), 0.0f);
+                while (traversing(L)) traverse_step<0u, Mem>(L, Sr, Mr);
+            }
+        }
+        out[0] = L.T; memcpy(&out[1], &L.best_prim, 4); out[2] = redo;
+    };
+    if (glob) run(GlobalMem{}); else run(FusedMem{});
+    return VK_OK;
 }
 
 }  // extern "C"

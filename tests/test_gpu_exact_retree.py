@@ -1,4 +1,4 @@
-"""-m gpu: exact re-treeing (vk_trace.h winner_is_early; include/vecchio_amd.h vk_scene_desc.flags) through the C ABI.  A scene of spheres
+"""-m gpu: exact re-treeing (vk_trace.h segment_unsafe; include/vecchio_amd.h vk_scene_desc.flags) through the C ABI.  A scene of spheres
 only is rendered on a tree rebuilt over the reference's leaf units (accel.rs:98-136 builds the units, accel.rs:58-83 gates each object
 by its unit's box); the tree as handed over decides wherever the winner of a segment could depend on the visiting order.  The image
 must be the handed-over tree's bit for bit: pixel sums are order independent, so it is unless some SAMPLE took another path."""
@@ -31,12 +31,17 @@ def render(name, w, spp, flags, tile=None):
     return img, st, rq.value, info
 
 
-@pytest.mark.parametrize("name,w,spp,in_lds", [("random_spheres_iow", 640, 96, True), ("stress_spheres:150", 512, 12, False),
-                                               ("stress_spheres:30", 384, 24, False)])
-def test_exact_retree_image_is_the_handed_over_trees(name, w, spp, in_lds, device):
+# (the stress scenes' reference trees have leaf boxes too long for grown gates: rebuilt only on request, in the empirical form)
+@pytest.mark.parametrize("name,w,spp,in_lds,flags,tree", [
+    ("random_spheres_iow", 640, 96, True, 0, ffi.VK_TREE_REBUILT_PROVEN),
+    ("random_spheres_iow", 640, 96, True, ffi.VK_SCENE_EMPIRICAL_TREES, ffi.VK_TREE_REBUILT_PROVEN),
+    ("stress_spheres:150", 512, 12, False, ffi.VK_SCENE_EMPIRICAL_TREES, ffi.VK_TREE_REBUILT_EMPIRICAL),
+    ("stress_spheres:30", 384, 24, False, ffi.VK_SCENE_EMPIRICAL_TREES, ffi.VK_TREE_REBUILT_EMPIRICAL)])
+def test_exact_retree_image_is_the_handed_over_trees(name, w, spp, in_lds, flags, tree, device):
     ref, st_r, rq_r, info_r = render(name, w, spp, ffi.VK_SCENE_REFERENCE_TREE)
-    img, st, rq, info = render(name, w, spp, 0)
-    assert rq_r == 0
+    img, st, rq, info = render(name, w, spp, flags)
+    assert rq_r == 0 and info_r.tree == ffi.VK_TREE_HANDED_OVER
+    assert info.tree == tree
     assert bool(st.scene_in_lds) == in_lds
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), int((img != ref).any(axis=2).sum())
     if in_lds:
@@ -45,12 +50,19 @@ def test_exact_retree_image_is_the_handed_over_trees(name, w, spp, in_lds, devic
     else:
         assert rq == 0          # both trees in one array: such segments are walked again in place
     # a tile partition of the frame: the second launch covers this rank's samples only
-    part, st_p, rq_p, _ = render(name, w, spp, 0, tile=(1, 3))
+    part, st_p, rq_p, _ = render(name, w, spp, flags, tile=(1, 3))
     tiles_x = (w + 7) // 8
     yy, xx = np.mgrid[0:ref.shape[0], 0:w]
     mine = ((yy // 8) * tiles_x + xx // 8) % 3 == 1
     assert np.array_equal(part[mine].view(np.uint32), ref[mine].view(np.uint32))
     assert rq_p <= rq
+
+
+def test_stress_scenes_are_walked_as_handed_over_by_default(device):
+    ref, _, _, info_r = render("stress_spheres:30", 256, 8, ffi.VK_SCENE_REFERENCE_TREE)
+    img, _, rq, info = render("stress_spheres:30", 256, 8, 0)
+    assert info.tree == ffi.VK_TREE_HANDED_OVER and info.n_items == info_r.n_items and rq == 0
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
 
 
 def test_a_full_redo_queue_never_yields_an_incomplete_frame(device):
@@ -85,7 +97,7 @@ def test_scene_with_mostly_early_winners_falls_back_to_the_handed_over_tree(devi
             "        rq = C.c_uint64(0); assert lib.vk_scene_last_requeued_samples(ds._h, C.byref(rq)) == 0\n"
             "        out.append((img, rq.value, st.samples, st.scene_in_lds))\n"
             "    return out\n"
-            "ref = frames(ffi.VK_SCENE_REFERENCE_TREE); x = frames(0)\n"
+            "ref = frames(ffi.VK_SCENE_REFERENCE_TREE); x = frames(ffi.VK_SCENE_EMPIRICAL_TREES)\n"
             "print('LDS', x[0][3], 'REQUEUED', x[0][1], x[1][1], 'OF', x[0][2])\n"
             "print('EQUAL', all(np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) for a, b in zip(ref, x)))\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
@@ -95,3 +107,27 @@ def test_scene_with_mostly_early_winners_falls_back_to_the_handed_over_tree(devi
     assert words[words.index("LDS") + 1] == "1"
     assert second == 0, r.stdout          # (the first frame either went through the second launch or, its queues full, was rendered again)
     assert "renders on the tree as handed over from now on" in r.stderr, r.stderr
+
+
+def test_the_constructed_counter_example_on_the_device(device, oracle, monkeypatch):
+    """tests/test_gate_lemma.py part C through the C ABI: 4096 primary rays around a ray that grazes a sphere where it touches its
+    (long) unit's box.  Default and VK_SCENE_REFERENCE_TREE: the oracle's samples.  VK_SCENE_EMPIRICAL_TREES with the scene traversed
+    from global memory (as the 1 M-sphere scene is): some of the rays that hit X in the reference hit Z — the hole the flag's
+    documentation describes (staged in LDS the fused box test's margin sends every such ray to the tree as handed over)."""
+    from test_gate_lemma import window_setup
+    from test_gpu_parity import device_samples
+    monkeypatch.setenv("VK_NO_LDS_SCENE", "1")
+    results = {}
+    for flags in (0, ffi.VK_SCENE_REFERENCE_TREE, ffi.VK_SCENE_EMPIRICAL_TREES):
+        d, desc, cam, p = window_setup(flags)
+        img_o, ps_o = oracle.render_samples(desc, cam, p)
+        ds = DeviceScene(desc)
+        tree = ds.info().tree
+        img_d, ps_d = device_samples(ds, cam, p)
+        ds.close()
+        results[flags] = (tree, int((ps_o[:, :3] != ps_d[:, :3]).any(axis=1).sum()), int((ps_o[:, 0] == 1.0).sum()))
+    print(results)
+    assert results[0][:2] == (ffi.VK_TREE_HANDED_OVER, 0) and results[ffi.VK_SCENE_REFERENCE_TREE][:2] == (ffi.VK_TREE_HANDED_OVER, 0)
+    assert results[0][2] > 1000                                  # the window does see the early hits on X
+    tree, wrong, _ = results[ffi.VK_SCENE_EMPIRICAL_TREES]
+    assert tree == ffi.VK_TREE_REBUILT_EMPIRICAL and wrong > 0

@@ -19,7 +19,7 @@
 //     fit next to that per-wave state WITHOUT costing occupancy, every workgroup stages them into its
 //     LDS (160 KB/CU) once and item fetches are ds_read_b128; otherwise they are L1/L2 gathers;
 //   * scenes of spheres only are walked on a tree REBUILT over the reference's leaf units (vk_linearize.cpp), and the tree as handed
-//     over decides every segment whose winner could depend on the visiting order (vk_trace.h winner_is_early): walked again in place
+//     over decides every segment whose winner could depend on the visiting order (vk_trace.h segment_unsafe): walked again in place
 //     where both trees sit in one array (global-memory scenes), or the sample is queued and rendered by a second launch of the same
 //     kernel in list mode (LDS scenes: enqueue_render_f32);
 //   * no MFMA: there is no dense contraction in a path tracer.
@@ -777,6 +777,8 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
         // (`exact`).  Traversed from global memory: both trees in one array, early segments are walked again in place (DScene::walk_start).
         const DScene hv = H.host_view();
         D.t_pad = hv.t_pad; D.gate_scale = hv.gate_scale; D.tmin_gate = hv.tmin_gate;
+        for (int k = 0; k < 3; k++) D.trust_c0[k] = hv.trust_c0[k];
+        D.trust_r0sq = hv.trust_r0sq;
         if (s->lds_bytes != 0) {
             UP(items, items); UP(ref_items, ref_items);
             D.n_ref_items = hv.n_ref_items; D.n_items = (uint32_t)H.items.size(); D.n_world_items = H.world_items;
@@ -834,6 +836,10 @@ int linearize_desc(const vk_scene_desc *desc, std::shared_ptr<const LinearScene>
     std::string err;
     LinearizeOptions opt;
     opt.retree = EnvSwitches::read().retree;
+    if (const char *e = getenv("VK_GATE_GROW")) opt.gate_grow = e[0] != '0';      // (tests: see LinearizeOptions)
+    if (const char *e = getenv("VK_T_PAD")) opt.t_pad = (float)atof(e);
+    if (const char *e = getenv("VK_GATE_PROOF")) { opt.want_proof = e[0] != '0'; if (!opt.want_proof) opt.allow_empirical = true; }
+    if (const char *e = getenv("VK_EMPIRICAL_TREES")) opt.allow_empirical = e[0] == '1';
     int rc = linearize(desc, *h, err, opt);
     if (rc != VK_OK) return fail(rc, err);
     out = h;
@@ -935,6 +941,8 @@ int vk_scene_get_info(const vk_scene *s, vk_scene_info *out) {
     out->device_bytes = b;
     out->lds_bytes = one->lds_bytes;
     out->features = pick_variant(one);
+    out->tree = !H.ref_items.empty() ? (H.proven ? VK_TREE_REBUILT_PROVEN : VK_TREE_REBUILT_EMPIRICAL)
+                                     : (!H.tie_rank.empty() ? VK_TREE_REBUILT_FAST : VK_TREE_HANDED_OVER);
     return VK_OK;
 }
 

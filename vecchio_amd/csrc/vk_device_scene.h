@@ -116,11 +116,14 @@ struct DScene {
     // by comparing their hit with this list instead of chasing sphere -> material -> texture): sphere index, texture, perlin table.
     // n_noise_spheres = ~0: more than fit here, look the material up.
     uint32_t n_noise_spheres; uint32_t noise_sphere[4], noise_tex[4], noise_perlin[4];
-    // Exact re-treeing (vk_linearize.cpp rt_collect, vk_trace.h winner_is_early): t_pad > 0 says that items[0, n_world_items) is a tree
+    // Exact re-treeing (vk_linearize.cpp rt_collect, vk_trace.h segment_unsafe): t_pad > 0 says that items[0, n_world_items) is a tree
     // REBUILT over the reference's leaf units, walked with the closest hit so far padded by (1 + t_pad); ref_items[0, n_ref_items) is
     // the tree as handed over, on which the rare sample whose result may depend on the visiting order is rendered again.
     // gate_scale = 1 / (1 + t_pad) and tmin_gate = T_MIN * gate_scale (rounded down); 1 and T_MIN when t_pad == 0.
     const DItem *ref_items; uint32_t n_ref_items; float t_pad, gate_scale, tmin_gate;
+    // ... and the trusted origin ball: the gates of the rebuilt tree are proven sound for rays that start inside it (vk_linearize.h
+    // rt_unit_growth); a segment that starts outside is decided on the tree as handed over (vk_trace.h segment_unsafe)
+    float trust_c0[3], trust_r0sq;
     // Scenes traversed from global memory keep BOTH trees in items[]: [the tree as handed over | a sentinel no ray passes | the
     // rebuilt tree], walk_start = index of the rebuilt tree's first item (0: items[] is one tree).  A segment whose winner is early
     // is then walked again right away, from item 0, instead of its sample being queued (vk_trace.h begin_segment).

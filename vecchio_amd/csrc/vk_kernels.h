@@ -327,7 +327,7 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool e
                                   // (dead) world-ray fields L.wo / L.wd / L.time, so it costs no registers
     const PreTurb pre_turb = cooperative_turb<F, Mem>(L, S, M, is_shade, lane);
     rearm = false;
-    // `early` (exact re-treeing): the winner of this lane's segment may depend on the visiting order (vk_trace.h winner_is_early,
+    // `early` (exact re-treeing): the winner of this lane's segment may depend on the visiting order (vk_trace.h segment_unsafe,
     // asked by the caller, which holds the segment's reciprocals)
     if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && !LDS_SCENE) {
         // scene in global memory (both trees in items[], DScene::walk_start): the segment is walked again, now on the tree as handed
@@ -493,7 +493,7 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool e
 // traversal state inside the box and primitive loops as soon as anything in the kernel changed: C3 moved between 330 and 520
 // Msamples/s with the spill placement).  Only what shading reads of the traversal state crosses, by value.
 struct ShadeIo {
-    // in: 1 is_shade, 2 active, 4 need, 64 early (winner_is_early);   out: 2 active, 4 need, 8 fresh, 16 touched, 32 rearm (same ray
+    // in: 1 is_shade, 2 active, 4 need, 64 early (segment_unsafe);   out: 2 active, 4 need, 8 fresh, 16 touched, 32 rearm (same ray
     // again)
     uint32_t flags;
     float T; uint32_t best_prim; int32_t best_inst; float best_aux;
@@ -746,7 +746,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
                     bool on_ref = false;   // the lane has just walked the tree as handed over: its answer stands
                     if constexpr (!LDS_SCENE) on_ref = (__float_as_uint(cold[CF_DEPTH * 64 + lane]) >> 31) != 0u;
-                    if (is_shade && !on_ref) early = winner_is_early<F, Mem>(L, S, M);
+                    if (is_shade && !on_ref) early = segment_unsafe<F, Mem>(L, S, M);
                 }
             }
             if constexpr (SPLIT) {

@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -33,6 +35,8 @@ DScene LinearScene::host_view() const {
     s.t_pad = ref_items.empty() ? 0.0f : t_pad;
     s.gate_scale = 1.0f / (1.0f + s.t_pad);
     s.tmin_gate = s.t_pad > 0.0f ? 0.001f * s.gate_scale * 0.999999f : 0.001f;     // (T_MIN of vk_trace.h)
+    for (int k = 0; k < 3; k++) s.trust_c0[k] = trust_c0[k];
+    s.trust_r0sq = trust_r0 * trust_r0;
     return s;
 }
 
@@ -54,6 +58,61 @@ std::vector<DItem> LinearScene::combined_items(uint32_t &walk_start) const {
         out.push_back(it);
     }
     return out;
+}
+
+double rt_unit_growth(const float umn[3], const float umx[3], int n, const float (*centers)[3], const float *radii, const RtDomain &dom,
+    double t_pad, bool box_grows) {
+    const double U24 = 1.0 / 16777216.0;
+    const double pad = t_pad * (1.0 - 1.0 / 1024.0);       // (what the f32 gate arithmetic leaves of it, generously)
+    // beyond rho1 = far (d* + 1.07 (R + g)) the padding covers a hit point outside the grown box: pad (rho1 - R - eta) >= d* + R + eta
+    // given g >= eta(rho1), because pad * far = 1 + pad and 1.07 (1 + pad) - pad >= 1 + pad / 2
+    const double far = 1.0 / pad + 1.0;
+    double maxabs = 0.0;
+    for (int a = 0; a < 3; a++) maxabs = std::max(maxabs, std::max(std::fabs((double)umn[a]), std::fabs((double)umx[a])));
+    double g = 0.0;
+    // farthest point of the box grown by g from a sphere's centre
+    auto dstar = [&](const float *c, double gg) {
+        double s2 = 0.0;
+        if (!box_grows) gg = 8.0 * U24 * maxabs;       // the box stays (but for its rounding slack): the growth is the spheres' own boxes'
+        for (int a = 0; a < 3; a++) {
+            const double d = std::max(std::fabs((double)umn[a] - gg - c[a]), std::fabs((double)umx[a] + gg - c[a]));
+            s2 += d * d;
+        }
+        return std::sqrt(s2);
+    };
+    auto rho_dom = [&](const float *c) {
+        double s2 = 0.0;
+        for (int a = 0; a < 3; a++) s2 += ((double)c[a] - dom.c0[a]) * ((double)c[a] - dom.c0[a]);
+        return std::sqrt(s2) + dom.r0;
+    };
+    // Near origins (rho <= rho1): the hit point lies within eta(rho) of the sphere, hence inside the box grown by g >= 1.25 eta(rho1)
+    // (the quarter is the margin the slab test's own rounding needs).  rho1 depends on g through the grown box: smallest fixed point.
+    for (int iter = 0; iter < 64; iter++) {
+        double gn = 0.0;
+        for (int k = 0; k < n; k++) {
+            const double R = radii[k];
+            const double rho1 = far * (dstar(centers[k], g) + 1.07 * (R + g));
+            gn = std::max(gn, 1.25 * rt_eta(std::min(rho1, rho_dom(centers[k])), R));
+        }
+        if (gn <= g) break;
+        g = gn * (1.0 + 1e-9);
+        if (iter == 63) {         // no fixed point below the ball's cap: the cap itself (every origin of the ball is a near one)
+            g = 0.0;
+            for (int k = 0; k < n; k++) g = std::max(g, 1.25 * rt_eta(rho_dom(centers[k]), radii[k]));
+        }
+    }
+    // Far origins (rho1 < rho <= rho_dom): the hit point may lie outside the grown box, but then precedes the ray's entry into it by at
+    // most d* + R + eta(rho), which the padding covers when pad (rho - R - eta) >= d* + R + eta.  The difference is concave in rho and
+    // non-negative at rho1 (by the choice of rho1), so it is enough to check the far end.
+    for (int k = 0; k < n; k++) {
+        const double R = radii[k], rd = rho_dom(centers[k]);
+        const double ds = dstar(centers[k], g), rho1 = far * (ds + 1.07 * (R + g));
+        if (rd <= rho1) continue;
+        const double eta = rt_eta(rd, R);
+        if (pad * (rd - R - eta) < ds + R + eta) return -1.0;
+    }
+    // the f32 roundings of the box bounds and of center -+ radius (Sphere::bounding_box): a few ulps of the largest coordinate
+    return g + 8.0 * U24 * maxabs;
 }
 
 namespace {
@@ -401,7 +460,7 @@ struct Builder {
             if (retree_units && !(d->spheres[VK_REF_INDEX(fr.ref)].radius > 0.0f)) { ok = false; return true; }
             if (!rt_bounds(fr.ref, o.mn, o.mx)) { ok = false; return status == VK_OK; }
             if (retree_units) {
-                // the early-winner test (vk_trace.h winner_is_early) takes the sphere's own box for a subset of its unit's: true of any
+                // the early-winner test (vk_trace.h segment_unsafe) takes the sphere's own box for a subset of its unit's: true of any
                 // tree BVHNode::new builds, checked because the tree is the caller's
                 const vk_bvh_node &pn = d->bvh[fr.parent];
                 for (int a = 0; a < 3; a++)
@@ -537,6 +596,86 @@ struct Builder {
         }
     }
 
+    // Exact re-treeing: the trusted origin ball and the growth of every unit's gate box (vk_linearize.h rt_unit_growth).  The ball is
+    // centred on the component-wise median of the sphere centres and reaches eight times as far as the spheres of ordinary size do
+    // (a ground sphere thousands of times larger than the rest does not count towards the extent: rays start on its near side);
+    // it shrinks until every unit's far-origin check holds.
+    // The growth goes with the square of a unit's size, and BVHNode::new's units can be long (random axis, median split; a scene whose
+    // spheres all share one coordinate wastes every split on that axis: one unit in a hundred of the 1 M-sphere stress scene is
+    // longer than 100 sphere diameters).  Grown, such units overlap everything around them and the rebuilt tree is worse than the tree
+    // handed over.  So the grown tree is used only where it is cheap — the leaves' surface areas grow by less than RT_MAX_AREA_GROWTH on
+    // average — and `proven` says so.  Otherwise the scene is walked on the tree as handed over, unless the caller asked for
+    // VK_SCENE_EMPIRICAL_TREES: then the units keep their boxes, the padding is RT_PAD_EMPIRICAL and the exactness of the rebuilt walk is
+    // what the test suites have measured, not what the gate lemma proves (include/vecchio_amd.h; tests/test_gate_lemma.py constructs a
+    // ray on which it fails).
+    bool gate_grow = true, want_proof = true, proof_only = true;
+    bool proven = false;
+    double gate_pad = RT_PAD;
+    bool rt_grow_units(std::vector<RtObj> &objs) {
+        if (objs.empty()) return false;
+        std::vector<float> cx, cy, cz, rr;
+        for (const RtObj &o : objs)
+            for (uint32_t dr : {o.dref, o.dref2}) {
+                if (!dr) continue;
+                const DSphere &sp = L.spheres[VKD_INDEX(dr)];
+                cx.push_back(sp.cx); cy.push_back(sp.cy); cz.push_back(sp.cz); rr.push_back(sp.r);
+            }
+        auto median = [](std::vector<float> v) { std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end()); return (double)v[v.size() / 2]; };
+        RtDomain dom;
+        dom.c0[0] = median(cx); dom.c0[1] = median(cy); dom.c0[2] = median(cz);
+        const double r_med = median(rr);
+        double ext = 0.0;
+        for (size_t i = 0; i < rr.size(); i++) {
+            if ((double)rr[i] > 64.0 * r_med) continue;
+            const double dx = cx[i] - dom.c0[0], dy = cy[i] - dom.c0[1], dz = cz[i] - dom.c0[2];
+            ext = std::max(ext, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)rr[i]);
+        }
+        if (!(ext > 0.0) || !std::isfinite(ext)) return false;
+        std::vector<double> grow(objs.size());
+        dom.r0 = 8.0 * ext;
+        for (;;) {
+            bool all = true;
+            for (size_t i = 0; i < objs.size() && all; i++) {
+                float c[2][3], r[2]; int n = 0;
+                for (uint32_t dr : {objs[i].dref, objs[i].dref2}) {
+                    if (!dr) continue;
+                    const DSphere &sp = L.spheres[VKD_INDEX(dr)];
+                    c[n][0] = sp.cx; c[n][1] = sp.cy; c[n][2] = sp.cz; r[n] = sp.r; n++;
+                }
+                grow[i] = rt_unit_growth(objs[i].mn, objs[i].mx, n, c, r, dom, gate_pad);
+                if (grow[i] < 0.0) all = false;
+            }
+            if (all) break;
+            dom.r0 *= 0.75;
+            if (dom.r0 < 2.0 * ext) return false;
+        }
+        double area0 = 0.0, area1 = 0.0, gmax = 0.0;
+        for (size_t i = 0; i < objs.size(); i++) {
+            float mn[3], mx[3];
+            const float g = std::nextafter((float)grow[i], INFINITY);
+            for (int a = 0; a < 3; a++) { mn[a] = std::nextafter(objs[i].mn[a] - g, -INFINITY); mx[a] = std::nextafter(objs[i].mx[a] + g, INFINITY);
+                if (!std::isfinite(mn[a]) || !std::isfinite(mx[a])) return false; }
+            // (per unit, relative: a ground sphere's box would outweigh all others in a sum of areas)
+            area0 += 1.0; area1 += (double)rt_half_area(mn, mx) / std::max((double)rt_half_area(objs[i].mn, objs[i].mx), 1e-300);
+            gmax = std::max(gmax, (double)g);
+        }
+        const bool cheap = area1 <= (1.0 + RT_MAX_AREA_GROWTH) * area0;
+        if (getenv("VK_RETREE_DEBUG"))
+            fprintf(stderr, "vecchio_amd: exact re-treeing: %zu units, trusted ball centre (%g %g %g) radius %g (extent %g), gate growth: "
+                "largest %g, leaf area x %.4f at padding %g -> %s\n", objs.size(), dom.c0[0], dom.c0[1], dom.c0[2], dom.r0, ext, gmax,
+                area1 / area0, gate_pad, cheap ? "grown gates (proven)" : "too dear");
+        if (!cheap) return false;
+        if (gate_grow)
+            for (size_t i = 0; i < objs.size(); i++) {
+                const float g = std::nextafter((float)grow[i], INFINITY);
+                for (int a = 0; a < 3; a++) { objs[i].mn[a] = std::nextafter(objs[i].mn[a] - g, -INFINITY);
+                    objs[i].mx[a] = std::nextafter(objs[i].mx[a] + g, INFINITY); }
+            }
+        for (int a = 0; a < 3; a++) L.trust_c0[a] = (float)dom.c0[a];
+        L.trust_r0 = (float)(dom.r0 * (1.0 - 1e-6));
+        return true;
+    }
+
     // dense object id of a dref for the tie table: [spheres][rects][boxes][lists]
     uint32_t tie_id(uint32_t dref) const {
         uint32_t k = VKD_KIND(dref), i = VKD_INDEX(dref);
@@ -576,6 +715,10 @@ struct Builder {
         objs.reserve((size_t)simple_count[root]);
         bool ok = true;
         if (!rt_collect(root, flip, inst, objs, ok)) return false;
+        if (ok && retree_units) {
+            proven = want_proof && rt_grow_units(objs);
+            if (!proven && proof_only) ok = false;      // (no VK_SCENE_EMPIRICAL_TREES: the tree as handed over rather than an unproven one)
+        }
         if (!ok || objs.size() < RETREE_MIN || objs.size() >= (1u << 20) ||
             (!objs.empty() && (objs.back().rank | objs.back().rank2) >= (1u << 20))) {
             // keep the reference's tree for this subtree: undo what collecting converted (memo entries past the old sizes)
@@ -822,6 +965,13 @@ int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, con
     if (mode < 0) mode = !desc ? 0 : ((desc->flags & VK_SCENE_FAST_ACCEL) ? 1 : ((desc->flags & VK_SCENE_REFERENCE_TREE) ? 0 : 2));
     b.retree = mode != 0;
     b.retree_units = mode == 2;
+    // opt.t_pad is a test switch; anything that is not a positive number below 1 would leave a rebuilt tree without a working gate: the
+    // tree as handed over is used instead
+    if (opt.t_pad != 0.0f && !(opt.t_pad > 0.0f && opt.t_pad < 1.0f)) { b.retree = false; b.retree_units = false; }
+    b.gate_grow = opt.gate_grow;
+    b.want_proof = opt.want_proof;
+    b.proof_only = !(desc && (desc->flags & VK_SCENE_EMPIRICAL_TREES) != 0u) && !opt.allow_empirical;
+    if (opt.t_pad > 0.0f && opt.t_pad < 1.0f) b.gate_pad = opt.t_pad;
     if (!b.run()) return b.status == VK_OK ? VK_ERR_BAD_ARG : b.status;
     out.world_items = b.world_items;
     if (out.features == 0u) {            // what the sphere-only kernel variants shade from
@@ -845,12 +995,14 @@ int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, con
             memcmp(ref.spheres.data(), out.spheres.data(), ref.spheres.size() * sizeof(DSphere)) == 0;
         if (!same) { err = "exact re-tree: the two linearisations number the spheres differently"; return VK_ERR_UNSUPPORTED; }
         out.ref_items = ref.items;
-        // 1/16: a computed hit point can lie outside its sphere's box (a grazing or false hit of a far sphere), and a ray nearly parallel
-        // to that face enters the box later than it "hits" by that distance over a small direction component.  1/256 lost one sample
-        // in 1.9 G that way (stress_spheres:200, a ray 0.5 degrees off a box face); the padding costs 0.8 % more steps at 1/16 (growing
-        // the unit boxes instead — by 1/32 of their smallest extent — costs 4-10 %)
-        out.t_pad = 1.0f / 16.0f;
-        if (const char *e = getenv("VK_T_PAD")) out.t_pad = (float)atof(e);
+        // The gate's relative padding.  Proven form (rt_grow_units succeeded): RT_PAD, which covers the hit points of FAR origins — they
+        // may precede the ray's entry into the unit's grown box by up to the box's size; near origins are covered by the growth.
+        // Empirical form: the units' boxes as handed over and RT_PAD_EMPIRICAL (1/256 lost one sample in 1.9 G on the stress scene, 1/16
+        // none in 12 G: DESIGN.md section 5), every origin "trusted".
+        out.proven = b.proven;
+        out.t_pad = (float)(b.proven ? RT_PAD : RT_PAD_EMPIRICAL);
+        if (opt.t_pad > 0.0f && opt.t_pad < 1.0f) out.t_pad = opt.t_pad;
+        if (!b.proven) { out.trust_c0[0] = out.trust_c0[1] = out.trust_c0[2] = 0.0f; out.trust_r0 = INFINITY; }
     }
     return VK_OK;
 }

@@ -37,6 +37,8 @@ struct LinearScene {
     std::vector<uint32_t> tie_rank;
     uint32_t tie_base_rect = 0, tie_base_box = 0, tie_base_list = 0;
     std::vector<DItem> ref_items; float t_pad = 0.0f;      // see DScene
+    float trust_c0[3] = {0.0f, 0.0f, 0.0f}; float trust_r0 = 0.0f;      // exact re-treeing: the trusted origin ball (DScene)
+    bool proven = false;        // exact re-treeing with grown gates: the gate lemma applies (vk_linearize.cpp rt_grow_units)
     uint32_t features = 0;
     uint32_t n_prims = 0;
     uint32_t world_items = 0;   // items[0, world_items) is the world BVH; instance child ranges follow
@@ -52,10 +54,35 @@ struct LinearizeOptions {
     //   1  every draw-free subtree, object by object (VK_SCENE_FAST_ACCEL: results may differ where a hit lies a rounding error
     //      outside its box)
     //   2  EXACT re-treeing: the world tree of a scene of spheres only, over the reference's leaf units, with the tree as handed
-    //      over riding along for the samples that need it (vk_trace.h winner_is_early): results are the reference's
+    //      over riding along for the samples that need it (vk_trace.h segment_unsafe): results are the reference's
     //  -1  as vk_scene_desc.flags says: VK_SCENE_FAST_ACCEL -> 1, VK_SCENE_REFERENCE_TREE -> 0, else 2
     int retree = -1;
+    // test switches of exact re-treeing (environment VK_GATE_GROW=0, VK_T_PAD=x through vk_api.hip / tests/emu): the unit boxes as handed
+    // over instead of grown ones, another relative padding of the gate (0 = RT_PAD).  Neither is sound; they exist so that the
+    // counter-examples of the gate lemma can be shown to bite.
+    bool gate_grow = true;
+    float t_pad = 0.0f;
+    bool want_proof = true;     // VK_GATE_PROOF=0: the empirical form even where the proven one is cheap (comparisons)
+    bool allow_empirical = false;   // VK_EMPIRICAL_TREES=1: as vk_scene_desc.flags & VK_SCENE_EMPIRICAL_TREES
 };
+
+// ---- exact re-treeing: the arithmetic behind the soundness of the rebuilt tree's gates ("Gate lemma").
+// Sphere::hit in f32 (hittable.rs:65-95) reports hit points that need not lie on the sphere: with u = 2^-24 and rho = |o - c|, the point
+// o + t d of an accepted root t lies within rt_eta(rho, R) of the sphere's surface (forward error analysis: K <= 30; measured <= 6;
+// RT_KAPPA = 32 u).  A unit's gate box is the reference's box grown by rt_unit_growth(): then, for every ray origin inside the trusted
+// ball `dom`, the gate passes whenever the reference could have accepted one of the unit's spheres — because the hit point lies inside
+// the grown box (near origins) or because it precedes the box entry by less than the gate's relative padding RT_PAD (far origins).
+// tests/test_gate_lemma.py hammers both statements with the kernel's own arithmetic.
+struct RtDomain { double c0[3]; double r0; };
+constexpr double RT_KAPPA = 1.0 / 524288.0;       // 2^-19 = 32 * 2^-24
+constexpr double RT_PAD = 1.0 / 4.0;              // LinearScene::t_pad of exact re-treeing with grown gates (the proven form)
+constexpr double RT_PAD_EMPIRICAL = 1.0 / 16.0;   // ... with the units' boxes as handed over (the empirical form)
+constexpr double RT_MAX_AREA_GROWTH = 0.05;       // the grown gates are used when they cost at most this much leaf surface area
+inline double rt_eta(double rho, double R) { return RT_KAPPA * (rho + R) * (rho + R) / R; }
+// growth (>= 0) of the box [umn, umx] gating the n spheres (centers, radii), or < 0 if no growth makes the gate sound for origins
+// as far away as the ball allows (the caller shrinks the ball)
+double rt_unit_growth(const float umn[3], const float umx[3], int n, const float (*centers)[3], const float *radii, const RtDomain &dom,
+    double t_pad = RT_PAD, bool box_grows = true);
 
 // returns VK_OK or an error code with `err` set
 int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, const LinearizeOptions &opt = LinearizeOptions());

@@ -509,45 +509,55 @@ VK_HD bool prim_is_heavy(uint32_t ref) {
 
 // ------------------------------------------------------------------ exact re-treeing (DScene::t_pad > 0; scenes of spheres only)
 // items[] is then a tree REBUILT over the reference's leaf units (vk_linearize.cpp rt_collect): every object is gated by the box the
-// reference gates it with, and boxes are nested, so the closest hit of a segment does not depend on the tree or on the visiting order —
-// except through objects whose computed hit distance is not behind their unit's computed box entry (rounding: a far, tiny or grazing
-// sphere).  Such an "early" object is accepted only by a walk that reaches its unit while the closest hit so far is still beyond
-// that entry, which depends on the order.  Two measures make the rebuilt walk agree with the reference's all the same:
-//  * the gate is padded: boxes are tested against T * (1 + t_pad) — by scaling the lane's reciprocals once per ray (set_space), not
-//    by a multiplication per step — so that this walk tests every unit in which the reference's walk can have accepted an early
-//    object (one that precedes its box entry by less than t_pad, relatively);
-//  * a segment whose WINNER is early (winner_is_early, asked once when the segment's walk has ended) is not trusted: the tree as
-//    handed over decides — for that segment, walked again in place, where items[] holds both trees (DScene::walk_start, scenes in global
-//    memory), or for the whole sample, dropped and rendered by a second launch (vk_kernels.h, scenes staged in LDS).
-// A winner that is not early is the closest of all gated objects in any order: every walk tests its unit (T >= t* > entry) and
-// accepts it.  tests/test_retree.py compares per sample with the oracle on the handed-over tree.
+// reference gates it with — grown a little — and boxes are nested.  DESIGN.md section 5 has the argument in full; in short:
+//  * CANDIDATES.  For a ray, a sphere's candidate is the root Sphere::hit would report with tmax = +inf (the first root above tmin);
+//    whatever tmax it is called with, Sphere::hit reports the candidate or nothing.  BVHNode::hit therefore ends with the minimum over
+//    the candidates it ACCEPTS, and it accepts X only when the boxes above X pass, the last of which is X's unit's.
+//  * SOUND GATES.  The rebuilt walk tests a unit when its grown box passes against T (1 + t_pad), T the closest hit so far.  The growth
+//    and the padding are chosen (vk_linearize.h rt_unit_growth, the "gate lemma") so that, for a ray with ordinary components that
+//    starts inside the scene's trusted ball, the gate of X passes whenever T exceeds X's candidate and the reference's box of the unit
+//    passes at all.  By induction the rebuilt walk then ends with a T no larger than any candidate the reference could accept.
+//  * SAFE WINNER.  If the rebuilt walk's winner W passes its OWN box (center -+ radius: inside every box the reference has above W) by a
+//    margin, with its hit behind that box's entry, then the reference's walk reaches W whatever it found before, with a tmax that is
+//    still >= t_W, and accepts it: both walks end with W.  (A miss is safe: no candidate exists.)
+//  * Everything else — a winner that is not safe, a ray from outside the ball, a ray with a tiny, huge or non-finite component — is
+//    decided by the tree as handed over: the segment is walked again in place where items[] holds both trees (DScene::walk_start,
+//    scenes in global memory), or its sample is dropped and rendered by a second launch (vk_kernels.h, scenes staged in LDS).
+// tests/test_retree.py compares per sample with the oracle on the handed-over tree; tests/test_gate_lemma.py attacks the lemma.
 template <uint32_t F>
 VK_HD float gate_of(const Lane &L, const DScene &S) {
     return ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && S.t_pad > 0.0f && L.i >= S.walk_start) ? L.T * (1.0f + S.t_pad) : L.T;
 }
-// Is the segment's winner early?  Asked of a lane whose reciprocals are the scaled ones (not of one on the tree as handed over).
-// The test uses the sphere's OWN box (center -+ radius, as Sphere::bounding_box computes it, hittable.rs:97-102) instead of its unit's:
-// the unit's box contains it, so its entry is no later, and "not behind the own box's entry" holds whenever "not behind the unit's"
-// does.  Decided on the scaled fast-path quantities with the box test's own margin on the side of "early": a false positive costs one
-// walk (or one sample) done twice.  A negative radius (an inverted own box) counts as early.
+// Must the segment just walked (on the rebuilt tree: the lane's reciprocals are the scaled ones) be decided by the tree as handed over?
+// Decided on the scaled fast-path quantities with the box test's own margin on the side of "unsafe": a false positive costs one walk
+// (or one sample) done twice.
 template <uint32_t F, class Mem>
-VK_HD bool winner_is_early(const Lane &L, const DScene &S, const Mem &M) {
-    if (!(S.t_pad > 0.0f) || L.best_prim == 0u) return false;
-    const DSphere sp = M.sphere(VKD_INDEX(L.best_prim));
-    const float bx0 = sp.cx - sp.r, bx1 = sp.cx + sp.r, by0 = sp.cy - sp.r, by1 = sp.cy + sp.r, bz0 = sp.cz - sp.r, bz1 = sp.cz + sp.r;
-    float x0, x1, y0, y1, z0, z1;
-    if constexpr (fused_box<F, Mem>()) {
-        x0 = __builtin_fmaf(bx0, L.inv.x, -L.oi.x); x1 = __builtin_fmaf(bx1, L.inv.x, -L.oi.x);
-        y0 = __builtin_fmaf(by0, L.inv.y, -L.oi.y); y1 = __builtin_fmaf(by1, L.inv.y, -L.oi.y);
-        z0 = __builtin_fmaf(bz0, L.inv.z, -L.oi.z); z1 = __builtin_fmaf(bz1, L.inv.z, -L.oi.z);
-    } else {
-        x0 = (bx0 - L.o.x) * L.inv.x; x1 = (bx1 - L.o.x) * L.inv.x;
-        y0 = (by0 - L.o.y) * L.inv.y; y1 = (by1 - L.o.y) * L.inv.y;
-        z0 = (bz0 - L.o.z) * L.inv.z; z1 = (bz1 - L.o.z) * L.inv.z;
+VK_HD bool segment_unsafe(const Lane &L, const DScene &S, const Mem &M) {
+    if (!(S.t_pad > 0.0f)) return false;
+    // the ray: inside the trusted ball, components the fast box test trusts (xnan is NaN otherwise)
+    const V3 oc = L.o - v3(S.trust_c0[0], S.trust_c0[1], S.trust_c0[2]);
+    bool unsafe = !(length2(oc) <= S.trust_r0sq) || !(L.xnan == L.xnan);
+    if (L.best_prim != 0u) {
+        const DSphere sp = M.sphere(VKD_INDEX(L.best_prim));
+        const float bx0 = sp.cx - sp.r, bx1 = sp.cx + sp.r, by0 = sp.cy - sp.r, by1 = sp.cy + sp.r, bz0 = sp.cz - sp.r, bz1 = sp.cz + sp.r;
+        float x0, x1, y0, y1, z0, z1;
+        if constexpr (fused_box<F, Mem>()) {
+            x0 = __builtin_fmaf(bx0, L.inv.x, -L.oi.x); x1 = __builtin_fmaf(bx1, L.inv.x, -L.oi.x);
+            y0 = __builtin_fmaf(by0, L.inv.y, -L.oi.y); y1 = __builtin_fmaf(by1, L.inv.y, -L.oi.y);
+            z0 = __builtin_fmaf(bz0, L.inv.z, -L.oi.z); z1 = __builtin_fmaf(bz1, L.inv.z, -L.oi.z);
+        } else {
+            x0 = (bx0 - L.o.x) * L.inv.x; x1 = (bx1 - L.o.x) * L.inv.x;
+            y0 = (by0 - L.o.y) * L.inv.y; y1 = (by1 - L.o.y) * L.inv.y;
+            z0 = (bz0 - L.o.z) * L.inv.z; z1 = (bz1 - L.o.z) * L.inv.z;
+        }
+        // AxisBB::hit of the own box with tmax = the winner's t (scaled like the reciprocals), as box_step_core decides it — but a
+        // decision inside the margin counts as a miss
+        const float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), S.tmin_gate));
+        const float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), L.T * S.gate_scale));
+        const bool passes = hi - lo > __builtin_fmaf(fabsf(hi), 4.0e-6f, L.xnan);      // false for a NaN margin
+        unsafe = unsafe || !passes || !(sp.r > 0.0f);
     }
-    const float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));      // entry into the own box (scaled; < 0: origin inside)
-    const bool behind = L.T * S.gate_scale > __builtin_fmaf(fabsf(lo), 4.0e-6f, lo) + L.xnan;   // false for NaN margins: early
-    return !behind || !(sp.r > 0.0f);
+    return unsafe;
 }
 
 // One box step of a lane that HAS box work and is inside its range (pend == 0, i < end).

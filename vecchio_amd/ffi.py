@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 ASSETS_DIR = os.path.join(os.path.dirname(_HERE), "tests", "golden", "assets")
 
-VK_ABI_VERSION = 4
+VK_ABI_VERSION = 5
 VK_OK, VK_ERR_BAD_ARG, VK_ERR_UNSUPPORTED, VK_ERR_HIP, VK_ERR_NO_DEVICE, VK_ERR_OOM = range(6)
 
 (VK_KIND_NONE, VK_KIND_BVH, VK_KIND_SPHERE, VK_KIND_MOVING_SPHERE, VK_KIND_RECT, VK_KIND_LIST,
@@ -27,6 +27,7 @@ VK_BACKGROUND_SOLID, VK_BACKGROUND_SKY = 0, 1
 VK_OUTPUT_F32, VK_OUTPUT_RGB8 = 0, 1
 VK_SCENE_FAST_ACCEL = 1
 VK_SCENE_REFERENCE_TREE = 2
+VK_SCENE_EMPIRICAL_TREES = 4
 
 
 def make_ref(kind, index, flip=False):
@@ -129,7 +130,10 @@ class Stats(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_items", C.c_uint32), ("n_prims", C.c_uint32), ("n_instances", C.c_uint32),
-                ("device_bytes", C.c_uint64), ("lds_bytes", C.c_uint32), ("features", C.c_uint32)]
+                ("device_bytes", C.c_uint64), ("lds_bytes", C.c_uint32), ("features", C.c_uint32), ("tree", C.c_uint32)]
+
+
+VK_TREE_HANDED_OVER, VK_TREE_REBUILT_PROVEN, VK_TREE_REBUILT_EMPIRICAL, VK_TREE_REBUILT_FAST = range(4)
 
 
 _host = None
