@@ -319,6 +319,10 @@ typedef struct vk_scene_info {
     uint32_t lds_bytes;        /* bytes staged into LDS per workgroup (0 = not resident) */
     uint32_t features;         /* VKF_* mask of the kernel variant selected */
     uint32_t tree;             /* VK_TREE_*: what the world is walked on (ABI 5; see vk_scene_desc.flags) */
+    /* frames for which a rebuilt tree is suspended (the tree as handed over is walked meanwhile): a frame that sends more than a quarter
+     * of its samples to the tree as handed over anyway, or more than the queues between the two launches hold, pauses the rebuilt tree
+     * for 32 frames, twice as long at every relapse; 0 = in use.  As of the last frame whose end the library has seen. */
+    uint32_t tree_suspended_frames;
 } vk_scene_info;
 enum {
     VK_TREE_HANDED_OVER = 0,        /* the tree of the description, item for item */

@@ -67,46 +67,57 @@ def test_stress_scenes_are_walked_as_handed_over_by_default(device):
 
 def test_a_full_redo_queue_never_yields_an_incomplete_frame(device):
     """VK_REDO_REGION_CAP=1 (a test switch) leaves one entry per queue between the two launches: samples that do not fit would be
-    missing from the frame.  vk_scene_last_requeued_samples reports it (VK_ERR_OOM), and vk_render renders the frame again on the tree
-    as handed over instead of returning it."""
+    missing from the frame.  The fallback launch behind the second one then renders the partition again on the tree as handed over —
+    on the device, whoever the caller is: vk_render and vk_render_device (enqueued on a stream, never polled) both return the
+    handed-over tree's frame, and the rebuilt tree is suspended for the next frames."""
     code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
-            "import numpy as np\n"
+            "import numpy as np, torch\n"
             "from vecchio_amd import DeviceScene, HostScene, ffi\n"
-            "def frame(flags):\n"
+            "def frames(flags):\n"
             "    hs = HostScene('random_spheres_iow', 1); hs.desc.contents.flags = flags; cam = hs.next_camera(); ds = DeviceScene(hs.desc)\n"
-            "    return ds.render(cam, hs.params(640, 96, 50))[0]\n"
-            "print('EQUAL', np.array_equal(frame(0).view(np.uint32), frame(ffi.VK_SCENE_REFERENCE_TREE).view(np.uint32)))\n") % ROOT
+            "    p = hs.params(640, 96, 50)\n"
+            "    fb = torch.zeros((p.height, p.width, 3), dtype=torch.float32, device='cuda')\n"
+            "    ds.render_device(cam, p, fb.data_ptr(), torch.cuda.current_stream().cuda_stream)\n"
+            "    a = fb.cpu().numpy().copy()\n"                       # (waits for the stream, asks the library nothing)
+            "    b = ds.render(cam, p)[0]\n"
+            "    return a, b, ds.info().tree_suspended_frames\n"
+            "xa, xb, susp = frames(0); ra, rb, _ = frames(ffi.VK_SCENE_REFERENCE_TREE)\n"
+            "print('EQUAL', all(np.array_equal(x.view(np.uint32), ra.view(np.uint32)) for x in (xa, xb, rb)), 'SUSPENDED', susp)\n") % ROOT
     env = dict(os.environ, VK_REDO_REGION_CAP="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "EQUAL True" in r.stdout, r.stdout + r.stderr
+    assert int(r.stdout.split()[-1]) >= 30, r.stdout + r.stderr
+    assert "overflowed its queues" in r.stderr, r.stderr
 
 
-def test_scene_with_mostly_early_winners_falls_back_to_the_handed_over_tree(device):
+def test_scene_with_mostly_early_winners_suspends_the_rebuilt_tree(device):
     """A small field on a ground sphere of radius 1e5, seen from above: most primary hits land on the ground, whose f32 quadratic is
-    off by more than the depth of the ground below its box's top — "early" winners everywhere.  The frame is still exact (every such
-    sample goes through the second launch), and the library then stops rebuilding for this scene (stderr says so)."""
+    off by more than the depth of the ground below its box's top — unsafe winners everywhere.  The frame is still exact (every such
+    sample goes through the second launch, or the fallback launch renders the frame), and the library then walks the tree as handed over
+    for a while (stderr says so; vk_scene_info.tree_suspended_frames counts down) and tries the rebuilt tree again afterwards."""
     code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
             "import numpy as np\n"
             "from vecchio_amd import DeviceScene, HostScene, ffi\n"
-            "lib = ffi.load_device_lib()\n"
-            "def frames(flags):\n"
+            "def frames(flags, n):\n"
             "    hs = HostScene('stress_spheres:12', 1); hs.desc.contents.flags = flags; cam = hs.next_camera(); ds = DeviceScene(hs.desc)\n"
             "    out = []\n"
-            "    for k in range(2):\n"
+            "    for k in range(n):\n"
             "        img, st = ds.render(cam, hs.params(512, 8, 50, seed=4))\n"
-            "        rq = C.c_uint64(0); assert lib.vk_scene_last_requeued_samples(ds._h, C.byref(rq)) == 0\n"
-            "        out.append((img, rq.value, st.samples, st.scene_in_lds))\n"
+            "        out.append((img, ds.last_requeued_samples(), st.samples, st.scene_in_lds, ds.info().tree_suspended_frames))\n"
             "    return out\n"
-            "ref = frames(ffi.VK_SCENE_REFERENCE_TREE); x = frames(ffi.VK_SCENE_EMPIRICAL_TREES)\n"
-            "print('LDS', x[0][3], 'REQUEUED', x[0][1], x[1][1], 'OF', x[0][2])\n"
-            "print('EQUAL', all(np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) for a, b in zip(ref, x)))\n") % ROOT
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+            "ref = frames(ffi.VK_SCENE_REFERENCE_TREE, 1); x = frames(ffi.VK_SCENE_EMPIRICAL_TREES, 36)\n"
+            "print('LDS', x[0][3], 'REQUEUED', x[0][1], x[1][1], x[32][1], 'OF', x[0][2], 'SUSPENDED', x[0][4], x[1][4], x[31][4], x[32][4])\n"
+            "print('EQUAL', all(np.array_equal(ref[0][0].view(np.uint32), b[0].view(np.uint32)) for b in x))\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "EQUAL True" in r.stdout, r.stdout + r.stderr
-    words = r.stdout.split()
-    first, second, total = int(words[words.index("REQUEUED") + 1]), int(words[words.index("REQUEUED") + 2]), int(words[words.index("OF") + 1])
-    assert words[words.index("LDS") + 1] == "1"
-    assert second == 0, r.stdout          # (the first frame either went through the second launch or, its queues full, was rendered again)
-    assert "renders on the tree as handed over from now on" in r.stderr, r.stderr
+    w = r.stdout.split()
+    first, second, later, total = (int(w[w.index("REQUEUED") + k]) for k in (1, 2, 3)) + (int(w[w.index("OF") + 1]),)
+    susp = [int(w[w.index("SUSPENDED") + k]) for k in (1, 2, 3, 4)]
+    assert w[w.index("LDS") + 1] == "1"
+    assert first * 4 > total and second == 0, r.stdout       # frame 1: mostly requeued; frame 2: on the tree as handed over
+    assert susp[0] >= 31 and susp[1] == susp[0] - 1 and susp[2] <= 1, r.stdout
+    assert later * 4 > total and susp[3] >= 60, r.stdout      # frame 33 tried the rebuilt tree again, relapsed: paused twice as long
+    assert "renders on the tree as handed over for the next 32 frames" in r.stderr and "next 64 frames" in r.stderr, r.stderr
 
 
 def test_the_constructed_counter_example_on_the_device(device, oracle, monkeypatch):

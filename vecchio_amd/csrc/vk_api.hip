@@ -158,8 +158,15 @@ struct vk_scene {
     uint32_t *redo_count = nullptr;
     bool redo_last = false;        // the last render had a second launch
     unsigned long long *wave_times = nullptr;      // VK_WAVE_TIMES=1 (diagnostics)
-    bool exact_off = false;        // the second launch took more than a quarter of a frame's samples: the scene renders on the tree as
-                                   // handed over from then on (vk_scene_last_requeued_samples)
+    // The rebuilt tree is SUSPENDED for a while when a frame sends more than a quarter of its samples through the second launch, or
+    // overflows the queues between the launches (the fallback launch then renders the frame a third time): the scene renders on the tree
+    // as handed over until frame `exact_resume`, then tries again; every relapse doubles the pause (32 frames .. 4096).  An animation
+    // that passes through one bad viewpoint loses the rebuilt tree for a few dozen frames, not for good.  The verdict on a frame is read
+    // from `plan_host` (pinned; copied behind the frame's last kernel) when the NEXT frame is enqueued, without waiting, or where the
+    // caller synchronises anyway (vk_scene_last_requeued_samples).
+    uint64_t frame_no = 0, exact_resume = 0, exact_pause = 32;
+    uint32_t *plan_host = nullptr;     // [4] the last frame's redo_plan
+    bool plan_pending = false;         // a frame with a second launch has been enqueued and its plan not judged yet
     uint64_t redo_last_samples = 0;    // samples of the partition the last render covered
     unsigned long long *phase_stats = nullptr;   // device, 16 counters (diagnostic kernel build)
     bool want_phase_stats = false;
@@ -409,6 +416,22 @@ uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
     return n;
 }
 
+// The verdict on the last frame with a second launch (its plan has arrived in plan_host): see vk_scene::exact_resume.
+void judge_last_frame(vk_scene *s) {
+    s->plan_pending = false;
+    const uint32_t requeued = s->plan_host[1], lost = s->plan_host[2];
+    const bool heavy = (uint64_t)requeued * 4u > s->redo_last_samples && s->redo_last_samples >= (1u << 20);
+    if (lost != 0u || heavy) {
+        s->exact_resume = s->frame_no + s->exact_pause;
+        fprintf(stderr, "vecchio_amd: exact re-treeing %s (%u of %llu samples requeued, %u did not fit); this scene renders on the tree as "
+            "handed over for the next %llu frames\n", lost ? "overflowed its queues and the frame was rendered again" : "sent over a quarter of "
+            "a frame through the second launch", requeued, (unsigned long long)s->redo_last_samples, lost, (unsigned long long)s->exact_pause);
+        s->exact_pause = std::min<uint64_t>(s->exact_pause * 2u, 4096u);
+    } else if (s->exact_pause > 32u) {
+        s->exact_pause /= 2u;           // a clean frame on the rebuilt tree: relapses are forgiven step by step
+    }
+}
+
 // Enqueues one render of this call's tile partition into the f32 framebuffer d_out (device memory of s->device) on `st`.
 int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params *p, float *d_out, hipStream_t st, bool want_debug,
     vk_stats *stats) {
@@ -417,7 +440,10 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     KArgs A;
     memset(&A, 0, sizeof(A));
     A.S = s->dev;
-    bool exact = s->exact && !s->want_phase_stats && !s->exact_off;     // (the diagnostic builds have no second launch)
+    // the last frame's verdict, if it has finished (never waits)
+    if (s->plan_pending && hipEventQuery(s->ev1) == hipSuccess) judge_last_frame(s);
+    s->frame_no++;
+    bool exact = s->exact && !s->want_phase_stats && s->frame_no >= s->exact_resume;     // (the diagnostic builds have no second launch)
     A.C.cam = *cam;
     A.C.width = p->width; A.C.height = p->height; A.C.spp = p->samples_per_pixel; A.C.max_depth = p->max_depth;
     A.C.seed = p->seed; A.C.integrator = p->integrator; A.C.background = p->background;
@@ -467,6 +493,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         if (rc != VK_OK) return rc;
         HIP_TRY(hipEventRecord(s->ev1, st));
         s->last_timed = true;
+        s->redo_last = false; s->dual_last = false;      // (nothing was launched: no second launch, no unit split to judge)
         return VK_OK;
     }
     // Heavy-first tile order.  A launch ends when its slowest unit does, and tile costs are skewed (C2's glass tiles cost 8x
@@ -495,14 +522,16 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         // queues for the samples the first launch drops: room for 1/32 of the partition's samples (C2 drops 0.05 %; 8 bytes each: 0.5 GB
         // for C2's 2.1 G samples), spread over REDO_REGIONS; a full queue is reported where the caller synchronises
         // (vk_scene_last_requeued_samples), vk_render then renders the frame again on the tree as handed over
+        // (at most 256 MB: a frame that needs more overflows, and the fallback launch renders it on the tree as handed over)
         s->redo_last_samples = partition_samples(p, g);
-        per_region = s->redo_last_samples / 32u / REDO_REGIONS + 4096u;
+        per_region = std::min<uint64_t>(s->redo_last_samples / 32u / REDO_REGIONS + 4096u, (256ull << 20) / sizeof(uint2) / REDO_REGIONS);
         if (s->env.redo_region_cap >= 1) per_region = (uint64_t)s->env.redo_region_cap;      // tests
-        if (per_region * REDO_REGIONS >= 0xFFFFFFFFull) exact = false;      // (a frame of > 10^11 samples: on the tree as handed over)
     }
     if (exact) {
-        int rc = ensure(s->redo_list, s->redo_bytes, (size_t)per_region * REDO_REGIONS * sizeof(uint2));
-        if (rc != VK_OK) return rc;
+        // (no memory for the queues: this frame on the tree as handed over, which needs none)
+        if (ensure(s->redo_list, s->redo_bytes, (size_t)per_region * REDO_REGIONS * sizeof(uint2)) != VK_OK) { (void)hipGetLastError(); exact = false; }
+    }
+    if (exact) {
         HIP_TRY(hipMemsetAsync(s->redo_count, 0, (REDO_REGIONS * REDO_COUNT_STRIDE + 16) * sizeof(uint32_t), st));
         A.redo_list = s->redo_list; A.redo_count = s->redo_count; A.redo_plan = s->redo_count + REDO_REGIONS * REDO_COUNT_STRIDE;
         A.redo_region_cap = (uint32_t)per_region;
@@ -623,7 +652,18 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         B.shade_defer = SHADE_DEFER; B.prim_weight = s->hot_bytes > (4u << 20) ? 3u : 1u;
         rc = launch_by_features(s, F, B, lds, dim3((uint32_t)s->num_cus * s->wgs_per_cu), shmem, st, false);
         if (rc != VK_OK) return rc;
-        s->redo_last = true;
+        // ... and the fallback behind it: should a queue have overflowed, the sums are cleared and the partition is rendered on the tree
+        // as handed over, so that a frame is never incomplete whoever the caller is (nearly always: two launches that return at once)
+        hipLaunchKernelGGL(redo_reset_kernel, dim3(1024), dim3(256), 0, st, (const uint32_t *)plan, reinterpret_cast<unsigned long long *>(s->accum),
+            n_pixels * 3, s->counter);
+        KArgs Fb = A;
+        Fb.S = s->ref_view; Fb.list_mode = 2u; Fb.redo_list = nullptr; Fb.wave_times = nullptr;
+        if (lds) Fb.lds_items = Fb.S.n_items;
+        Fb.shade_defer = SHADE_DEFER; Fb.prim_weight = B.prim_weight;
+        rc = launch_by_features(s, F, Fb, lds, dim3(grid), shmem, st, false);
+        if (rc != VK_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(s->plan_host, plan, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        s->redo_last = true; s->plan_pending = true;
     }
     {
         uint32_t blocks = (uint32_t)((n_pixels + 255) / 256);
@@ -728,6 +768,7 @@ void destroy_one(vk_scene *s) {
         (void *)s->tile_cost,
                     (void *)s->tile_order, (void *)s->order_hist, (void *)s->slab, (void *)s->redo_list, (void *)s->redo_count})
         if (p) (void)hipFree(p);
+    if (s->plan_host) (void)hipHostFree(s->plan_host);
     if (s->landing) { (void)hipSetDevice(s->landing_device); (void)hipFree(s->landing); (void)hipSetDevice(s->device); }
     for (hipEvent_t e : {s->ev0, s->ev1, s->ev_landed, s->ev_begin, s->ev_fork, s->ev_join})
         if (e) (void)hipEventDestroy(e);
@@ -821,6 +862,8 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
         s->ref_view.ref_items = nullptr; s->ref_view.n_ref_items = 0; s->ref_view.t_pad = 0.0f; s->ref_view.gate_scale = 1.0f;
         s->ref_view.tmin_gate = T_MIN; s->ref_view.tie_rank = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->redo_count), (REDO_REGIONS * REDO_COUNT_STRIDE + 16) * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->plan_host), 4 * sizeof(uint32_t), hipHostMallocDefault));
+        memset(s->plan_host, 0, 4 * sizeof(uint32_t));
     }
     if (s->dual_launch) {
         HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
@@ -943,6 +986,10 @@ int vk_scene_get_info(const vk_scene *s, vk_scene_info *out) {
     out->features = pick_variant(one);
     out->tree = !H.ref_items.empty() ? (H.proven ? VK_TREE_REBUILT_PROVEN : VK_TREE_REBUILT_EMPIRICAL)
                                      : (!H.tie_rank.empty() ? VK_TREE_REBUILT_FAST : VK_TREE_HANDED_OVER);
+    out->tree_suspended_frames = 0;
+    for (const vk_scene *q : (s->parts.empty() ? std::vector<vk_scene *>{const_cast<vk_scene *>(s)} : s->parts))
+        if (q->exact_resume > q->frame_no + 1u) out->tree_suspended_frames = std::max<uint32_t>(out->tree_suspended_frames,
+            (uint32_t)(q->exact_resume - q->frame_no - 1u));
     return VK_OK;
 }
 
@@ -1031,15 +1078,15 @@ int vk_scene_last_clamped_samples(vk_scene *s, uint64_t *out) {
 }
 
 // Exact re-treeing: samples of the last render that the first launch handed to the second one (rendered on the tree as handed
-// over); waits for the render's end.  A queue that overflowed (more than an eighth of the samples, or a very uneven spread) means
-// the frame is INCOMPLETE: reported as an error here, in vk_scene_last_kernel_ms and by vk_render.
+// over); waits for the render's end.  A frame whose queues overflowed is complete all the same (the fallback launch rendered it on the
+// tree as handed over: enqueue_render_f32); it counts as entirely requeued.
 int vk_scene_last_requeued_samples(vk_scene *s, uint64_t *out) {
     if (!s || !out) return fail(VK_ERR_BAD_ARG, "null argument");
     if (!s->last_timed) return fail(VK_ERR_BAD_ARG, "no render enqueued yet");
     *out = 0;
     if (!s->parts.empty()) {
         int worst = VK_OK;
-        for (vk_scene *q : s->parts) {       // (every part is asked: each one switches itself off after an overflow)
+        for (vk_scene *q : s->parts) {
             uint64_t v = 0;
             int rc = vk_scene_last_requeued_samples(q, &v);
             if (rc != VK_OK) worst = rc;
@@ -1050,26 +1097,9 @@ int vk_scene_last_requeued_samples(vk_scene *s, uint64_t *out) {
     if (!s->redo_last) return VK_OK;
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipEventSynchronize(s->ev1));
-    uint32_t plan[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(plan, s->redo_count + REDO_REGIONS * REDO_COUNT_STRIDE, sizeof(plan), hipMemcpyDeviceToHost));
-    *out = plan[1];
-    if (!s->exact_off && (uint64_t)plan[1] * 4u > s->redo_last_samples && s->redo_last_samples >= (1u << 20)) {
-        // (e.g. a field of spheres on a ground sphere of radius 1e5 seen from above: most hits on the ground are "early")
-        s->exact_off = true;
-        fprintf(stderr, "vecchio_amd: exact re-treeing sent %u of %llu samples through the second launch; this scene renders on the tree "
-            "as handed over from now on\n", plan[1], (unsigned long long)s->redo_last_samples);
-    }
-    if (plan[2] != 0u) s->exact_off = true;      // (later frames render on the tree as handed over; vk_render repeats this one)
-    if (plan[2] != 0u) return fail(VK_ERR_OOM, "exact re-treeing: " + std::to_string(plan[2]) +
-        " samples did not fit the redo queues, the frame is "
-        "incomplete (VK_RETREE=0 or VK_SCENE_REFERENCE_TREE renders on the tree handed over)");
+    *out = s->plan_host[2] != 0u ? s->redo_last_samples : s->plan_host[1];
+    if (s->plan_pending) judge_last_frame(s);
     return VK_OK;
-}
-
-// did the last frame's redo queues overflow and has every part been switched off exact re-treeing since?
-static bool redo_overflow_handled(const vk_scene *s) {
-    if (!s->parts.empty()) { bool any = false; for (const vk_scene *q : s->parts) any |= q->exact_off; return any; }
-    return s->exact_off;
 }
 
 static int render_host(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, void *out_host, vk_stats *stats_out,
@@ -1089,17 +1119,14 @@ static int render_host(vk_scene *scene, const vk_camera *cam, const vk_render_pa
     if (rc != VK_OK) return rc;
     vk_stats st;
     double ms = 0.0;
-    for (int attempt = 0; ; attempt++) {
+    {
         memset(&st, 0, sizeof(st));
         rc = enqueue_render(scene, cam, params, d_img, nullptr, debug_out != nullptr, &st);
         if (rc != VK_OK) return rc;
         HIP_TRY(hipStreamSynchronize(nullptr));
         uint64_t requeued = 0;
-        rc = vk_scene_last_requeued_samples(scene, &requeued);
-        // exact re-treeing's queues overflowed: the scene has just been switched to the tree as handed over, render the frame again
-        if (rc == VK_ERR_OOM && attempt == 0 && redo_overflow_handled(scene)) continue;
+        rc = vk_scene_last_requeued_samples(scene, &requeued);      // (judges the frame: see vk_scene::exact_resume)
         if (rc != VK_OK) return rc;
-        break;
     }
     rc = vk_scene_last_kernel_ms(scene, &ms);
     if (rc != VK_OK) return rc;

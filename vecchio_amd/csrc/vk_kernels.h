@@ -60,6 +60,9 @@ struct KArgs {
     // k = u / REDO_REGIONS, for k below the slice count redo_plan_kernel leaves in redo_plan[0] and n = redo_plan[3] entries per unit.
     // redo_list == null: nothing is dropped
     // (the probe launch, scenes without a rebuilt tree).
+    // list_mode = 2: the FALLBACK launch behind the second one — an ordinary launch over the tiles on the scene as handed over, which runs
+    // only if redo_plan[2] != 0, i.e. if a queue overflowed and the frame of the first two launches is incomplete (redo_reset_kernel has
+    // zeroed the sums by then); otherwise every workgroup returns at once.
     uint2 *redo_list; uint32_t *redo_count; const uint32_t *redo_plan; uint32_t redo_region_cap; uint32_t list_mode;
     // diagnostic builds (-DVK_WAVE_TIMES, with the environment's VK_WAVE_TIMES=1): per wave {start, last unit pull, end}, 100 MHz ticks
     unsigned long long *wave_times;
@@ -414,13 +417,13 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool e
         uint32_t txy = __builtin_amdgcn_readfirstlane(ws.x), s0 = __builtin_amdgcn_readfirstlane(ws.y);
         uint32_t total = __builtin_amdgcn_readfirstlane(ws.z), next = __builtin_amdgcn_readfirstlane(ws.w);
         // the second launch of exact re-treeing (sphere-only variants): units are slices of the redo queues
-        const bool list_mode = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) && LDS_SCENE && KARG(P, list_mode) != 0u;
+        const bool list_mode = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) && LDS_SCENE && KARG(P, list_mode) == 1u;
         if (next >= total) {
             uint32_t unit = 0;
             if (lane == 0) {
                 unit = atomicAdd(KARG(P, counter), 1u);
                 // (once per 2 048 samples or more; the dual launch's self-check counts the first launch's units only)
-                if (!list_mode) atomicAdd(KARG(P, launch_units) + (blockDim.x == 1024u ? 0 : 1), 1u);
+                if (KARG(P, list_mode) == 0u) atomicAdd(KARG(P, launch_units) + (blockDim.x == 1024u ? 0 : 1), 1u);
             }
             unit = __builtin_amdgcn_readfirstlane(unit);
             if (list_mode) {
@@ -553,6 +556,10 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
         st_t_mat = 0, st_t_refill = 0, st_t_install = 0, st_t1 = 0;
     if (STATS) st_t_total = clock64();
 
+    if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && LDS_SCENE) {      // the fallback launch of exact re-treeing: nothing to do, nearly always
+        KArgsC P = kargs_fresh();
+        if (KARG(P, list_mode) == 2u && KARG(P, redo_plan)[2] == 0u) return;
+    }
     // ---- LDS layout: [items][spheres][boxes][per wave: cold lane state | tile sums | wave state]
     uint32_t lds_items = 0;
     float *cold;
@@ -827,6 +834,15 @@ __global__ void redo_plan_kernel(const uint32_t *count, uint32_t cap, uint32_t *
         while (unit < REDO_UNIT && (uint64_t)s_total > (uint64_t)unit * n_waves * 2u) unit *= 2u;
         plan[0] = (s_max + unit - 1u) / unit; plan[1] = s_total; plan[2] = s_lost; plan[3] = unit;
     }
+}
+
+// Behind the second launch: if a queue overflowed (plan[2] != 0) the frame is incomplete — the sums and the unit counter are cleared and the
+// fallback launch (list_mode = 2) renders the partition again on the tree as handed over.  Nearly always: nothing.
+__global__ void redo_reset_kernel(const uint32_t *plan, unsigned long long *accum, size_t n_words, uint32_t *counter) {
+    if (plan[2] == 0u) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { counter[0] = 0u; counter[2] = 0u; counter[3] = 0u; }      // the unit counter and the clamped-sample count
+    for (size_t k = i; k < n_words; k += (size_t)gridDim.x * blockDim.x) accum[k] = 0ull;
 }
 
 // ---- heavy-first tile order (bucket sort of the probe's per-tile times, dearest first).

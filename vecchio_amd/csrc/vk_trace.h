@@ -550,11 +550,14 @@ VK_HD bool segment_unsafe(const Lane &L, const DScene &S, const Mem &M) {
             y0 = (by0 - L.o.y) * L.inv.y; y1 = (by1 - L.o.y) * L.inv.y;
             z0 = (bz0 - L.o.z) * L.inv.z; z1 = (bz1 - L.o.z) * L.inv.z;
         }
-        // AxisBB::hit of the own box with tmax = the winner's t (scaled like the reciprocals), as box_step_core decides it — but a
-        // decision inside the margin counts as a miss
-        const float lo = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), S.tmin_gate));
-        const float hi = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), L.T * S.gate_scale));
-        const bool passes = hi - lo > __builtin_fmaf(fabsf(hi), 4.0e-6f, L.xnan);      // false for a NaN margin
+        // AxisBB::hit of the own box with tmax = the winner's t (scaled like the reciprocals): max(entry, tmin) < min(exit, t), i.e.
+        // entry < min(exit, t) and tmin < exit (tmin < t holds for every accepted hit) — as box_step_core decides it, but a decision
+        // inside the margin counts as a miss.  (An origin inside the box has a negative entry: nothing about it is in doubt.)
+        const float entry = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+        const float ex = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        const float hi = fminf(ex, L.T * S.gate_scale);
+        const bool passes = (hi - entry > __builtin_fmaf(fabsf(hi), 4.0e-6f, L.xnan)) &&     // (false for a NaN margin)
+                            (ex - S.tmin_gate > __builtin_fmaf(fabsf(ex), 4.0e-6f, L.xnan));
         unsafe = unsafe || !passes || !(sp.r > 0.0f);
     }
     return unsafe;

@@ -130,7 +130,8 @@ class Stats(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_items", C.c_uint32), ("n_prims", C.c_uint32), ("n_instances", C.c_uint32),
-                ("device_bytes", C.c_uint64), ("lds_bytes", C.c_uint32), ("features", C.c_uint32), ("tree", C.c_uint32)]
+                ("device_bytes", C.c_uint64), ("lds_bytes", C.c_uint32), ("features", C.c_uint32), ("tree", C.c_uint32),
+                ("tree_suspended_frames", C.c_uint32)]
 
 
 VK_TREE_HANDED_OVER, VK_TREE_REBUILT_PROVEN, VK_TREE_REBUILT_EMPIRICAL, VK_TREE_REBUILT_FAST = range(4)
