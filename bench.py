@@ -19,9 +19,11 @@ Also reported in the same JSON line:
                rocprofv3 PMC pass of this command, 2 cycles each on a SIMD-32, 1024 SIMDs x 2.4 GHz)
   cpu_baseline the oracle (restated CPU path, "port") timed on this box's host cores on a bounded sample of the
                same workload (N = 1 only)
-  config.also  one step each of the other BASELINE configs at full size (C4, C3, C5), of C2 and C5 on the tree handed over alone
-               (VK_SCENE_REFERENCE_TREE: no exact re-treeing) and of C2 with VK_SCENE_FAST_ACCEL, each verified the same way
-               (N = 1 only; --no-also skips them)
+  handed_over_tree  one step of the same workload with VK_SCENE_REFERENCE_TREE (the tree of the description, nothing rebuilt), verified
+               the same way: what the rebuilt tree of exact re-treeing is worth (N = 1 only)
+  config.also  one step each of the other BASELINE configs at full size (C4, C3, C5 — C5 as the default walks it, i.e. on the tree as
+               handed over, AND with VK_SCENE_EMPIRICAL_TREES), of C2 in the empirical form and with VK_SCENE_FAST_ACCEL, each verified
+               the same way (N = 1 only; --no-also skips them)
 """
 import argparse
 import ctypes as C
@@ -35,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2.0   # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles, 2.4 GHz max clock
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 WORKLOADS = {
     # name: (scene builder, width, spp, max_depth, label)
@@ -68,7 +70,7 @@ LDS_PEAK_BPS = 150e12           # MI355X_MICROARCH.md: ~150 TB/s aggregate for d
 L2_PEAK_BPS = 34.5e12           # MI355X_MICROARCH.md: ~34.5 TB/s aggregate L2
 
 
-def physical_bounds(c, samples, seconds, scene_in_lds, issue):
+def physical_bounds(c, samples, seconds, scene_in_lds, issue, walked=None):
     """What physically limits the kernel, every fraction <= 1 by construction (unlike the algorithmic-HBM `roofline`, whose bytes
     are served from LDS / L2):
       valu_issue  vector instruction issue: wave-instructions/s against 1024 SIMDs x 2.4 GHz / 2 cycles; x lane fill = the share of
@@ -81,13 +83,17 @@ def physical_bounds(c, samples, seconds, scene_in_lds, issue):
     n = float(c["samples"])
     rec = 32.0 * (c["n_aabb"] - c["n_aabb_nonfinite"]) + 16.0 * (c["n_sphere"] - c["n_sphere_nonfinite"]) + 36.0 * c["n_moving"] + 24.0 * c["n_rect"] + \
         32.0 * c["n_xform"] + 8.0 * c["n_medium"]
+    note = "record bytes from the oracle's visit counts: the device walks the same tree, item for item"
+    if walked:      # the device walks a rebuilt tree: its own visits (tests/emu, the kernel's per-lane code on the host, same sample)
+        rec = (32.0 * walked["box_tests"] + 16.0 * walked["sphere_tests"]) * n
+        note = ("record bytes of the walk the device performs (rebuilt tree, second walks and requeued samples included), counted by the "
+                "kernel's per-lane code built for the host (tests/emu) on the same bounded sample as the oracle's counters")
     rate = rec / n * samples / seconds
     out = {"bound": "valu_issue", "unit": "wave-instr/s", "achieved": None, "peak": VALU_WAVE_INSTR_PER_S, "frac": None,
            "lane_fill": None, "useful_lane_frac": None,
            "memory": {"level": "lds" if scene_in_lds else "l2", "record_bytes_per_sample": round(rec / n, 1), "achieved_Bps": round(rate, 1),
                       "peak_Bps": LDS_PEAK_BPS if scene_in_lds else L2_PEAK_BPS, "frac": round(rate / (LDS_PEAK_BPS if scene_in_lds else L2_PEAK_BPS), 4),
-                      "note": "record bytes from the oracle's visit counts on the tree as handed over: an upper bound where the device walks "
-                              "a rebuilt tree (exact re-treeing of scenes of spheres only: about 0.7x the box tests on C2, 0.5x on C5)"}}
+                      "note": note}}
     if issue:
         out.update(achieved=issue["achieved_wave_instr_per_s"], frac=issue["frac"], lane_fill=issue["lane_fill"],
                    useful_lane_frac=round(issue["frac"] * issue["lane_fill"], 4), counters=issue.get("note"))
@@ -230,6 +236,8 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the single steps of the other BASELINE configs")
     ap.add_argument("--reference-tree", action="store_true", help="set VK_SCENE_REFERENCE_TREE: walk only the tree handed over (no exact "
                     "re-treeing of scenes of spheres only)")
+    ap.add_argument("--empirical-trees", action="store_true", help="set VK_SCENE_EMPIRICAL_TREES: rebuilt trees also where their exactness is "
+                    "measured, not proven (include/vecchio_amd.h)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not measure the HBM traffic of a launch now (two one-step child runs under rocprofv3 --pmc); "
                          "roofline.traffic then comes from the committed profile")
@@ -283,8 +291,11 @@ def main():
     import oracle_ffi as O
     cores = usable_cpus()          # threads for the oracle: affinity mask capped by the cgroup quota
 
+    TREE_NAMES = {0: "handed over", 1: "rebuilt, proven (exact re-treeing with grown gates)", 2: "rebuilt, empirical (VK_SCENE_EMPIRICAL_TREES)",
+                  3: "rebuilt object by object (VK_SCENE_FAST_ACCEL)"}
+
     def run_workload(name, steps, warmup, spp_override=0, want_cpu=False, bvh="reference", fast_accel=False, live_traffic=False,
-                     handed_over_tree=False):
+                     handed_over_tree=False, empirical=False):
         scene_name, width, spp, depth, label = WORKLOADS[name]
         if spp_override:
             spp = spp_override
@@ -298,11 +309,16 @@ def main():
             hs.desc.contents.flags = ffi.VK_SCENE_FAST_ACCEL
             label += " [VK_SCENE_FAST_ACCEL: draw-free subtrees rebuilt by the library]"
         if handed_over_tree:
-            # the default for a scene of spheres only is exact re-treeing (vk_trace.h winner_is_early); this walks the tree as built by
+            # the default for a scene of spheres only is exact re-treeing (vk_trace.h segment_unsafe); this walks the tree as built by
             # the host mirror of BVHNode::new and nothing else
             from vecchio_amd import ffi
             hs.desc.contents.flags = ffi.VK_SCENE_REFERENCE_TREE
             label += " [VK_SCENE_REFERENCE_TREE: only the tree handed over]"
+        if empirical:
+            # rebuilt trees also where their exactness is measured, not proven (include/vecchio_amd.h)
+            from vecchio_amd import ffi
+            hs.desc.contents.flags = ffi.VK_SCENE_EMPIRICAL_TREES
+            label += " [VK_SCENE_EMPIRICAL_TREES]"
         cam = hs.next_camera()
         params = hs.params(width, spp, depth, seed=2, tile_rank=rank, tile_world=world)   # render seed 2
         height = params.height
@@ -379,13 +395,28 @@ def main():
             bps = algorithmic_bytes_per_sample(c, spp)
             sphere_only = info.features == 0       # the sphere-only kernel variant: the one that skips those walks
             bps_walked = algorithmic_bytes_per_sample(c, spp, walked_only=sphere_only)
+            # The walk the device PERFORMS.  On the tree as handed over it is the oracle's, item for item (minus the NaN rays' walks).  On a
+            # rebuilt tree it is counted by the kernel's own per-lane code built for the host (tests/emu: same linearisation, same gates,
+            # second walks and requeued samples included) on the same bounded sample.
+            walked = None
+            if info.tree != 0 and sphere_only:
+                import emu_ffi
+                os.environ["EMU_GLOBAL_VARIANT"] = "0" if info.lds_bytes else "1"
+                emu_ffi.take_visit_counts()
+                pe = hs.params(cw, 1, depth, seed=2)
+                _, ps_e, _, _ = emu_ffi.render_samples(hs.desc, cam, pe, threads=cores)
+                nb, ns = emu_ffi.take_visit_counts()
+                ne = float(ps_e.shape[0])
+                walked = {"box_tests": nb / ne, "sphere_tests": ns / ne, "oracle_box_tests": c["n_aabb"] / float(c["samples"]),
+                          "oracle_sphere_tests": c["n_sphere"] / float(c["samples"])}
+                bps_walked = 32.0 * walked["box_tests"] + 16.0 * walked["sphere_tests"] + 16.0 * c["n_closest"] / float(c["samples"]) + 12.0 / spp
             k_ms = float(np.mean(kernel_ms)) if kernel_ms else None
             # measured HBM traffic and instruction counts per launch: PMC counters cannot be collected from inside this
             # process, so they come from the committed rocprofv3 passes of this same command (profiles/, tests/prof_r02.sh):
             # WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950: FETCH_SIZE counts half the bytes of wide reads -> upper bound)
             traffic, issue, prof_path = None, None, None
             t_read = t_write = scratch_share = scratch_detail = None
-            if n_gpus == 1 and not spp_override and bvh == "reference" and not fast_accel and not handed_over_tree:
+            if n_gpus == 1 and not spp_override and bvh == "reference" and not fast_accel and not handed_over_tree and not empirical:
                 prof, prof_path = pmc_summary(name)
                 if prof:
                     d = prof.get("derived", {})
@@ -405,7 +436,7 @@ def main():
                                          "kernel time; frac x lane_fill = share of the 78.6 T lane-instr/s the kernel's useful lanes occupy"}
             traffic_note = (f"HBM bytes per launch from the committed rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this command ({prof_path}), "
                             "not re-measured in this run")
-            if live_traffic and not spp_override and bvh == "reference" and not fast_accel and not handed_over_tree:
+            if live_traffic and not spp_override and bvh == "reference" and not fast_accel and not handed_over_tree and not empirical:
                 live, why = measure_counters_live(name)
                 if live is not None:
                     traffic_note = ("HBM bytes of one launch MEASURED IN THIS RUN: one-step child runs of this script under rocprofv3 --pmc "
@@ -444,15 +475,19 @@ def main():
                         "algorithmic_bytes_per_sample": round(bps, 1), "kernel_ms": round(k_ms, 3),
                         "algorithmic_bytes_per_sample_walked": round(bps_walked, 1),
                         "frac_walked": round(achieved * bps_walked / bps / HBM_PEAK_GBPS, 4),
-                        "walked_note": "the same, without the whole-tree walks of NaN / infinite rays that the reference performs and the device "
-                                       "skips in sphere-only scenes (their outcome is a miss); equal to frac for every other scene",
+                        "walked": walked,
+                        "walked_note": "the bytes of the walk the device PERFORMS: on the tree as handed over the oracle's visits without the "
+                                       "whole-tree walks of NaN / infinite rays (the device skips them in sphere-only scenes: their outcome is a "
+                                       "miss); on a rebuilt tree the visits of that tree, second walks included (`walked`), counted by the "
+                                       "kernel's per-lane code on the host.  algorithmic_bytes_per_sample (SURVEY 8d: the oracle on the tree "
+                                       "handed over) stays the contract value.",
                         "note": "algorithmic bytes (SURVEY 8d record sizes x oracle visit counts); the scene is LDS/L2 resident, so this is not "
                                 "a physical bound (it can exceed 1): the physical one is `issue`",
                         "issue": issue}
-            physical = physical_bounds(c, local_samples, k_ms * 1e-3, bool(info.lds_bytes), issue) if k_ms else None
+            physical = physical_bounds(c, local_samples, k_ms * 1e-3, bool(info.lds_bytes), issue, walked) if k_ms else None
             res = {"value": round(value, 2), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
                    "physical": physical, "kernel_ms": k_ms, "requeued_samples": ds.last_requeued_samples(),
-                   "label": label, "integrator": "scatter" if hs.integrator else "pdf", "bvh_items": info.n_items,
+                   "label": label, "integrator": "scatter" if hs.integrator else "pdf", "bvh_items": info.n_items, "tree": TREE_NAMES.get(info.tree),
                    "scene_in_lds": bool(info.lds_bytes), "verified": verified, "roofline": roof, "cpu_baseline": cpu}
         if world > 1:
             # what a driver needs to see that N ranks really ran: every rank's device, and the gathered image against ONE device's
@@ -478,13 +513,19 @@ def main():
 
     main_res = run_workload(args.workload, args.steps, args.warmup, args.spp, want_cpu=(n_gpus == 1 and not args.no_cpu), bvh=args.bvh,
                             fast_accel=args.fast_accel, live_traffic=(n_gpus == 1 and world == 1 and not args.no_traffic and not rehearsal),
-                            handed_over_tree=args.reference_tree)
+                            handed_over_tree=args.reference_tree, empirical=args.empirical_trees)
     also = []
+    handed_over = None
+    if n_gpus == 1 and not args.no_also and not args.spp and not args.reference_tree and rank == 0:
+        # the same workload on the tree of the description alone: the number the rebuilt tree has to be read against
+        r = run_workload(args.workload, 1, 1, 0, handed_over_tree=True)
+        handed_over = {"value": r["value"], "unit": "Msamples/s", "ms_per_step": r["ms_per_step"], "kernel_ms": r["kernel_ms"], "steps": 1, "warmup": 1,
+                       "workload": r["label"], "verified": r["verified"]}
     if n_gpus == 1 and not args.no_also and args.workload == "C2" and not args.spp:
-        for name, spp_o, fa, ho in (("C4", 0, False, False), ("C3", 0, False, False), ("C5", 0, False, False), ("C2", 0, False, True),
-                                    ("C5", 0, False, True), ("C2", 0, True, False)):
-            r = run_workload(name, 1, 0, spp_o, fast_accel=fa, handed_over_tree=ho)
-            also.append({"workload": r["label"], "Msamples_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": 1,
+        for name, spp_o, fa, ho, emp in (("C4", 0, False, False, False), ("C3", 0, False, False, False), ("C5", 0, False, False, False),
+                                         ("C5", 0, False, False, True), ("C2", 0, False, False, True), ("C2", 0, True, False, False)):
+            r = run_workload(name, 1, 0, spp_o, fast_accel=fa, handed_over_tree=ho, empirical=emp)
+            also.append({"workload": r["label"], "tree": r["tree"], "Msamples_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": 1,
                          # one step, no warm-up: `Msamples_per_s` includes the variant's first-use costs (code-object load, buffer
                          # allocation); the kernel-time rate does not and is the one comparable with the headline
                          "requeued_samples": r["requeued_samples"],
@@ -503,12 +544,13 @@ def main():
             "config": {"workload": r["label"], "scene_seed": 1, "render_seed": 2,
                        "integrator": r["integrator"], "tiles": "8x8 round-robin over ranks", "multi_gpu": mode,
                        "bvh_builder": args.bvh, "bvh_items": r["bvh_items"], "scene_in_lds": r["scene_in_lds"],
-                       # scenes of spheres only are walked on a tree rebuilt over the reference's leaf units; where a segment's winner could
-                       # depend on the visiting order the tree handed over decides (vk_trace.h winner_is_early).  `requeued_samples`: the
-                       # samples of the last step that went through the second launch for that (scenes staged in LDS)
-                       "tree": "handed over" if args.reference_tree else ("VK_SCENE_FAST_ACCEL" if args.fast_accel else "exact re-treeing (default)"),
+                       # scenes of spheres only may be walked on a tree rebuilt over the reference's leaf units; where the rebuilt walk's
+                       # winner is not certain to be the reference's, the tree handed over decides (vk_trace.h segment_unsafe).
+                       # `requeued_samples`: the samples of the last step that went through the second launch for that (scenes in LDS)
+                       "tree": r["tree"],
                        "requeued_samples": r["requeued_samples"], "also": also},
             "verified": r["verified"], "roofline": r["roofline"], "physical": r["physical"], "cpu_baseline": r["cpu_baseline"],
+            "handed_over_tree": handed_over,
         }
         if r.get("distributed"):
             out["distributed"] = r["distributed"]

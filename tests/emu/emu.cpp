@@ -20,6 +20,9 @@ using namespace vkd;
 
 static thread_local std::string g_err;
 static std::atomic<uint64_t> g_redo(0), g_segments(0);      // exact re-treeing: segments walked twice / all segments
+// what the device's walk visits (bench.py: the algorithmic bytes of the walk performed, next to the oracle's on the tree handed over):
+// box tests (one per item stepped over) and sphere tests of scenes of spheres only, second walks and samples rendered again included
+static std::atomic<uint64_t> g_box_tests(0), g_sphere_tests(0);
 
 // VK_RETREE=0/1 forces re-treeing off / on (same switch as the device library); default: vk_scene_desc.flags
 static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string &err) {
@@ -65,7 +68,13 @@ static void trace_one(const DScene &S, const GlobalMem &M0, const RenderConsts &
     start_sample<F, Mem>(L, S, C, pixel % C.width, pixel / C.width, sample);
     bool on_ref = false;      // the segment just walked was walked on the tree as handed over
     for (;;) {
-        while (traversing(L)) { traverse_step<F, Mem>(L, S, M); if (steps) (*steps)++; }
+        uint64_t nb = 0, ns = 0;
+        while (traversing(L)) {
+            if (has_prim_work(L)) ns += ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && L.pend2) ? 2u : 1u; else nb++;
+            traverse_step<F, Mem>(L, S, M);
+            if (steps) (*steps)++;
+        }
+        g_box_tests += nb; g_sphere_tests += ns;
         const bool early = !on_ref && segment_unsafe<F, Mem>(L, S, M);
         if (getenv("EMU_TRACE")) fprintf(stderr, "  seg depth %u o (%.9g %.9g %.9g) d (%.9g %.9g %.9g) T %.9g prim %08x early %d on_ref %d t_pad %g\n", L.depth,
             L.o.x, L.o.y, L.o.z, L.d.x, L.d.y, L.d.z, L.T, L.best_prim, (int)early, (int)on_ref, S.t_pad);
@@ -161,6 +170,8 @@ const char *emu_last_error(void) { return g_err.c_str(); }
 
 // exact re-treeing: samples rendered again on the tree as handed over since the last call (and segments walked)
 void emu_take_redo_stats(uint64_t out[2]) { out[0] = g_redo.exchange(0); out[1] = g_segments.exchange(0); }
+// box tests and (scenes of spheres only) sphere tests of every walk since the last call
+void emu_take_visit_counts(uint64_t out[2]) { out[0] = g_box_tests.exchange(0); out[1] = g_sphere_tests.exchange(0); }
 
 // the full-feature variants, and for scenes of spheres only the sphere-only ones (as the device library picks them: they
 // run the fused box test, vk_trace.h set_space); the Cornell-type variants in between are the same code as the full ones

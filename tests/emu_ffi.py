@@ -46,3 +46,12 @@ def take_redo_stats():
     out = (C.c_uint64 * 2)()
     lib.emu_take_redo_stats(out)
     return int(out[0]), int(out[1])
+
+
+def take_visit_counts():
+    """(box tests, sphere tests) of every walk since the last call — second walks and samples rendered again included; sphere tests are
+    counted for scenes of spheres only (other scenes: primitive steps)"""
+    lib = load()
+    out = (C.c_uint64 * 2)()
+    lib.emu_take_visit_counts(out)
+    return int(out[0]), int(out[1])

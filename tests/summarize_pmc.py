@@ -11,8 +11,10 @@ frames = int(sys.argv[4]) if len(sys.argv) > 4 else 0       # frames rendered pe
 cmd = open(os.path.join(src, "command.txt")).read().strip() if os.path.exists(os.path.join(src, "command.txt")) else "bench.py --steps 2 --warmup 1 --no-cpu"
 out = {"command": f"rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 {cmd} (separate passes; see tests/prof_r03.sh)",
        "samples_per_dispatch": samples, "counters_per_dispatch": {}}
+single = {}
 for f in sorted(glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv")):
     agg = collections.defaultdict(list)
+    is_single = "/pmc_sq2_single/" in f
     for r in csv.DictReader(open(f)):
         # the production build of the megakernel only (..., false, false>): not the probe (COST) launch that precedes it
         if "render_kernel" in r["Kernel_Name"] and ", true>(" not in r["Kernel_Name"]:
@@ -21,6 +23,9 @@ for f in sorted(glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv")):
             if "dispatch" not in out:
                 out["dispatch"] = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
     for k, v in agg.items():
+        if is_single:      # the single-launch shape (VK_NO_DUAL_LAUNCH=1): kept apart
+            single[k] = sum(v) / (frames if frames else len(v))
+            continue
         # per frame: a frame may be more than one dispatch of the production kernel (the dual launch of sphere-only LDS scenes)
         out["counters_per_dispatch"][k] = sum(v) / (frames if frames else len(v))
         out["dispatches_per_frame"] = len(v) / frames if frames else 1
@@ -35,6 +40,19 @@ if "SQ_THREAD_CYCLES_VALU" in c:
 if "SQ_WAVE_CYCLES" in c and "SQ_WAIT_ANY" in c:
     w = c["SQ_WAVE_CYCLES"]
     d["wave_time_split"] = {"issuing": c["SQ_ACTIVE_INST_ANY"] / w, "waiting(s_waitcnt)": c["SQ_WAIT_ANY"] / w, "issue_stall": c["SQ_WAIT_INST_ANY"] / w}
+if single.get("SQ_WAVE_CYCLES"):
+    w = single["SQ_WAVE_CYCLES"]
+    d["wave_time_split_single_launch_shape"] = {"issuing": single["SQ_ACTIVE_INST_ANY"] / w, "waiting(s_waitcnt)": single["SQ_WAIT_ANY"] / w,
+        "issue_stall": single["SQ_WAIT_INST_ANY"] / w, "waves": single.get("SQ_WAVES"),
+        "note": "VK_NO_DUAL_LAUNCH=1: 2 x 768-thread workgroups per CU (six waves per SIMD), the shape that runs under the counter profiler as "
+                "it is timed; the 16 + 12-wave dual launch is serialised by the profiler, so `wave_time_split` above describes a 16-wave and "
+                "a 12-wave run one after the other, not the timed kernel"}
+    out["counters_single_launch_shape"] = single
+if "TCC_ATOMIC_sum" in c:
+    d["l2_write_requests_per_frame"] = {"writes": c.get("TCC_WRITE_sum"), "atomics": c["TCC_ATOMIC_sum"], "to_memory_writes": c.get("TCC_EA0_WRREQ_sum"),
+        "to_memory_atomics": c.get("TCC_EA0_ATOMIC_sum"),
+        "note": "the kernel's vector-memory writes: 64-bit atomic adds of the fixed-point pixel sums (unit flushes + stragglers) against plain stores "
+                "(register spills, redo queue entries, per-sample debug dumps)"}
 if "SQ_LDS_BANK_CONFLICT" in c:
     d["lds_bank_conflict_fraction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
 if "SQ_INSTS_VALU" in c and "SQ_BUSY_CYCLES" in c:

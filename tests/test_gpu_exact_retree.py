@@ -111,7 +111,8 @@ def test_scene_with_mostly_early_winners_suspends_the_rebuilt_tree(device):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "EQUAL True" in r.stdout, r.stdout + r.stderr
     w = r.stdout.split()
-    first, second, later, total = (int(w[w.index("REQUEUED") + k]) for k in (1, 2, 3)) + (int(w[w.index("OF") + 1]),)
+    first, second, later = (int(w[w.index("REQUEUED") + k]) for k in (1, 2, 3))
+    total = int(w[w.index("OF") + 1])
     susp = [int(w[w.index("SUSPENDED") + k]) for k in (1, 2, 3, 4)]
     assert w[w.index("LDS") + 1] == "1"
     assert first * 4 > total and second == 0, r.stdout       # frame 1: mostly requeued; frame 2: on the tree as handed over
