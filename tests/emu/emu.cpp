@@ -81,7 +81,7 @@ static void trace_one(const DScene &S, const GlobalMem &M0, const RenderConsts &
         on_ref = false;
         if (S.walk_start != 0u && early) {                      // exact re-treeing, both trees in items[] (the device's global-memory
             g_redo++;                                           // scenes): this segment again, on the tree as handed over
-            begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, L.o, L.d, L.time, true);
+            begin_segment<Mem::ISHIFT, fused_box<F, Mem>(), spheres_only<F>()>(L, S, L.o, L.d, L.time, true);
             on_ref = true;
             continue;
         }
@@ -479,7 +479,7 @@ int emu_hit(const vk_scene_desc *desc, const float o[3], const float d[3], float
         using Mem = decltype(mem_tag);
         Mem M; static_cast<GlobalMem &>(M) = GlobalMem{S.items, S.spheres, S.sphere_mat, S.boxes};
         Lane L; memset(&L, 0, sizeof(L));
-        begin_segment<Mem::ISHIFT, fused_box<0u, Mem>()>(L, S, v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), 0.0f);
+        begin_segment<Mem::ISHIFT, fused_box<0u, Mem>(), true>(L, S, v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), 0.0f);
         while (traversing(L)) {
             const uint32_t before = L.pend; const float Tb = L.T;
             traverse_step<0u, Mem>(L, S, M);
@@ -489,12 +489,12 @@ int emu_hit(const vk_scene_desc *desc, const float o[3], const float d[3], float
         if (segment_unsafe<0u, Mem>(L, S, M)) {
             redo = 1.0f;
             if (S.walk_start != 0u) {
-                begin_segment<Mem::ISHIFT, fused_box<0u, Mem>()>(L, S, L.o, L.d, L.time, true);
+                begin_segment<Mem::ISHIFT, fused_box<0u, Mem>(), true>(L, S, L.o, L.d, L.time, true);
                 while (traversing(L)) traverse_step<0u, Mem>(L, S, M);
             } else {
                 DScene Sr = reference_view(S);
                 Mem Mr; static_cast<GlobalMem &>(Mr) = GlobalMem{Sr.items, Sr.spheres, Sr.sphere_mat, Sr.boxes};
-                begin_segment<Mem::ISHIFT, fused_box<0u, Mem>()>(L, Sr, v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), 0.0f);
+                begin_segment<Mem::ISHIFT, fused_box<0u, Mem>(), true>(L, Sr, v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), 0.0f);
                 while (traversing(L)) traverse_step<0u, Mem>(L, Sr, Mr);
             }
         }

@@ -70,6 +70,32 @@ def test_device_arithmetic_is_bit_identical_to_host(device, oracle):
     assert np.array_equal(dev(9, a, b), (a * b).astype(np.float32) + a)
 
 
+def test_quotients_by_a_shared_reciprocal_are_the_divisions(device):
+    """vk_trace.h div_by_a: the sphere test's n / |d|^2 from a reciprocal refined once and two fma corrections, in the range it is used
+    in (|d|^2 in 3e-12 .. 3e12, |n| < 2^54, quotients down to far below tmin): 2^26 pairs, every one the correctly rounded quotient."""
+    lib = device
+    lib.vk_debug_math.restype = C.c_int
+    lib.vk_debug_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(12)
+    n = 1 << 22
+    bad = 0
+    for rep in range(16):
+        den = np.exp(rng.uniform(np.log(3e-12), np.log(3e12), n)).astype(np.float32)
+        mag = np.exp(rng.uniform(np.log(1e-20), np.log(1.8e16), n))
+        num = (mag * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+        if rep % 4 == 1:                                   # quotients near 1 and near tmin, where a decision hangs on the last bit
+            num = (den.astype(np.float64) * rng.choice([1.0, 1e-3, 0.5, 7.0], n) * (1.0 + rng.uniform(-1e-6, 1e-6, n))).astype(np.float32)
+        if rep % 4 == 2:                                   # |d|^2 of unit-ish directions, numerators of ordinary scenes
+            den = rng.uniform(0.2, 4.0, n).astype(np.float32); num = rng.uniform(-60.0, 60.0, n).astype(np.float32)
+        out = np.empty_like(num)
+        assert lib.vk_debug_math(0, 10, num.ctypes.data, den.ctypes.data, out.ctypes.data, n) == 0, lib.vk_last_error()
+        want = (num / den).astype(np.float32)
+        normal = np.abs(want) >= np.float32(1.2e-38)       # (a denormal quotient is far below tmin: its last bits decide nothing)
+        bad += int((out[normal].view(np.uint32) != want[normal].view(np.uint32)).sum())
+        assert (np.abs(out[~normal]) < np.float32(1e-30)).all()
+    assert bad == 0, bad
+
+
 @pytest.mark.parametrize("name", BUILDER_SCENES)
 def test_builder_scene_per_sample(name, device, oracle, host_scenes):
     hs, cam = host_scenes(name)

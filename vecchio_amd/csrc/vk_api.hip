@@ -843,6 +843,7 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
     if (!H.tie_rank.empty()) UP(tie_rank, tie_rank);
 #undef UP
     D.tie_base_rect = H.tie_base_rect; D.tie_base_box = H.tie_base_box; D.tie_base_list = H.tie_base_list;
+    D.fast_div = H.host_view().fast_div;
     D.n_noise_spheres = H.n_noise_spheres;
     for (int k = 0; k < 4; k++) { D.noise_sphere[k] = H.noise_sphere[k]; D.noise_tex[k] = H.noise_tex[k];
         D.noise_perlin[k] = H.noise_perlin[k]; }

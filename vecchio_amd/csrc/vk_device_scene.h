@@ -124,6 +124,9 @@ struct DScene {
     // ... and the trusted origin ball: the gates of the rebuilt tree are proven sound for rays that start inside it (vk_linearize.h
     // rt_unit_growth); a segment that starts outside is decided on the tree as handed over (vk_trace.h segment_unsafe)
     float trust_c0[3], trust_r0sq;
+    // every sphere's centre coordinates and radius are below 2^30 in magnitude: the sphere tests of the sphere-only kernel variants may
+    // divide by |d|^2 through a shared reciprocal (vk_trace.h div_by_a)
+    uint32_t fast_div;
     // Scenes traversed from global memory keep BOTH trees in items[]: [the tree as handed over | a sentinel no ray passes | the
     // rebuilt tree], walk_start = index of the rebuilt tree's first item (0: items[] is one tree).  A segment whose winner is early
     // is then walked again right away, from item 0, instead of its sample being queued (vk_trace.h begin_segment).

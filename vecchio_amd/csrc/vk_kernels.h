@@ -769,7 +769,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     KArgsC P = kargs_fresh();
                     DScene S = KARG(P, S);
                     // (the callee stored the path state, new world ray included)
-                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, io.o, io.d, io.time, rearm);
+                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>(), spheres_only<F>()>(L, S, io.o, io.d, io.time, rearm);
                 }
             } else {
                 PhaseClocks clk;
@@ -782,7 +782,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                     KArgsC P = kargs_fresh();
                     DScene S = KARG(P, S);
                     // one copy of the exact reciprocals for both kinds of new ray
-                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, L.wo, L.wd, L.time, rearm);
+                    begin_segment<Mem::ISHIFT, fused_box<F, Mem>(), spheres_only<F>()>(L, S, L.wo, L.wd, L.time, rearm);
                 }
                 if (active && touched) cold_store_path<F>(cold, lane, L);
                 if (STATS) st_t_install += clock64() - st_t1;
@@ -953,6 +953,7 @@ __global__ void math_probe_kernel(int op, const float *a, const float *b, float 
         case 8: { vk::Rng g = vk::rng_for_sample(__float_as_uint(a[i]), (uint32_t)i, 0);
             r = vk::gen_range(g, -1.0f, 1.0f) + vk::gen_f32(g); break; }
         case 9: r = a[i] * b[i] + a[i]; break;   // must stay an unfused mul+add
+        case 10: r = div_by_a(a[i], b[i], refined_rcp(b[i]), true); break;      // the sphere test's quotient by a shared reciprocal
     }
     out[i] = r;
 }

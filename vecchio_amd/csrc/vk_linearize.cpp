@@ -37,6 +37,9 @@ DScene LinearScene::host_view() const {
     s.tmin_gate = s.t_pad > 0.0f ? 0.001f * s.gate_scale * 0.999999f : 0.001f;     // (T_MIN of vk_trace.h)
     for (int k = 0; k < 3; k++) s.trust_c0[k] = trust_c0[k];
     s.trust_r0sq = trust_r0 * trust_r0;
+    s.fast_div = 1u;
+    for (const DSphere &sp : spheres)
+        if (!(fabsf(sp.cx) < 1073741824.0f && fabsf(sp.cy) < 1073741824.0f && fabsf(sp.cz) < 1073741824.0f && fabsf(sp.r) < 1073741824.0f)) s.fast_div = 0u;
     return s;
 }
 

@@ -95,10 +95,12 @@ VK_HD float nextafter_up(float t) { return (t > 0.0f && t < INFINITY) ? vk::bits
 // back to the reference's own division sequence inside it; the fused form needs three more registers per lane (o/d), which
 // only the sphere-only variants have to spare, and its margin carries a term in |o/d| (cancellation when b*(1/d) ~ o/d).
 template <uint32_t F, class Mem> constexpr bool fused_box() { return (F & ~(uint32_t)VKF_INTEG_PDF) == 0u && Mem::FUSED_BOX; }
+template <uint32_t F> constexpr bool spheres_only() { return (F & ~(uint32_t)VKF_INTEG_PDF) == 0u; }
 
 // gate_scale: 1, or DScene::gate_scale = 1 / (1 + t_pad) under exact re-treeing (see exact re-treeing below): the box test then runs
 // on distances scaled by it, i.e. it compares the boxes with the closest hit so far times (1 + t_pad)
-template <bool FUSED = false>
+// TIGHT (sphere-only variants): the narrower range of ray components in which the sphere test divides through a shared reciprocal
+template <bool FUSED = false, bool TIGHT = FUSED>
 VK_HD void set_space(Lane &L, V3 o, V3 d, float gate_scale = 1.0f) {
     L.o = o; L.d = d;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(VK_EXACT_INV)
@@ -123,11 +125,16 @@ VK_HD void set_space(Lane &L, V3 o, V3 d, float gate_scale = 1.0f) {
         // bounds hold without overflow go through the exact test every time (xnan = NaN).
         L.oi = v3(o.x * L.inv.x, o.y * L.inv.y, o.z * L.inv.z);
         float c = fmaxf(fmaxf(fabsf(L.oi.x), fabsf(L.oi.y)), fabsf(L.oi.z));
-        bool ok = ax > 1e-18f && ax < 1e18f && ay > 1e-18f && ay < 1e18f && az > 1e-18f && az < 1e18f && c < 1e18f;
+        // (1e-6 .. 1e6 and an origin below 1e9: also the range in which the sphere test may divide by |d|^2 with a shared reciprocal,
+        // div_by_a below; a scattered direction has a component below 1e-6 three times in a million)
+        bool ok = ax > 1e-6f && ax < 1e6f && ay > 1e-6f && ay < 1e6f && az > 1e-6f && az < 1e6f && c < 1e12f &&
+                  fabsf(o.x) + fabsf(o.y) + fabsf(o.z) < 1e9f;
         L.xnan = ok ? c * 4.76837158203125e-7f : vk::bits_f32(0x7FC00000u);      // 2^-21
     } else {
         // reciprocal-multiply slab test is only trusted when 1/d is a full-precision normal number
         bool ok = ax > 1e-30f && ax < 1e30f && ay > 1e-30f && ay < 1e30f && az > 1e-30f && az < 1e30f;
+        if (TIGHT) ok = ax > 1e-6f && ax < 1e6f && ay > 1e-6f && ay < 1e6f && az > 1e-6f && az < 1e6f &&
+                        fabsf(o.x) + fabsf(o.y) + fabsf(o.z) < 1e9f;      // (see the fused form)
         L.xnan = ok ? 0.0f : vk::bits_f32(0x7FC00000u);
     }
 }
@@ -188,6 +195,58 @@ VK_HD bool sphere_t(float cx, float cy, float cz, float r, V3 o, V3 d, float a, 
         if (tmin < t1 && t1 < tmax) { t = t1; return true; }
         float t2 = (-half_b + root) / a;
         if (tmin < t2 && t2 < tmax) { t = t2; return true; }
+    }
+    return false;
+}
+// ---- division by a = |d|^2 with a shared reciprocal (sphere-only variants, vk_trace.h prim_step).  A leaf's two sphere tests divide by
+// the same a up to four times; the compiler expands every f32 division into v_div_scale x2, v_rcp, five fma, v_div_fmas, v_div_fixup
+// (11 instructions).  Without the scaling and the fix-up — which only act on operands near the ends of the exponent range — that
+// expansion is: y = rcp(a) refined once; q = n y; r = fma(-a, q, n); q = fma(r, y, q); r = fma(-a, q, n); q = fma(r, y, q): the
+// correctly rounded quotient.  So the refined reciprocal is computed once per step and a quotient costs five instructions, for rays
+// inside the range set_space trusts (|d| components in 1e-6 .. 1e6, origin below 1e9: xnan is not NaN) in scenes whose spheres lie
+// below 2^30 (DScene::fast_div): then a is in 3e-12 .. 3e12, |n| < 2^54, and no intermediate leaves the normal range except towards
+// zero, where the quotient is below tmin either way.  Any other lane divides.  The host build (tests/emu) always divides: the per-sample
+// GPU parity tests and test_gpu_parity's 2^26-pair probe compare the two bit for bit.
+VK_HD float refined_rcp(float a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float y = __builtin_amdgcn_rcpf(a);
+    const float e = __builtin_fmaf(-a, y, 1.0f);
+    return __builtin_fmaf(e, y, y);
+#else
+    return 1.0f / a;
+#endif
+}
+VK_HD float div_by_a(float n, float a, float y, bool fast) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float q = n * y;
+    float r = __builtin_fmaf(-a, q, n);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-a, q, n);
+    q = __builtin_fmaf(r, y, q);
+    if (__builtin_amdgcn_ballot_w64(!fast) != 0ull) {      // (wave-uniform: no lane in a million takes it)
+        asm volatile("");
+        if (!fast) q = n / a;
+    }
+    return q;
+#else
+    (void)y; (void)fast;
+    return n / a;
+#endif
+}
+// sphere_t_tie with the quotients from div_by_a
+VK_HD bool sphere_t_tie_y(float cx, float cy, float cz, float r, V3 o, V3 d, float a, float y, bool fast, float tmin, float tmax,
+    float &t, bool &tie) {
+    V3 oc = o - v3(cx, cy, cz);
+    float half_b = dot(oc, d);
+    float c = length2(oc) - r * r;
+    float disc = half_b * half_b - a * c;
+    tie = false;
+    if (disc > 0.0f) {
+        float root = sqrtf(disc);
+        float t1 = div_by_a(-half_b - root, a, y, fast);
+        if (tmin < t1 && t1 <= tmax) { t = t1; tie = t1 == tmax; return true; }
+        float t2 = div_by_a(-half_b + root, a, y, fast);
+        if (tmin < t2 && t2 <= tmax) { t = t2; tie = t2 == tmax; return true; }
     }
     return false;
 }
@@ -327,10 +386,10 @@ VK_HD bool slab_exact(const DItem &n, V3 o, V3 d, float tmin, float tmax) {
 // ------------------------------------------------------------------ traversal
 // redo (exact re-treeing of a scene traversed from global memory, DScene::walk_start != 0): this lane walks the tree as handed over,
 // items[0, walk_start - 1), on unscaled distances
-template <uint32_t ISHIFT = 0, bool FUSED = false>
+template <uint32_t ISHIFT = 0, bool FUSED = false, bool TIGHT = FUSED>
 VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time, bool redo = false) {
     L.wo = o; L.wd = d; L.time = time;
-    set_space<FUSED>(L, o, d, redo ? 1.0f : S.gate_scale);
+    set_space<FUSED, TIGHT>(L, o, d, redo ? 1.0f : S.gate_scale);
     L.i = redo ? 0u : (S.walk_start << ISHIFT); L.end = S.n_world_items << ISHIFT; L.pend = 0; L.pend2 = 0; L.cur_inst = -1;
     L.T = INFINITY; L.best_prim = 0; L.best_inst = -1; L.best_aux = 0.0f;
     // A ray with a NaN (or infinite) direction or origin hits EVERY box — f32::min/max drop the NaN quotients, accel.rs:21-31 —
@@ -669,11 +728,13 @@ VK_HD void prim_step(Lane &L, const DScene &S, const Mem &M) {
         DSphere sa = M.sphere(VKD_INDEX(ref));
         DSphere sb = M.sphere(VKD_INDEX(ref2 ? ref2 : ref));
         float t; bool tie;
-        if (sphere_t_tie(sa.cx, sa.cy, sa.cz, sa.r, L.o, L.d, L.a, T_MIN, L.T, t, tie)) {
+        const float ya = refined_rcp(L.a);
+        const bool fast = S.fast_div != 0u && (L.xnan == L.xnan);
+        if (sphere_t_tie_y(sa.cx, sa.cy, sa.cz, sa.r, L.o, L.d, L.a, ya, fast, T_MIN, L.T, t, tie)) {
             if (!tie || tie_replaces(L, S, ref)) accept<F, Mem>(L, t, ref, 0.0f);
         }
         if (ref2) {
-            if (sphere_t_tie(sb.cx, sb.cy, sb.cz, sb.r, L.o, L.d, L.a, T_MIN, L.T, t, tie)) {
+            if (sphere_t_tie_y(sb.cx, sb.cy, sb.cz, sb.r, L.o, L.d, L.a, ya, fast, T_MIN, L.T, t, tie)) {
                 if (!tie || tie_replaces(L, S, ref2)) accept<F, Mem>(L, t, ref2, 0.0f);
             }
         }
@@ -1056,7 +1117,7 @@ template <uint32_t F = VKF_ALL_SCENE, class Mem = GlobalMem>
 VK_HD void start_sample(Lane &L, const DScene &S, const RenderConsts &C, uint32_t x, uint32_t y, uint32_t sample) {
     V3 o, d; float time;
     start_sample_core(L, C, x, y, sample, o, d, time);
-    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, o, d, time);
+    begin_segment<Mem::ISHIFT, fused_box<F, Mem>(), spheres_only<F>()>(L, S, o, d, time);
 }
 
 VK_HD V3 background_of(const RenderConsts &C, V3 ud) {       // ud = unit(ray direction), only read for the sky
@@ -1210,7 +1271,7 @@ template <uint32_t F, class Mem>
 VK_HD bool shade(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C) {
     V3 o, d; float time;
     if (!shade_core<F, Mem>(L, S, M, C, o, d, time)) return false;
-    begin_segment<Mem::ISHIFT, fused_box<F, Mem>()>(L, S, o, d, time);
+    begin_segment<Mem::ISHIFT, fused_box<F, Mem>(), spheres_only<F>()>(L, S, o, d, time);
     return true;
 }
 
