@@ -420,7 +420,7 @@ int emu_gate_soundness(uint64_t n, uint64_t seed, int grow, float pad, double ba
             const double theta = g.log_uni(1e-7, 0.3), zs = (g.uni() - 0.5) * g.log_uni(1e-6, 0.1);
             double dir[3] = {1.0, -theta, zs};
             const double dn = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
-            const double dl = g.log_uni(1e-2, 1e2);
+            const double dl = g.log_uni(1e-2, 1e3);
             o = v3((float)(P[0] - dir[0] / dn * rho), (float)(P[1] - dir[1] / dn * rho), (float)(P[2] - dir[2] / dn * rho));
             d = v3((float)(dir[0] / dn * dl), (float)(dir[1] / dn * dl), (float)(dir[2] / dn * dl));
         } else {
@@ -453,8 +453,10 @@ int emu_gate_soundness(uint64_t n, uint64_t seed, int grow, float pad, double ba
         { const float q0 = (U.mny - o.y) / d.y, q1 = (U.mxy - o.y) / d.y; lo = fmaxf(fminf(q0, q1), lo); }
         { const float q0 = (U.mnz - o.z) / d.z, q1 = (U.mxz - o.z) / d.z; lo = fmaxf(fminf(q0, q1), lo); }
         double early = (double)lo / (double)t - 1.0;
-        // (preferred for rendering: ordinary magnitudes — a direction of length 1..10, a hit a few units away, early by a factor of 3+)
-        if (length2(d) > 1.0f && length2(d) < 100.0f && t > 1.0f && t < 6.0f && early > 3.0 && early < 50.0) early += 1.0e6;
+        // (preferred for rendering: ordinary magnitudes — every direction component above 2e-6, so that the kernel's fast box test is
+        // trusted for the ray (vk_trace.h set_space), a direction of length 10..300, early by a factor of 3+)
+        if (fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)) > 2.0e-6f && length2(d) > 100.0f && length2(d) < 1.0e5f && early > 3.0 &&
+            early < 50.0) early += 1.0e6;
         if (early > worst && viol) {
             worst = early;
             const float v[19] = {c[0][0], c[0][1], c[0][2], R, c[1][0], c[1][1], c[1][2], R, o.x, o.y, o.z, d.x, d.y, d.z, t, lo,
