@@ -244,6 +244,8 @@ def main():
     ap.add_argument("--fast-accel", action="store_true",
                     help="set VK_SCENE_FAST_ACCEL in the scene description: the library rebuilds draw-free subtrees with its SAH builder "
                          "(opt-in; not the headline: see include/vecchio_amd.h)")
+    ap.add_argument("--rgb8", action="store_true", help="N ranks: gather RGB8 slabs (Vec3::to_color fused into the pack, vec3.rs:54-61) "
+                    "instead of f32 ones")
     ap.add_argument("--in-library", action="store_true",
                     help="N GPUs from ONE process through vk_scene_create_multi (the library deals tiles, gathers on device 0) "
                          "instead of one process per GPU; run without torchrun")
@@ -258,7 +260,7 @@ def main():
     import torch
     import torch.distributed as dist
     from vecchio_amd import DeviceScene, HostScene
-    from vecchio_amd.distributed import FramebufferGather
+    from vecchio_amd.distributed import DeviceFramebufferGather
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -326,8 +328,10 @@ def main():
         ds = DeviceScene(hs.desc, devices=in_lib_devices) if args.in_library else DeviceScene(hs.desc, device=dev_index)
         info = ds.info()
         fb = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
-        full = torch.zeros_like(fb) if (world > 1 and rank == 0) else None
-        gather = FramebufferGather(width, height, rank, world, dev, stage_on_cpu=rehearsal)
+        # the gathered frame on rank 0: f32 (y up), or with --rgb8 the reference's output stage fused into the exchange (bytes through
+        # Vec3::to_color, top row first: a quarter of the traffic over xGMI)
+        full = torch.zeros((height, width, 3), dtype=torch.uint8 if args.rgb8 else torch.float32, device=dev) if (world > 1 and rank == 0) else None
+        gather = DeviceFramebufferGather(ds, width, height, rank, world, dev, stage_on_cpu=rehearsal, rgb8=args.rgb8) if world > 1 else None
         stream = torch.cuda.current_stream().cuda_stream
         kernel_ms = []
 
@@ -363,7 +367,8 @@ def main():
             value = total_samples * steps / elapsed / 1e6
             final = (full if world > 1 else fb).cpu().numpy()    # the image the last timed step produced
             verified = None
-            if not args.no_verify:
+            rgb8_gathered = world > 1 and args.rgb8
+            if not args.no_verify and not rgb8_gathered:
                 verified = verify_against_oracle(O, hs, cam, final, width, spp, depth)
             # ---- bounded oracle sample: visit counters (algorithmic bytes) + CPU baseline
             cw = width if name != "C5" else 1024     # C5's 16.7M pixels: sample a quarter-res grid on the CPU
@@ -499,7 +504,17 @@ def main():
             if rank == 0:
                 ds1 = DeviceScene(hs.desc, device=dev_index)
                 ref, _ = ds1.render(cam, hs.params(width, spp, depth, seed=2))
-                same = bool((full.cpu().numpy() == ref).all())
+                if args.rgb8:
+                    # the gathered frame is bytes (to_color fused into the exchange): against ONE device's own RGB8 output of the whole
+                    # frame; the oracle check then runs on that device's f32 frame
+                    from vecchio_amd import ffi
+                    ref8, _ = ds1.render(cam, hs.params(width, spp, depth, seed=2, output_format=ffi.VK_OUTPUT_RGB8))
+                    same = bool((full.cpu().numpy() == ref8).all())
+                    if not args.no_verify:
+                        res["verified"] = verify_against_oracle(O, hs, cam, ref, width, spp, depth)
+                        res["verified"]["note"] = "the one-GPU f32 frame, whose RGB8 output the gathered frame equals byte for byte"
+                else:
+                    same = bool((full.cpu().numpy() == ref).all())
                 ds1.close()
                 res["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": names,
                                       "distinct_devices": len({(n["device_index"]) for n in names}),

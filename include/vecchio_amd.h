@@ -310,6 +310,22 @@ int vk_render_device(vk_scene *scene, const vk_camera *cam, const vk_render_para
 int vk_to_color_device(vk_scene *scene, const void *d_rgb, uint32_t width, uint32_t height,
                        void *d_rgb8_out, void *hip_stream);
 
+/* ---- tile slabs: the exchange format of the multi-GPU host.  Rank r of w renders the 8x8 tiles t = r, r + w, r + 2w ...
+ * (vk_render_params.tile_rank / tile_world); its SLAB is those tiles packed one after the other, 64 pixel slots per tile (slot
+ * (y % 8) * 8 + x % 8; slots outside the image are present and unused), 3 components per slot: floats (VK_OUTPUT_F32) or bytes through
+ * Vec3::to_color (VK_OUTPUT_RGB8, vec3.rs:54-61: a quarter of the traffic).  A one-process-per-GPU host calls vk_render_device
+ * (VK_OUTPUT_F32) and vk_pack_tiles_device on every rank, gathers the equal-sized slabs on rank 0 (RCCL: ONE message per GPU, the
+ * path's only exchange) and calls vk_unpack_tiles_device once per rank there.  replaces: nothing (single address space, main.rs:181). */
+/* bytes of one rank's slab; the largest over the ranks (they differ by at most one tile) when tile_rank >= tile_world */
+size_t vk_tile_slab_bytes(uint32_t width, uint32_t height, uint32_t output_format, uint32_t tile_rank, uint32_t tile_world);
+/* d_fb: this rank's f32 framebuffer (width*height*3 floats, y up) on the scene's device -> d_slab */
+int vk_pack_tiles_device(vk_scene *scene, const void *d_fb, uint32_t width, uint32_t height, uint32_t output_format,
+                         uint32_t tile_rank, uint32_t tile_world, void *d_slab, void *hip_stream);
+/* d_slab of rank tile_rank -> its tiles of the full image d_img on the scene's device: f32, y up (VK_OUTPUT_F32), or bytes, top row
+ * first (VK_OUTPUT_RGB8, main.rs:209) */
+int vk_unpack_tiles_device(vk_scene *scene, const void *d_slab, uint32_t width, uint32_t height, uint32_t output_format,
+                           uint32_t tile_rank, uint32_t tile_world, void *d_img, void *hip_stream);
+
 /* introspection used by bench/tests: bytes of the linearised scene, item counts */
 typedef struct vk_scene_info {
     uint32_t n_items;          /* 32-byte linear BVH records */

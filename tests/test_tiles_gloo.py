@@ -58,6 +58,50 @@ def _worker(rank, world, port, w, h, outdir, use_hip):
     dist.destroy_process_group()
 
 
+def _device_worker(rank, world, port, w, h, outdir):
+    """the product's exchange: render on the device, pack the slab with the library's tile kernel, ONE gather, unpack on rank 0 — no
+    torch indexing anywhere (gloo cannot move GPU tensors: the slabs are staged through host memory, as in bench.py's rehearsal)"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vecchio_amd import DeviceScene, HostScene
+    from vecchio_amd.distributed import DeviceFramebufferGather
+    hs = HostScene("cornell_box", 1)
+    cam = hs.next_camera()
+    p = hs.params(w, 4, 20, height=h, tile_rank=rank, tile_world=world)
+    ds = DeviceScene(hs.desc, device=0)
+    dev = torch.device("cuda", 0)
+    fb = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+    for rgb8 in (False, True):
+        g = DeviceFramebufferGather(ds, w, h, rank, world, dev, stage_on_cpu=True, rgb8=rgb8)
+        ds.render_device(cam, p, fb.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        full = g.gather(fb)
+        dist.barrier()
+        if rank == 0:
+            np.save(os.path.join(outdir, "dev_gathered8.npy" if rgb8 else "dev_gathered.npy"), full.cpu().numpy())
+    ds.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_device_gather_packs_and_unpacks_on_the_device(device, host_scenes, tmp_path):
+    import golden_checks as G
+    from vecchio_amd import DeviceScene
+    w, h = 52, 44
+    mp.spawn(_device_worker, args=(2, free_port(), w, h, str(tmp_path)), nprocs=2, join=True)
+    hs, cam = host_scenes("cornell_box")
+    ds = DeviceScene(hs.desc)
+    single, _ = ds.render(cam, hs.params(w, 4, 20, height=h))
+    ds.close()
+    assert np.array_equal(np.load(tmp_path / "dev_gathered.npy"), single)
+    assert np.array_equal(np.load(tmp_path / "dev_gathered8.npy"), G.to_color(single)[::-1])
+    import inspect
+    from vecchio_amd import distributed
+    src = inspect.getsource(distributed.DeviceFramebufferGather)
+    assert "index_select" not in src and "index_copy" not in src
+
+
 @pytest.mark.gpu
 def test_two_rank_gather_of_the_hip_path_is_bit_exact(device, host_scenes, tmp_path):
     """two processes, each calling vk_render for its tile partition on the MI355X, gathered over gloo"""
@@ -108,6 +152,12 @@ def test_bench_gpus_n_without_a_launcher_starts_n_ranks(device):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
+    # ... and with the output stage fused into the exchange (RGB8 slabs)
+    r8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--spp", "16",
+                         "--no-cpu", "--no-also", "--no-traffic", "--rgb8"], env=env, capture_output=True, text=True, timeout=600)
+    assert r8.returncode == 0, r8.stdout[-2000:] + r8.stderr[-4000:]
+    d8 = json.loads([l for l in r8.stdout.splitlines() if l.startswith("{")][-1])
+    assert d8["distributed"]["gathered_image_equals_one_gpu_render"] is True and d8["verified"]["ok"] is True
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     dd = d["distributed"]
     assert dd["world_size"] == 2 and dd["self_launched"] and len(dd["ranks"]) == 2 and {x["rank"] for x in dd["ranks"]} == {0, 1}

@@ -950,6 +950,9 @@ int vk_scene_create_multi(const vk_scene_desc *desc, const int *devices, int n_d
             if (devices[j] != devices[0]) {          // let devices[0] and this device address each other's memory (xGMI peer copies)
                 int can = 0;
                 HIP_TRY(hipDeviceCanAccessPeer(&can, devices[j], devices[0]));
+                if (!can)
+                    fprintf(stderr, "vecchio_amd: device %d cannot address device %d's memory (no peer access): its tile slab travels "
+                        "through host memory\n", devices[j], devices[0]);
                 if (can) {
                     HIP_TRY(hipSetDevice(devices[j]));
                     hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
@@ -1171,6 +1174,48 @@ int vk_debug_render_samples(vk_scene *scene, const vk_camera *cam, const vk_rend
     if (!samples_out) return fail(VK_ERR_BAD_ARG, "null samples buffer");
     if (params && params->output_format != VK_OUTPUT_F32) return fail(VK_ERR_BAD_ARG, "per-sample debug output needs VK_OUTPUT_F32");
     return guarded([&]() -> int { return render_host(scene, cam, params, rgb_out, nullptr, samples_out); });
+}
+
+size_t vk_tile_slab_bytes(uint32_t width, uint32_t height, uint32_t output_format, uint32_t tile_rank, uint32_t tile_world) {
+    if (width == 0 || height == 0 || output_format > VK_OUTPUT_RGB8) return 0;
+    vk_render_params p; memset(&p, 0, sizeof(p));
+    p.width = width; p.height = height; p.tile_world = tile_world ? tile_world : 1u;
+    p.tile_rank = tile_rank < p.tile_world ? tile_rank : 0u;       // (rank 0 holds the most tiles)
+    return (size_t)TileGeom(&p).n_local * 64u * (output_format == VK_OUTPUT_RGB8 ? 3u : 12u);
+}
+
+static int tile_call_args(vk_scene *scene, const void *a, const void *b, uint32_t width, uint32_t height, uint32_t output_format,
+    uint32_t tile_rank, uint32_t tile_world, vk_render_params &p) {
+    if (!scene || !a || !b) return fail(VK_ERR_BAD_ARG, "null argument");
+    if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 31) / 3 || width > 65535u || height > 65535u) return fail(VK_ERR_BAD_ARG,
+        "image too large");
+    if (output_format > VK_OUTPUT_RGB8) return fail(VK_ERR_BAD_ARG, "bad output_format");
+    memset(&p, 0, sizeof(p));
+    p.width = width; p.height = height; p.tile_world = tile_world ? tile_world : 1u; p.tile_rank = tile_rank;
+    if (p.tile_rank >= p.tile_world) return fail(VK_ERR_BAD_ARG, "tile_rank >= tile_world");
+    return VK_OK;
+}
+
+int vk_pack_tiles_device(vk_scene *scene, const void *d_fb, uint32_t width, uint32_t height, uint32_t output_format, uint32_t tile_rank,
+    uint32_t tile_world, void *d_slab, void *hip_stream) {
+    vk_render_params p;
+    int rc = tile_call_args(scene, d_fb, d_slab, width, height, output_format, tile_rank, tile_world, p);
+    if (rc != VK_OK) return rc;
+    HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    return output_format == VK_OUTPUT_RGB8 ? tile_move<TM_PACK_U8>(d_fb, d_slab, &p, TileGeom(&p), st)
+                                           : tile_move<TM_PACK_F32>(d_fb, d_slab, &p, TileGeom(&p), st);
+}
+
+int vk_unpack_tiles_device(vk_scene *scene, const void *d_slab, uint32_t width, uint32_t height, uint32_t output_format, uint32_t tile_rank,
+    uint32_t tile_world, void *d_img, void *hip_stream) {
+    vk_render_params p;
+    int rc = tile_call_args(scene, d_slab, d_img, width, height, output_format, tile_rank, tile_world, p);
+    if (rc != VK_OK) return rc;
+    HIP_TRY(hipSetDevice(scene->device));
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    return output_format == VK_OUTPUT_RGB8 ? tile_move<TM_UNPACK_U8>(d_slab, d_img, &p, TileGeom(&p), st)
+                                           : tile_move<TM_UNPACK_F32>(d_slab, d_img, &p, TileGeom(&p), st);
 }
 
 int vk_to_color_device(vk_scene *scene, const void *d_rgb, uint32_t width, uint32_t height, void *d_rgb8_out, void *hip_stream) {

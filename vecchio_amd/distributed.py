@@ -2,6 +2,12 @@
 exchange step of the path — the final framebuffer gather to rank 0 (RCCL over xGMI when the
 tensors live on MI355X, gloo on CPU in tests).  No all-reduce: every pixel is produced by
 exactly one rank, so the collective is a gather of equal-sized tile slabs.
+
+DeviceFramebufferGather is the product path: slabs are packed and unpacked by the library's own
+tile kernels (vk_pack_tiles_device / vk_unpack_tiles_device), so a step is render -> pack ->
+dist.gather -> unpack with no torch indexing op in it.  FramebufferGather is the index-based
+twin for tensors that never were on a GPU (the CPU tests, where the oracle stands in for the
+renderer).
 """
 import numpy as np
 
@@ -67,3 +73,49 @@ class FramebufferGather:
             m = self.all_idx[r].numel()
             ff.index_copy_(0, self.all_idx[r], self.recv[r][:m].to(ff.device))
         return full
+
+
+class DeviceFramebufferGather:
+    """One step's exchange for a one-process-per-GPU host.  `scene` is this rank's DeviceScene; `fb` the f32 framebuffer its
+    vk_render_device call wrote (this rank's tiles).  gather(fb, out) packs the rank's slab on the device (floats, or bytes through
+    Vec3::to_color when rgb8), moves the slabs to rank 0 with ONE torch.distributed.gather (RCCL when the tensors are on the GPU;
+    stage_on_cpu: through host tensors, for gloo rehearsals) and unpacks them there into `out`: (height, width, 3) float32 with
+    y = 0 the bottom row, or uint8 with row 0 the top row (VK_OUTPUT_RGB8)."""
+
+    def __init__(self, scene, width, height, rank, world, device, stage_on_cpu=False, rgb8=False):
+        import torch
+        from . import ffi
+        self.torch, self.scene = torch, scene
+        self.width, self.height, self.rank, self.world = width, height, rank, world
+        self.fmt = ffi.VK_OUTPUT_RGB8 if rgb8 else ffi.VK_OUTPUT_F32
+        self.stage_on_cpu = stage_on_cpu
+        lib = ffi.load_device_lib()
+        self.slab_bytes = int(lib.vk_tile_slab_bytes(width, height, self.fmt, world, world))     # the largest rank's
+        self.slab = torch.zeros(self.slab_bytes, dtype=torch.uint8, device=device)
+        xdev = "cpu" if stage_on_cpu else device
+        self.xslab = torch.zeros(self.slab_bytes, dtype=torch.uint8, device=xdev) if stage_on_cpu else self.slab
+        self.recv = [torch.zeros(self.slab_bytes, dtype=torch.uint8, device=xdev) for _ in range(world)] if rank == 0 and world > 1 else None
+        self.landing = torch.zeros(self.slab_bytes, dtype=torch.uint8, device=device) if stage_on_cpu and rank == 0 else None
+
+    def gather(self, fb, out=None):
+        import torch.distributed as dist
+        torch = self.torch
+        stream = torch.cuda.current_stream().cuda_stream
+        self.scene.pack_tiles_device(fb.data_ptr(), self.width, self.height, self.fmt, self.rank, self.world, self.slab.data_ptr(), stream)
+        if self.stage_on_cpu:
+            self.xslab.copy_(self.slab)
+        if self.world > 1:
+            dist.gather(self.xslab, self.recv if self.rank == 0 else None, dst=0)
+        if self.rank != 0:
+            return None
+        if out is None:
+            out = torch.zeros((self.height, self.width, 3), dtype=torch.uint8 if self.fmt else torch.float32, device=fb.device)
+        for r in range(self.world):
+            src = self.recv[r] if self.world > 1 else self.xslab
+            if self.stage_on_cpu:
+                self.landing.copy_(src)
+                src = self.landing
+            self.scene.unpack_tiles_device(src.data_ptr(), self.width, self.height, self.fmt, r, self.world, out.data_ptr(), stream)
+            if self.stage_on_cpu:
+                torch.cuda.current_stream().synchronize()      # (the one landing buffer is reused for the next rank's slab)
+        return out

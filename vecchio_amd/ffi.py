@@ -191,6 +191,7 @@ DEVICE_SYMBOLS = [
     "vk_abi_version", "vk_device_count", "vk_last_error", "vk_scene_create", "vk_scene_destroy",
     "vk_render", "vk_render_device", "vk_to_color_device", "vk_scene_get_info", "vk_scene_create_multi",
     "vk_scene_last_kernel_ms", "vk_scene_last_clamped_samples", "vk_scene_last_requeued_samples",
+    "vk_tile_slab_bytes", "vk_pack_tiles_device", "vk_unpack_tiles_device",
 ]
 
 
@@ -233,6 +234,11 @@ def load_device_lib():
     lib.vk_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     lib.vk_to_color_device.restype = C.c_int
     lib.vk_to_color_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.vk_tile_slab_bytes.restype = C.c_size_t
+    lib.vk_tile_slab_bytes.argtypes = [C.c_uint32] * 5
+    for fn in (lib.vk_pack_tiles_device, lib.vk_unpack_tiles_device):
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.vk_scene_get_info.restype = C.c_int
     lib.vk_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
     _dev = lib

@@ -91,6 +91,9 @@ extern "C" {
     pub fn vk_scene_last_kernel_ms(scene: *mut vk_scene, ms_out: *mut f64) -> c_int;
     pub fn vk_scene_last_clamped_samples(scene: *mut vk_scene, count_out: *mut u64) -> c_int;
     pub fn vk_scene_last_requeued_samples(scene: *mut vk_scene, count_out: *mut u64) -> c_int;
+    pub fn vk_tile_slab_bytes(width: u32, height: u32, output_format: u32, tile_rank: u32, tile_world: u32) -> usize;
+    pub fn vk_pack_tiles_device(scene: *mut vk_scene, d_fb: *const c_void, width: u32, height: u32, output_format: u32, tile_rank: u32, tile_world: u32, d_slab: *mut c_void, stream: *mut c_void) -> c_int;
+    pub fn vk_unpack_tiles_device(scene: *mut vk_scene, d_slab: *const c_void, width: u32, height: u32, output_format: u32, tile_rank: u32, tile_world: u32, d_img: *mut c_void, stream: *mut c_void) -> c_int;
 }
 
 /// What `flatten()` pushes into (flatten.rs).  One record per Arc; shared Arcs are de-duplicated

@@ -117,6 +117,16 @@ class DeviceScene:
         check(self._lib, self._lib.vk_scene_last_requeued_samples(self._h, C.byref(n)))
         return n.value
 
+    def pack_tiles_device(self, d_fb, width, height, output_format, tile_rank, tile_world, d_slab, stream=None):
+        """this rank's tiles of the f32 framebuffer at d_fb -> its slab at d_slab (floats, or bytes through to_color for RGB8)"""
+        check(self._lib, self._lib.vk_pack_tiles_device(self._h, C.c_void_p(d_fb), width, height, output_format, tile_rank, tile_world,
+                                                        C.c_void_p(d_slab), C.c_void_p(stream or 0)))
+
+    def unpack_tiles_device(self, d_slab, width, height, output_format, tile_rank, tile_world, d_img, stream=None):
+        """rank tile_rank's slab at d_slab -> its tiles of the full image at d_img (f32 y up, or RGB8 top row first)"""
+        check(self._lib, self._lib.vk_unpack_tiles_device(self._h, C.c_void_p(d_slab), width, height, output_format, tile_rank, tile_world,
+                                                          C.c_void_p(d_img), C.c_void_p(stream or 0)))
+
     def to_color_device(self, d_rgb, width, height, d_rgb8, stream=None):
         check(self._lib, self._lib.vk_to_color_device(self._h, C.c_void_p(d_rgb), width, height, C.c_void_p(d_rgb8), C.c_void_p(stream or 0)))
 
