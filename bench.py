@@ -132,7 +132,7 @@ def measure_counters_live(workload, timeout_s=75):
         return None, "this run is itself being profiled"
     got = {}
     for group in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"),
-                  ("SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS")):
+                  ("SQ_INSTS_VMEM_WR", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS"), ("TCC_WRITE_sum", "TCC_ATOMIC_sum")):
         tmp = tempfile.mkdtemp(prefix="vk_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", *group, "--kernel-trace", "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.join(ROOT, "bench.py"),
                "--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu", "--no-verify", "--no-also", "--no-traffic"]
@@ -449,16 +449,17 @@ def main():
                                     f"{live['written_bytes']:.0f} B written); committed profile ({prof_path}): {traffic}")
                     t_read, t_write = live["read_bytes_upper_bound"], live["written_bytes"]
                     traffic = t_read + t_write
-                    # Share of the HBM writes that can be register spills — an UPPER bound from two sides: (a) the bytes the spill stores
-                    # issue (scratch stores are the kernel's only vector-memory writes apart from ~4 wave-level atomics per work unit; a
-                    # wave-wide dword store is 256 B; they only reach HBM when the scratch working set outgrows the L2), (b) what is
-                    # left of WRITE_SIZE after the flushes of the tile sums (192 atomics per unit, a 32-B sector each at the memory side)
-                    n_units_est = ((width + 7) // 8) * ((height + 7) // 8) * max(1, -(-spp // 64)) / max(1, world)
-                    spill_instr = max(0.0, live["SQ_INSTS_VMEM_WR"] - 4.0 * n_units_est)
-                    spill_bytes = spill_instr * 256.0
-                    scratch_share = round(max(0.0, min(1.0, spill_bytes / max(1.0, t_write), 1.0 - n_units_est * 192.0 * 32.0 / max(1.0, t_write))), 4)
-                    scratch_detail = {"spill_store_wave_instr": round(spill_instr), "spill_bytes_issued": round(spill_bytes),
-                                      "tile_sum_flush_bytes_estimate": round(n_units_est * 192.0 * 32.0)}
+                    # What the HBM writes are made of, from the L2's request counters: the kernel's vector-memory writes are the 64-bit
+                    # atomic adds of the fixed-point pixel sums (a unit's flush of its tile sums, and the samples that finish after their
+                    # wave has moved on to the next unit) and plain stores (register spills, the redo queue entries of exact re-treeing).
+                    # Every atomic ends as a write request to memory (profiles/r04/c2_pmc_summary.json: TCC_EA0_WRREQ = TCC_ATOMIC +
+                    # TCC_WRITE to 0.1 %), so the plain stores' share of the requests bounds the spills' share of the written bytes.
+                    plain, atomics = live["TCC_WRITE_sum"], live["TCC_ATOMIC_sum"]
+                    scratch_share = round(plain / max(1.0, plain + atomics), 4)
+                    scratch_detail = {"l2_plain_store_requests": round(plain), "l2_atomic_requests": round(atomics),
+                                      "written_bytes_per_request": round(t_write / max(1.0, plain + atomics), 1),
+                                      "note": "plain stores = register spills + redo queue entries (8 B per requeued sample); atomics = tile-sum "
+                                              "flushes + stragglers' direct adds"}
                     if k_ms:
                         vi = live["SQ_INSTS_VALU"] / local_samples
                         rate = live["SQ_INSTS_VALU"] / (k_ms * 1e-3)

@@ -78,6 +78,7 @@ constexpr double RT_KAPPA = 1.0 / 524288.0;       // 2^-19 = 32 * 2^-24
 constexpr double RT_PAD = 1.0 / 4.0;              // LinearScene::t_pad of exact re-treeing with grown gates (the proven form)
 constexpr double RT_PAD_EMPIRICAL = 1.0 / 16.0;   // ... with the units' boxes as handed over (the empirical form)
 constexpr double RT_MAX_AREA_GROWTH = 0.05;       // the grown gates are used when they cost at most this much leaf surface area
+constexpr double RT_LONG_GROWTH = 0.25;           // a unit whose gate would grow by more than this (in units of its smaller radius) is "long"
 inline double rt_eta(double rho, double R) { return RT_KAPPA * (rho + R) * (rho + R) / R; }
 // growth (>= 0) of the box [umn, umx] gating the n spheres (centers, radii), or < 0 if no growth makes the gate sound for origins
 // as far away as the ball allows (the caller shrinks the ball)
