@@ -1,8 +1,12 @@
 /*
- * vecchio_amd_debug.h — test and diagnostic entry points of libvecchio_amd.so.
+ * vecchio_amd_debug.h — test and diagnostic entry points.
  *
  * Not part of the drop-in boundary (include/vecchio_amd.h): nothing here replaces a reference
  * interface, and the Rust shim does not bind it.  Used by tests/ and bench.py only.
+ * vk_debug_render_samples is in libvecchio_amd.so: it is vk_render with the PRODUCTION kernel's per-sample dump switched on.
+ * vk_debug_phase_stats and vk_debug_math need kernels of their own (the instrumented STATS builds of the megakernel, the arithmetic
+ * probe): they are in libvecchio_amd_debug.so, the same sources compiled with -DVK_DEBUG_LIB, so that the product library's code
+ * object holds production kernels only.  A vk_scene belongs to the library that created it.
  */
 #ifndef VECCHIO_AMD_DEBUG_H
 #define VECCHIO_AMD_DEBUG_H

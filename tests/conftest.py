@@ -20,6 +20,7 @@ def built():
     build.build_oracle()
     build.build_emu()
     build.build_device()
+    build.build_device_debug()
     return True
 
 

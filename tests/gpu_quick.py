@@ -76,11 +76,12 @@ def main():
         img, st = ds.render(cam, p)
         print(f"timing {w}x{p.height} spp={spp}: kernel {st.kernel_ms:.2f} ms -> {st.samples / st.kernel_ms / 1e3:.1f} Msamples/s (lds={st.scene_in_lds})", flush=True)
     # phase scheduler statistics (instrumented kernel build)
-    lib = ffi.load_device_lib()
+    lib = ffi.load_debug_lib()
     lib.vk_debug_phase_stats.restype = C.c_int
     lib.vk_debug_phase_stats.argtypes = [C.c_void_p, C.POINTER(ffi.Camera), C.POINTER(ffi.RenderParams), C.POINTER(C.c_uint64 * 16)]
     p = hs.params(1920, 64, 50)
     out = (C.c_uint64 * 16)()
+    ds.close(); ds = DeviceScene(hs.desc, lib=lib)
     if lib.vk_debug_phase_stats(ds._h, C.byref(cam), C.byref(p), C.byref(out)) == 0:
         v = list(out)
         ns = p.width * p.height * p.samples_per_pixel

@@ -2,13 +2,13 @@
 import sys, os, ctypes as C
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from vecchio_amd import HostScene, DeviceScene, ffi
-lib = ffi.load_device_lib()
+lib = ffi.load_debug_lib()
 lib.vk_debug_phase_stats.restype = C.c_int
 lib.vk_debug_phase_stats.argtypes = [C.c_void_p, C.POINTER(ffi.Camera), C.POINTER(ffi.RenderParams), C.POINTER(C.c_uint64 * 16)]
 jobs = [a.split(":") for a in sys.argv[1:]] or [("final_scene", 800, 256), ("random_spheres_iow", 1920, 128)]
 for job in jobs:
     name, w, spp = ":".join(job[:-2]), int(job[-2]), int(job[-1])
-    hs = HostScene(name, 1); cam = hs.next_camera(); ds = DeviceScene(hs.desc); p = hs.params(w, spp, 50)
+    hs = HostScene(name, 1); cam = hs.next_camera(); ds = DeviceScene(hs.desc, lib=lib); p = hs.params(w, spp, 50)
     ds.render(cam, p); img, st = ds.render(cam, p)
     out = (C.c_uint64 * 16)()
     rc = lib.vk_debug_phase_stats(ds._h, C.byref(cam), C.byref(p), C.byref(out))

@@ -106,10 +106,18 @@ def test_multi_device_render_device_and_errors(device, host_scenes):
     bad = hs.params(16, 4, 10, output_format=5)
     out = np.zeros((bad.height, 16, 3), np.float32)
     assert lib.vk_render(ds._h, C.byref(cam), C.byref(bad), out.ctypes.data, None) == ffi.VK_ERR_BAD_ARG
-    lib.vk_debug_phase_stats.restype = C.c_int
-    lib.vk_debug_phase_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    assert lib.vk_debug_phase_stats(ds._h, None, None, None) == ffi.VK_ERR_BAD_ARG          # used to dereference params first
     ds.close()
+    # (the diagnostic entry points live in libvecchio_amd_debug.so; a scene belongs to the library that made it)
+    dbg = ffi.load_debug_lib()
+    dd = DeviceScene(hs.desc, lib=dbg)
+    dbg.vk_debug_phase_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert dbg.vk_debug_phase_stats(dd._h, None, None, None) == ffi.VK_ERR_BAD_ARG          # used to dereference params first
+    dbg.vk_debug_phase_stats.argtypes = [C.c_void_p, C.POINTER(ffi.Camera), C.POINTER(ffi.RenderParams), C.POINTER(C.c_uint64 * 16)]
+    out = (C.c_uint64 * 16)()
+    ps = hs.params(96, 8, 20)
+    assert dbg.vk_debug_phase_stats(dd._h, C.byref(cam), C.byref(ps), C.byref(out)) == 0 and out[0] > 0 and out[12] > 0
+    dd.close()
+    assert not hasattr(lib, "vk_debug_phase_stats") and not hasattr(lib, "vk_debug_math")      # the product library: production kernels only
 
 
 def test_max_depth_zero_and_one(device, oracle, host_scenes):

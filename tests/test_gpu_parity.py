@@ -44,9 +44,7 @@ def compare_samples(ps_o, ps_d, img_o, img_d):
 
 
 def test_device_arithmetic_is_bit_identical_to_host(device, oracle):
-    lib = device
-    lib.vk_debug_math.restype = C.c_int
-    lib.vk_debug_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib = ffi.load_debug_lib()            # (the probe kernel lives in the debug build of the same sources, same compiler flags)
     rng = np.random.default_rng(11)
     n = 1 << 18
     a = np.concatenate([rng.uniform(-1e4, 1e4, n // 2), rng.uniform(-1, 1, n // 2)]).astype(np.float32)
@@ -73,9 +71,7 @@ def test_device_arithmetic_is_bit_identical_to_host(device, oracle):
 def test_quotients_by_a_shared_reciprocal_are_the_divisions(device):
     """vk_trace.h div_by_a: the sphere test's n / |d|^2 from a reciprocal refined once and two fma corrections, in the range it is used
     in (|d|^2 in 3e-12 .. 3e12, |n| < 2^54, quotients down to far below tmin): 2^26 pairs, every one the correctly rounded quotient."""
-    lib = device
-    lib.vk_debug_math.restype = C.c_int
-    lib.vk_debug_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib = ffi.load_debug_lib()
     rng = np.random.default_rng(12)
     n = 1 << 22
     bad = 0

@@ -38,6 +38,8 @@ def test_resource_file_lists_every_variant(built):
         minw = 6
         assert (f, True, minw, False) in v                               # LDS-resident scene
         assert (f, False, 7 if f in (0, F_PDF) else minw, False) in v    # global-memory scene (sphere-only: 7 waves/SIMD since exact re-treeing)
+    # the product library holds production kernels only: the instrumented (STATS) builds live in libvecchio_amd_debug.so
+    assert not any(k[3] for k in v), [k for k in v if k[3]]
 
 
 def test_sphere_only_variant_keeps_six_waves_per_simd(built):

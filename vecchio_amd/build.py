@@ -109,6 +109,24 @@ def build_cli(force=False):
     return out
 
 
+def build_device_debug(force=False):
+    """libvecchio_amd_debug.so: the product library's sources with -DVK_DEBUG_LIB — plus the instrumented (STATS) kernel builds behind
+    vk_debug_phase_stats and the device arithmetic probe vk_debug_math (include/vecchio_amd_debug.h).  Tests and diagnostics only:
+    the product library holds production kernels only."""
+    out = os.path.join(LIB, "libvecchio_amd_debug.so")
+    srcs, deps = _device_deps()
+    flags = HIPFLAGS + ["-DVK_DEBUG_LIB"]
+    if force or _newer(out, deps, flags):
+        os.makedirs(LIB, exist_ok=True)
+        _run_atomic([HIPCC] + flags + ["-shared", "-o"], out, srcs)
+        _stamp(out, deps, flags)
+    return out
+
+
+def debug_is_stale():
+    return _newer(os.path.join(LIB, "libvecchio_amd_debug.so"), _device_deps()[1], HIPFLAGS + ["-DVK_DEBUG_LIB"])
+
+
 def build_device(force=False):
     """hipcc cross-compiles for gfx950 without a GPU present."""
     out = os.path.join(LIB, "libvecchio_amd.so")
@@ -188,7 +206,7 @@ def build_emu(force=False):
 
 
 def build_all(force=False):
-    return [build_host(force), build_device(force), build_oracle(force), build_emu(force), build_cli(force)]
+    return [build_host(force), build_device(force), build_device_debug(force), build_oracle(force), build_emu(force), build_cli(force)]
 
 
 if __name__ == "__main__":

@@ -607,6 +607,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         for (int k = 0; k < 3; k++) { o.org[k] = cam->origin[k]; o.llc[k] = cam->lower_left_corner[k]; }
     }
     HIP_TRY(hipMemsetAsync(s->counter, 0, 32, st));       // work counter, this frame's clamped-sample count, per-launch unit counts
+#ifdef VK_DEBUG_LIB
     if (s->want_phase_stats) {
         const uint32_t FULLPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
         if (F != 0u && F != FULLPDF)
@@ -625,6 +626,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         HIP_TRY(hipGetLastError());
         F = 0xFFFFFFFFu;   // launched
     }
+#endif
     if (F != 0xFFFFFFFFu) {
         // enough units for 28 waves per CU to stay busy: the dual launch; else (tiny frames) the single 2 x 768-thread shape
         const bool dual = s->dual_launch && lds && n_units >= (uint64_t)s->num_cus * 28u * 4u && s->stream2;
@@ -1229,6 +1231,7 @@ int vk_to_color_device(vk_scene *scene, const void *d_rgb, uint32_t width, uint3
     return VK_OK;
 }
 
+#ifdef VK_DEBUG_LIB      // libvecchio_amd_debug.so only (build.py build_device_debug): the product library holds production kernels only
 // diagnostic: render with the instrumented kernel build and return the phase scheduler's counters (vecchio_amd_debug.h)
 int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, uint64_t out[16]) {
     if (!out) return fail(VK_ERR_BAD_ARG, "null argument");
@@ -1269,5 +1272,7 @@ int vk_debug_math(int device, int op, const float *a, const float *b, float *out
     HIP_TRY(hipMemcpy(out, dout.p, n * 4, hipMemcpyDeviceToHost));
     return VK_OK;
 }
+
+#endif
 
 }  // extern "C"

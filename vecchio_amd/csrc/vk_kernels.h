@@ -936,6 +936,7 @@ __global__ void tile_move_kernel(const void *src, void *dst, uint32_t width, uin
     }
 }
 
+#ifdef VK_DEBUG_LIB
 // device math probe (tests: GPU transcendental/draw functions are bit-identical to the host's)
 __global__ void math_probe_kernel(int op, const float *a, const float *b, float *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -957,6 +958,8 @@ __global__ void math_probe_kernel(int op, const float *a, const float *b, float 
     }
     out[i] = r;
 }
+
+#endif
 
 }  // namespace
 #endif

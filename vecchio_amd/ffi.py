@@ -200,20 +200,8 @@ def device_lib_path():
     return os.environ.get("VK_DEVICE_LIB") or os.path.join(LIB_DIR, "libvecchio_amd.so")
 
 
-def load_device_lib():
-    """libvecchio_amd.so: the HIP product behind include/vecchio_amd.h.  Fails loudly if absent."""
-    global _dev
-    if _dev is not None:
-        return _dev
-    path = device_lib_path()
-    from . import build
-    if not os.environ.get("VK_DEVICE_LIB") and build.device_is_stale():
-        try:                        # a fresh or edited checkout: compile with hipcc; there is no CPU fallback to use instead
-            _build_locked(path, build.build_device)
-        except Exception as e:
-            raise RuntimeError(f"{path} missing or stale and hipcc could not build it ({e}); the HIP extension is required "
-                               "(no CPU fallback exists)") from e
-    lib = C.CDLL(path)
+def _bind(lib):
+    """restype / argtypes of every entry point of include/vecchio_amd.h"""
     lib.vk_abi_version.restype = C.c_int
     lib.vk_device_count.restype = C.c_int
     lib.vk_last_error.restype = C.c_char_p
@@ -241,5 +229,46 @@ def load_device_lib():
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
     lib.vk_scene_get_info.restype = C.c_int
     lib.vk_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
+
+
+_dbg = None
+
+
+def load_debug_lib():
+    """libvecchio_amd_debug.so: the same sources built with -DVK_DEBUG_LIB (instrumented kernel builds, device arithmetic probe:
+    include/vecchio_amd_debug.h).  TESTS AND DIAGNOSTICS ONLY.  A vk_scene belongs to the library that created it:
+    DeviceScene(desc, lib=load_debug_lib())."""
+    global _dbg
+    if _dbg is not None:
+        return _dbg
+    path = os.path.join(LIB_DIR, "libvecchio_amd_debug.so")
+    from . import build
+    if build.debug_is_stale():
+        _build_locked(path, build.build_device_debug)
+    lib = C.CDLL(path)
+    _bind(lib)
+    lib.vk_debug_phase_stats.restype = C.c_int
+    lib.vk_debug_phase_stats.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.POINTER(C.c_uint64 * 16)]
+    lib.vk_debug_math.restype = C.c_int
+    lib.vk_debug_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    _dbg = lib
+    return lib
+
+
+def load_device_lib():
+    """libvecchio_amd.so: the HIP product behind include/vecchio_amd.h.  Fails loudly if absent."""
+    global _dev
+    if _dev is not None:
+        return _dev
+    path = device_lib_path()
+    from . import build
+    if not os.environ.get("VK_DEVICE_LIB") and build.device_is_stale():
+        try:                        # a fresh or edited checkout: compile with hipcc; there is no CPU fallback to use instead
+            _build_locked(path, build.build_device)
+        except Exception as e:
+            raise RuntimeError(f"{path} missing or stale and hipcc could not build it ({e}); the HIP extension is required "
+                               "(no CPU fallback exists)") from e
+    lib = C.CDLL(path)
+    _bind(lib)
     _dev = lib
     return lib

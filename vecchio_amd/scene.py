@@ -68,10 +68,11 @@ def check(lib, status):
 
 
 class DeviceScene:
-    def __init__(self, desc, device=0, devices=None):
+    def __init__(self, desc, device=0, devices=None, lib=None):
         """device: one MI355X (vk_scene_create).  devices=[...]: one handle over several (vk_scene_create_multi):
-        render() then deals the tiles over them and gathers on devices[0] inside the library."""
-        self._lib = ffi.load_device_lib()
+        render() then deals the tiles over them and gathers on devices[0] inside the library.
+        lib: another build of the library (ffi.load_debug_lib(): the handle belongs to the library that made it)."""
+        self._lib = lib or ffi.load_device_lib()
         h = C.c_void_p()
         if devices is not None:
             arr = (C.c_int * len(devices))(*devices)
