@@ -15,11 +15,16 @@ import oracle_ffi as O  # noqa: E402
 from test_gpu_parity import compare_samples, device_samples  # noqa: E402
 from vecchio_amd import DeviceScene, HostScene  # noqa: E402
 
-jobs = [("random_spheres_iow", 1920, 32, 50), ("cornell_box", 1024, 32, 50), ("final_scene", 800, 32, 50), ("stress_spheres:500", 2048, 4, 50)]
+jobs = [("random_spheres_iow", 1920, 32, 50), ("cornell_box", 1024, 32, 50), ("final_scene", 800, 32, 50), ("stress_spheres:500", 2048, 4, 50),
+        ("stress_spheres:500+empirical", 2048, 4, 50)]
 if len(sys.argv) == 5:
     jobs = [(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))]
 for name, width, spp, depth in jobs:
-    hs = HostScene(name, 1)
+    empirical = name.endswith("+empirical")
+    hs = HostScene(name.replace("+empirical", ""), 1)
+    if empirical:
+        from vecchio_amd import ffi
+        hs.desc.contents.flags = ffi.VK_SCENE_EMPIRICAL_TREES
     cam = hs.next_camera()
     ds = DeviceScene(hs.desc)
     p = hs.params(width, spp, depth, seed=2)

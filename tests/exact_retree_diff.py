@@ -17,7 +17,8 @@ if a:
 lib = ffi.load_device_lib()
 for name, w, spp in jobs:
     imgs = []
-    for flags in (ffi.VK_SCENE_REFERENCE_TREE, 0):
+    # (the stress worlds are rebuilt only on request: their default is the tree as handed over)
+    for flags in (ffi.VK_SCENE_REFERENCE_TREE, ffi.VK_SCENE_EMPIRICAL_TREES if name.startswith("stress") else 0):
         hs = HostScene(name, 1)
         hs.desc.contents.flags = flags
         cam = hs.next_camera()
