@@ -2,7 +2,9 @@
 only, the program directly after `--`: MI355X_MICROARCH.md's recipe).
     python tests/prof_counters.py OUT.json "<bench args>" "CTR_A CTR_B" "CTR_C ..."
     python tests/prof_counters.py OUT.json "@<scene> <width> <spp>" "CTR_A CTR_B" ...      (tests/render_once.py instead of bench.py)
-Writes {counter: average per dispatch of the production render kernel} plus derived per-sample figures."""
+Writes {counter: sum over the production render-kernel dispatches of the ONE frame rendered — a frame is two or more dispatches
+when the library launches 16 + 12 waves per CU, and three more with exact re-treeing's second and fallback launches} plus
+`dispatches` = their number."""
 import csv
 import glob
 import json
@@ -35,7 +37,8 @@ for group in groups:
                 vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
                 res["kernel"] = row["Kernel_Name"]
     for c in group:
-        res["counters"][c] = sum(vals[c]) / len(vals[c]) if vals[c] else None
+        res["counters"][c] = sum(vals[c]) if vals[c] else None       # one frame was rendered: its dispatches add up
+        res["dispatches"] = len(vals[c]) if vals[c] else res.get("dispatches")
     if r.returncode != 0:
         res.setdefault("errors", []).append({"group": group, "rc": r.returncode, "stderr": r.stderr[-500:]})
     res.setdefault("stdout", []).append(r.stdout[-300:])
