@@ -124,14 +124,13 @@ def test_the_constructed_ray(variant, lem, oracle):
     d, desc = adversarial_scene()
     h = oracle.hit(desc, RAY_O, RAY_D)
     assert h is not None and abs(h["t"] - T_X) < 1e-5          # the reference's answer: sphere X, early by a factor of four
-    # the default: the long unit {X, Y} (and Z's) stay in the pruned copy of the tree as handed over that is walked first, in the
-    # reference's order; everything else is rebuilt with grown gates (vk_linearize.cpp rt_grow_units): the reference's answer
+    # the default: a world with a unit too long for a grown gate is not rebuilt (vk_linearize.cpp rt_grow_units): walked as handed over
     t, prim, _ = emu_hit(lem, desc, EMU_GLOBAL_VARIANT=variant)
     assert (t, prim) == (h["t"], 0)
     desc.contents.flags = ffi.VK_SCENE_REFERENCE_TREE
     assert emu_hit(lem, desc, EMU_GLOBAL_VARIANT=variant)[:2] == (h["t"], 0)
-    # the empirical form (every unit rebuilt with its bare box; VK_GATE_PROOF=0 forces it where the proven form exists), as the device
-    # runs scenes from global memory: Z first, then X's unit does not pass T (1 + 1/16): WRONG
+    # the empirical form (every unit rebuilt with its bare box), as the device runs scenes from global memory: Z first, then X's unit
+    # does not pass T (1 + 1/16): WRONG
     desc.contents.flags = ffi.VK_SCENE_EMPIRICAL_TREES
     t, prim, redone = emu_hit(lem, desc, EMU_GLOBAL_VARIANT=variant, VK_GATE_PROOF="0")
     if variant == "1":

@@ -605,13 +605,15 @@ struct Builder {
     // it shrinks until every unit's far-origin check holds.
     // The growth goes with the square of a unit's size, and BVHNode::new's units can be long (random axis, median split; a scene whose
     // spheres all share one coordinate wastes every split on that axis: one unit in a hundred of the 1 M-sphere stress scene is
-    // longer than 100 sphere diameters).  Grown, such units would overlap everything around them.  LONG units — growth beyond
-    // RT_LONG_GROWTH of their smaller radius, or a far-origin check that fails — are therefore not rebuilt at all: they keep their
-    // place in a copy of the tree as handed over that is pruned down to them (rt_emit_long), and that copy is walked FIRST.  Walked
-    // first and in the reference's order, with the reference's boxes, a long unit sees a closest hit so far that is at least the one
-    // the reference's walk has when it reaches the unit (the reference has visited everything this walk has, and more), so its gate
-    // passes whenever the reference's does: sound without any lemma.  The compact units follow in the rebuilt tree with grown gates.
-    // `proven` = this worked out and the compact units' boxes grew by less than RT_MAX_AREA_GROWTH in surface area on average.
+    // longer than 100 sphere diameters).  Grown, such units would overlap everything around them.  A unit is LONG when its growth
+    // would exceed RT_LONG_GROWTH of its smaller radius or its far-origin check fails, and a world with a long unit is not rebuilt in
+    // the proven form.  (Round 4 tried to keep long units in a pruned copy of the tree as handed over, walked first in the reference's
+    // order — "the reference has visited everything this walk has, so its closest hit is no larger, so the gate passes whenever the
+    // reference's does".  Writing the proof out showed the hole: this walk can accept an EARLY candidate of a long unit that the
+    // reference skips because it already holds a hit from a compact unit, and from then on its closest hit is SMALLER than the
+    // reference's; a second early candidate in a later long unit is then missed although the reference takes it.  Two early candidates
+    // on one ray: never observed, but not a theorem.  docs/gate_lemma.md section 4.)
+    // `proven` = no long unit, and the units' boxes grow by less than RT_MAX_AREA_GROWTH in surface area on average.
     // Otherwise the scene is walked on the tree as handed over, unless the caller asked for VK_SCENE_EMPIRICAL_TREES: then every unit
     // is rebuilt with its box as handed over, the padding is RT_PAD_EMPIRICAL and the exactness of the rebuilt walk is what the test
     // suites have measured, not what the gate lemma proves (include/vecchio_amd.h; tests/test_gate_lemma.py constructs a ray on which
@@ -619,8 +621,6 @@ struct Builder {
     bool gate_grow = true, want_proof = true, proof_only = true;
     bool proven = false;
     double gate_pad = RT_PAD;
-    std::vector<char> rt_long_node;         // per vk_bvh_node: its unit is a long one (rt_emit_long)
-    size_t rt_n_long = 0;
     bool rt_grow_units(std::vector<RtObj> &objs) {
         if (objs.empty()) return false;
         std::vector<float> cx, cy, cz, rr;
@@ -630,6 +630,11 @@ struct Builder {
                 const DSphere &sp = L.spheres[VKD_INDEX(dr)];
                 cx.push_back(sp.cx); cy.push_back(sp.cy); cz.push_back(sp.cz); rr.push_back(sp.r);
             }
+        // (the error analysis behind rt_eta assumes no overflow or underflow inside Sphere::hit: coordinates and radii below 2^30, radii
+        // above 2^-40)
+        for (size_t i = 0; i < rr.size(); i++)
+            if (!(std::fabs(cx[i]) < 1073741824.0f && std::fabs(cy[i]) < 1073741824.0f && std::fabs(cz[i]) < 1073741824.0f &&
+                  rr[i] < 1073741824.0f && rr[i] > 9.0949470177292824e-13f)) return false;
         auto median = [](std::vector<float> v) { std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end()); return (double)v[v.size() / 2]; };
         RtDomain dom;
         dom.c0[0] = median(cx); dom.c0[1] = median(cy); dom.c0[2] = median(cz);
@@ -673,107 +678,21 @@ struct Builder {
             area0 += 1.0; area1 += (double)rt_half_area(mn, mx) / std::max((double)rt_half_area(objs[i].mn, objs[i].mx), 1e-300);
             gmax = std::max(gmax, (double)g);
         }
-        // (too many long units: the walk would mostly be the reference's own)
-        const bool cheap = area0 >= (double)RETREE_MIN && area1 <= (1.0 + RT_MAX_AREA_GROWTH) * area0 && n_long * 4 <= objs.size();
+        const bool cheap = n_long == 0 && area1 <= (1.0 + RT_MAX_AREA_GROWTH) * area0;
         if (getenv("VK_RETREE_DEBUG"))
-            fprintf(stderr, "vecchio_amd: exact re-treeing: %zu units, %zu of them long (kept in the pruned tree as handed over); trusted ball "
+            fprintf(stderr, "vecchio_amd: exact re-treeing: %zu units, %zu of them long; trusted ball "
                 "centre (%g %g %g) radius %g (extent %g); growth of the others: largest %g, leaf area x %.4f at padding %g -> %s\n",
                 objs.size(), n_long, dom.c0[0], dom.c0[1], dom.c0[2], dom.r0, ext, gmax, area1 / std::max(area0, 1.0), gate_pad,
                 cheap ? "grown gates (proven)" : "too dear");
         if (!cheap) return false;
-        rt_long_node.assign(d->n_bvh, 0);
-        std::vector<RtObj> compact;
-        compact.reserve(objs.size() - n_long);
-        for (size_t i = 0; i < objs.size(); i++) {
-            if (is_long[i]) { rt_long_node[objs[i].parent] = 1; continue; }
-            RtObj o = objs[i];
-            if (gate_grow) {
+        if (gate_grow)
+            for (size_t i = 0; i < objs.size(); i++) {
                 const float g = std::nextafter((float)grow[i], INFINITY);
-                for (int a = 0; a < 3; a++) { o.mn[a] = std::nextafter(o.mn[a] - g, -INFINITY); o.mx[a] = std::nextafter(o.mx[a] + g, INFINITY); }
+                for (int a = 0; a < 3; a++) { objs[i].mn[a] = std::nextafter(objs[i].mn[a] - g, -INFINITY);
+                    objs[i].mx[a] = std::nextafter(objs[i].mx[a] + g, INFINITY); }
             }
-            compact.push_back(o);
-        }
-        rt_n_long = n_long;
-        objs.swap(compact);
         for (int a = 0; a < 3; a++) L.trust_c0[a] = (float)dom.c0[a];
         L.trust_r0 = (float)(dom.r0 * (1.0 - 1e-6));
-        return true;
-    }
-
-    // The tree as handed over, pruned down to the long units (rt_grow_units), in the reference's order: an inner node survives if two
-    // or more of {its own unit, its left subtree, its right subtree} hold a long unit (a node with one survivor only repeats a gate the
-    // survivor's own box implies: boxes are nested), a unit's objects keep their order.  Emitted in front of the rebuilt tree.
-    bool rt_emit_long(uint32_t root, uint32_t flip0, int32_t inst) {
-        if (rt_n_long == 0) return true;
-        // has[n]: the subtree of node n holds a long unit (post-order over an explicit stack)
-        std::vector<char> has(d->n_bvh, 0);
-        {
-            struct Fr { uint32_t node; int stage; };
-            std::vector<Fr> st; st.push_back(Fr{root, 0});
-            while (!st.empty()) {
-                Fr fr = st.back();
-                const vk_bvh_node &n = d->bvh[fr.node];
-                if (fr.stage == 0) {
-                    st.back().stage = 1;
-                    if (VK_REF_KIND(n.right) == VK_KIND_BVH) st.push_back(Fr{VK_REF_INDEX(n.right), 0});
-                    if (VK_REF_KIND(n.left) == VK_KIND_BVH) st.push_back(Fr{VK_REF_INDEX(n.left), 0});
-                    continue;
-                }
-                char h = rt_long_node[fr.node];
-                if (VK_REF_KIND(n.left) == VK_KIND_BVH) h |= has[VK_REF_INDEX(n.left)];
-                if (VK_REF_KIND(n.right) == VK_KIND_BVH) h |= has[VK_REF_INDEX(n.right)];
-                has[fr.node] = h;
-                st.pop_back();
-            }
-        }
-        struct Fr { uint32_t node; uint32_t flip; int stage; uint32_t item; bool inner; };
-        std::vector<Fr> st; st.push_back(Fr{root, flip0, 0, 0, false});
-        while (!st.empty()) {
-            Fr &fr = st.back();
-            const vk_bvh_node &n = d->bvh[fr.node];
-            const bool lb = VK_REF_KIND(n.left) == VK_KIND_BVH, rb = VK_REF_KIND(n.right) == VK_KIND_BVH;
-            if (fr.stage == 0) {
-                const int own = rt_long_node[fr.node] ? 1 : 0;
-                const int survivors = own + (lb && has[VK_REF_INDEX(n.left)] ? 1 : 0) + (rb && has[VK_REF_INDEX(n.right)] ? 1 : 0);
-                if (survivors == 0) { st.pop_back(); continue; }
-                DItem it; memset(&it, 0, sizeof(it));
-                it.mnx = n.bb_min[0]; it.mny = n.bb_min[1]; it.mnz = n.bb_min[2]; it.mxx = n.bb_max[0]; it.mxy = n.bb_max[1]; it.mxz = n.bb_max[2];
-                if (own && !lb && !rb) {             // a long unit of one or two spheres: a leaf with the node's box, as emit_bvh makes it
-                    uint32_t a, b = 0;
-                    if (!convert_object(n.left, fr.flip, inst, a)) return false;
-                    if (n.left != n.right && !convert_object(n.right, fr.flip, inst, b)) return false;
-                    it.w0 = a; it.w1 = b;
-                    L.items.push_back(it);
-                    L.n_prims += b ? 2u : 1u;
-                    st.pop_back();
-                    continue;
-                }
-                fr.inner = survivors >= 2;
-                if (fr.inner) { fr.item = (uint32_t)L.items.size(); L.items.push_back(it); }
-                fr.stage = 1;
-                continue;
-            }
-            if (fr.stage == 1 || fr.stage == 2) {
-                const vk_ref child = fr.stage == 1 ? n.left : n.right;
-                const uint32_t node = fr.node, flip = fr.flip;
-                fr.stage += 1;
-                if (VK_REF_KIND(child) == VK_KIND_BVH) {
-                    if (has[VK_REF_INDEX(child)]) st.push_back(Fr{VK_REF_INDEX(child), flip ^ ((child & VK_REF_FLIP) ? DREF_FLIP : 0u), 0, 0, false});
-                } else if (rt_long_node[node]) {     // an object beside a subtree: the reference gates it by this node's box alone
-                    DItem it = fr.inner ? always_hit_leaf() : DItem();
-                    if (!fr.inner) { memset(&it, 0, sizeof(it)); it.mnx = n.bb_min[0]; it.mny = n.bb_min[1]; it.mnz = n.bb_min[2];
-                        it.mxx = n.bb_max[0]; it.mxy = n.bb_max[1]; it.mxz = n.bb_max[2]; }
-                    uint32_t a;
-                    if (!convert_object(child, flip, inst, a)) return false;
-                    it.w0 = a; it.w1 = 0;
-                    L.items.push_back(it);
-                    L.n_prims += 1;
-                }
-                continue;
-            }
-            if (fr.inner) L.items[fr.item].w0 = (uint32_t)L.items.size();      // skip link: first item after this subtree
-            st.pop_back();
-        }
         return true;
     }
 
@@ -849,7 +768,6 @@ struct Builder {
                 if (first || VKD_KIND(dr) == DK_RECT) L.tie_rank[id] = (n_blocks << 20) | (k ? ranked[i].rank2 : ranked[i].rank);
             }
         }
-        if (retree_units && proven && !rt_emit_long(root, flip, inst)) return false;
         rt_emit(objs, 0, objs.size(), 0);
         done = true;
         if (inst < 0 && VK_REF_KIND(d->world) == VK_KIND_BVH && root == VK_REF_INDEX(d->world)) world_rebuilt = true;
