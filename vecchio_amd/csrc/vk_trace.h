@@ -384,11 +384,19 @@ VK_HD bool slab_exact(const DItem &n, V3 o, V3 d, float tmin, float tmax) {
     return true;
 }
 // ------------------------------------------------------------------ traversal
+// exact re-treeing: outside the ball in which the gate lemma's bounds hold (DScene::trust_c0; never for r0 = +inf)
+VK_HD bool origin_untrusted(const DScene &S, V3 o) {
+    const V3 oc = o - v3(S.trust_c0[0], S.trust_c0[1], S.trust_c0[2]);
+    return !(length2(oc) <= S.trust_r0sq);
+}
 // redo (exact re-treeing of a scene traversed from global memory, DScene::walk_start != 0): this lane walks the tree as handed over,
 // items[0, walk_start - 1), on unscaled distances
 template <uint32_t ISHIFT = 0, bool FUSED = false, bool TIGHT = FUSED>
 VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time, bool redo = false) {
     L.wo = o; L.wd = d; L.time = time;
+    // (both trees in items[]: a segment that starts outside the trusted ball is the handed-over tree's from the start — segment_unsafe
+    // would send it there after a wasted walk)
+    if (S.walk_start != 0u) redo = redo || origin_untrusted(S, o);
     set_space<FUSED, TIGHT>(L, o, d, redo ? 1.0f : S.gate_scale);
     L.i = redo ? 0u : (S.walk_start << ISHIFT); L.end = S.n_world_items << ISHIFT; L.pend = 0; L.pend2 = 0; L.cur_inst = -1;
     L.T = INFINITY; L.best_prim = 0; L.best_inst = -1; L.best_aux = 0.0f;
@@ -594,8 +602,9 @@ template <uint32_t F, class Mem>
 VK_HD bool segment_unsafe(const Lane &L, const DScene &S, const Mem &M) {
     if (!(S.t_pad > 0.0f)) return false;
     // the ray: inside the trusted ball, components the fast box test trusts (xnan is NaN otherwise)
-    const V3 oc = L.o - v3(S.trust_c0[0], S.trust_c0[1], S.trust_c0[2]);
-    bool unsafe = !(length2(oc) <= S.trust_r0sq) || !(L.xnan == L.xnan);
+    const bool outside = origin_untrusted(S, L.o);
+    if (S.walk_start != 0u && outside) return false;       // (begin_segment: this one WAS walked on the tree as handed over)
+    bool unsafe = outside || !(L.xnan == L.xnan);
     if (L.best_prim != 0u) {
         const DSphere sp = M.sphere(VKD_INDEX(L.best_prim));
         const float bx0 = sp.cx - sp.r, bx1 = sp.cx + sp.r, by0 = sp.cy - sp.r, by1 = sp.cy + sp.r, bz0 = sp.cz - sp.r, bz1 = sp.cz + sp.r;
