@@ -1,0 +1,64 @@
+"""A `len == 1` node of BVHNode::new (accel.rs:108-111) holds the same object as both children and calls it twice, the second time
+with tmax = the first call's hit.  The lineariser drops the second call where it cannot return anything: simple objects, and — since
+round 4 — a Translate / Rotate chain over a child in which nothing draws (vk_linearize.cpp draw_free_instance; the final scene's sphere
+cluster sits in such a node).  A chain over a ConstantMedium keeps both calls: the second one draws again (hittable.rs:473)."""
+import numpy as np
+import pytest
+
+from descs import Desc, camera, params
+from test_emu_parity import compare
+from vecchio_amd import ffi
+
+
+def _scene(with_medium, n=40, seed=7):
+    r = np.random.default_rng(seed)
+    d = Desc()
+    grey, glass = d.lambertian(0.6, 0.6, 0.7), d.mat(ffi.VK_MAT_DIELECTRIC, 0, 1.5)
+    iso = d.mat(ffi.VK_MAT_ISOTROPIC, d.solid(0.8, 0.8, 0.9))
+    light = d.light(7, 7, 7)
+
+    def tree(objs):
+        if len(objs) == 1:
+            return objs[0]
+        k = len(objs) // 2
+        (l, lb), (rr, rb) = tree(objs[:k]), tree(objs[k:])
+        lo, hi = np.minimum(lb[0], rb[0]), np.maximum(lb[1], rb[1])
+        return d.bvh_node(l, rr, tuple(lo.astype(np.float32)), tuple(hi.astype(np.float32))), (lo, hi)
+
+    balls = []
+    for _ in range(n):
+        c, rad = r.uniform(-2, 2, 3), float(r.uniform(0.15, 0.5))
+        balls.append((d.sphere(tuple(c), rad, grey if r.uniform() < 0.7 else glass), (c - rad, c + rad)))
+    if with_medium:
+        c = np.zeros(3)
+        balls.append((d.medium(d.sphere((0.0, 0.0, 0.0), 1.5, glass), 0.8, iso), (c - 1.5, c + 1.5)))
+    cluster, bb = tree(balls)
+    inst = d.translate(d.rotate(cluster, 1, 15.0), (5.0, 5.0, 5.0))
+    lo, hi = bb[0] - 1.0 + 5.0, bb[1] + 1.0 + 5.0
+    dup = d.bvh_node(inst, inst, tuple(lo.astype(np.float32)), tuple(hi.astype(np.float32)))          # the len == 1 node
+    lref = d.xz_rect(2.0, 8.0, 2.0, 8.0, 9.5, light)
+    world = d.bvh_node(dup, Desc.flip(lref), (-1.0, -1.0, -1.0), (11.0, 11.0, 11.0))
+    desc = d.finish(world, [lref])
+    return desc, camera((5.0, 5.5, -6.0), (5, 5, 5), vfov=45.0), params(40, 30, 8, max_depth=50, seed=11)
+
+
+@pytest.mark.parametrize("with_medium", [False, True])
+def test_a_len1_node_enters_a_draw_free_instance_once(with_medium, oracle, emu, built):
+    desc, cam, p = _scene(with_medium)
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    img_e, ps_e, steps, info = emu.render_samples(desc, cam, p)
+    compare(ps_o, ps_e, img_o, img_e)
+    assert info[2] == (2 if with_medium else 1), info      # instance records: one per call the device makes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_medium", [False, True])
+def test_a_len1_node_on_the_gpu(with_medium, device, oracle):
+    from test_gpu_parity import compare_samples, device_samples
+    from vecchio_amd import DeviceScene
+    desc, cam, p = _scene(with_medium)
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    ds = DeviceScene(desc)
+    img_d, ps_d = device_samples(ds, cam, p)
+    compare_samples(ps_o, ps_d, img_o, img_d)
+    ds.close()

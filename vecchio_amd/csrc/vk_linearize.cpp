@@ -318,6 +318,28 @@ struct Builder {
         return it;
     }
 
+    // A `len == 1` node (accel.rs:108-111: both children the same Arc) calls its object twice, the second time with tmax = the first
+    // call's hit.  For an object in which nothing draws the second call returns None: every box it passes it passed in the first call
+    // (AxisBB::hit is monotone in tmax, and the second call's tmax is the first call's final one), so every sphere it tests was tested
+    // then with a larger tmax, and a root below the final t would have been accepted.  That holds under a Translate / Rotate chain as
+    // well (hittable.rs:507-524,578-624 pass tmin and tmax through): an instance whose child holds no ConstantMedium is entered once.
+    // (The final scene's 1 000-sphere cluster sits in such a node: 213 -> 173 steps per sample, C3 +26 %.)
+    bool draw_free_instance(uint32_t idx, bool &yes) {
+        yes = false;
+        const DInstance &I = L.instances[idx];
+        if (I.child_ref != 0u) {
+            if (VKD_KIND(I.child_ref) == DK_INSTANCE) return draw_free_instance(VKD_INDEX(I.child_ref), yes);
+            yes = draw_free(I.child_ref);
+            return true;
+        }
+        for (const Pending &p : pending)
+            if (p.inst == (int32_t)idx) {
+                if (simple_count.empty() || simple_count[p.bvh_index] == -2) { if (!classify(p.bvh_index)) return false; }
+                yes = simple_count[p.bvh_index] >= 0;
+                return true;
+            }
+        return true;
+    }
     static bool draw_free(uint32_t dref) { uint32_t k = VKD_KIND(dref);
         return k == DK_SPHERE || k == DK_MOVING || k == DK_RECT || k == DK_LIST || k == DK_BOX; }
 
@@ -803,7 +825,9 @@ struct Builder {
                     uint32_t a, b = 0;
                     if (!convert_object(n.left, fr.flip, inst, a)) return false;
                     bool dup = (n.left == n.right);
-                    if (!(dup && draw_free(a))) { if (!convert_object(n.right, fr.flip, inst, b)) return false; }
+                    bool skip_second = dup && draw_free(a);
+                    if (dup && !skip_second && VKD_KIND(a) == DK_INSTANCE) { if (!draw_free_instance(VKD_INDEX(a), skip_second)) return false; }
+                    if (!skip_second) { if (!convert_object(n.right, fr.flip, inst, b)) return false; }
                     L.items[pos].w0 = a; L.items[pos].w1 = b;
                     set_home(a, pos + 1, b);
                     set_home(b, pos + 1, 0);

@@ -396,7 +396,7 @@ VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time, bool 
     L.wo = o; L.wd = d; L.time = time;
     // (both trees in items[]: a segment that starts outside the trusted ball is the handed-over tree's from the start — segment_unsafe
     // would send it there after a wasted walk)
-    if (S.walk_start != 0u) redo = redo || origin_untrusted(S, o);
+    if (TIGHT && S.walk_start != 0u) redo = redo || origin_untrusted(S, o);      // (TIGHT: the sphere-only variants)
     set_space<FUSED, TIGHT>(L, o, d, redo ? 1.0f : S.gate_scale);
     L.i = redo ? 0u : (S.walk_start << ISHIFT); L.end = S.n_world_items << ISHIFT; L.pend = 0; L.pend2 = 0; L.cur_inst = -1;
     L.T = INFINITY; L.best_prim = 0; L.best_inst = -1; L.best_aux = 0.0f;
