@@ -10,7 +10,7 @@ from test_emu_parity import compare
 from vecchio_amd import ffi
 
 
-def _scene(with_medium, n=40, seed=7):
+def _scene(with_medium, n=40, seed=7, bare=None):
     r = np.random.default_rng(seed)
     d = Desc()
     grey, glass = d.lambertian(0.6, 0.6, 0.7), d.mat(ffi.VK_MAT_DIELECTRIC, 0, 1.5)
@@ -33,6 +33,10 @@ def _scene(with_medium, n=40, seed=7):
         c = np.zeros(3)
         balls.append((d.medium(d.sphere((0.0, 0.0, 0.0), 1.5, glass), 0.8, iso), (c - 1.5, c + 1.5)))
     cluster, bb = tree(balls)
+    if bare == "sphere":                # the chain's child is ONE object, not a BVH (DInstance::child_ref)
+        cluster, bb = d.sphere((0.0, 0.0, 0.0), 1.2, glass), (np.full(3, -1.2), np.full(3, 1.2))
+    elif bare == "medium":
+        cluster, bb = d.medium(d.sphere((0.0, 0.0, 0.0), 1.5, glass), 0.8, iso), (np.full(3, -1.5), np.full(3, 1.5))
     inst = d.translate(d.rotate(cluster, 1, 15.0), (5.0, 5.0, 5.0))
     lo, hi = bb[0] - 1.0 + 5.0, bb[1] + 1.0 + 5.0
     dup = d.bvh_node(inst, inst, tuple(lo.astype(np.float32)), tuple(hi.astype(np.float32)))          # the len == 1 node
@@ -49,6 +53,15 @@ def test_a_len1_node_enters_a_draw_free_instance_once(with_medium, oracle, emu, 
     img_e, ps_e, steps, info = emu.render_samples(desc, cam, p)
     compare(ps_o, ps_e, img_o, img_e)
     assert info[2] == (2 if with_medium else 1), info      # instance records: one per call the device makes
+
+
+@pytest.mark.parametrize("bare,records", [("sphere", 1), ("medium", 2)])
+def test_a_len1_node_over_a_chain_with_one_object(bare, records, oracle, emu, built):
+    desc, cam, p = _scene(False, bare=bare)
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    img_e, ps_e, steps, info = emu.render_samples(desc, cam, p)
+    compare(ps_o, ps_e, img_o, img_e)
+    assert info[2] == records, info
 
 
 @pytest.mark.gpu
