@@ -84,7 +84,14 @@ def physical_bounds(c, samples, seconds, scene_in_lds, issue, walked=None):
     rec = 32.0 * (c["n_aabb"] - c["n_aabb_nonfinite"]) + 16.0 * (c["n_sphere"] - c["n_sphere_nonfinite"]) + 36.0 * c["n_moving"] + 24.0 * c["n_rect"] + \
         32.0 * c["n_xform"] + 8.0 * c["n_medium"]
     note = "record bytes from the oracle's visit counts: the device walks the same tree, item for item"
-    if walked:      # the device walks a rebuilt tree: its own visits (tests/emu, the kernel's per-lane code on the host, same sample)
+    if walked and "sphere_tests" not in walked:
+        # the tree as handed over, but for the second call of `len == 1` nodes over draw-free instances, which the device does not make
+        # (vk_linearize.cpp draw_free_instance): its box tests counted by the kernel's per-lane code on the host, the primitive visits
+        # still the oracle's (an upper bound)
+        rec -= 32.0 * (walked["oracle_box_tests"] - walked["box_tests"]) * n
+        note = ("box tests of the walk the device performs (tests/emu: the tree as handed over without the second call of len-1 nodes over "
+                "draw-free instances); primitive visits from the oracle's counts (upper bound)")
+    elif walked:      # the device walks a rebuilt tree: its own visits (tests/emu, the kernel's per-lane code on the host, same sample)
         rec = (32.0 * walked["box_tests"] + 16.0 * walked["sphere_tests"]) * n
         note = ("record bytes of the walk the device performs (rebuilt tree, second walks and requeued samples included), counted by the "
                 "kernel's per-lane code built for the host (tests/emu) on the same bounded sample as the oracle's counters")
@@ -415,6 +422,14 @@ def main():
                 walked = {"box_tests": nb / ne, "sphere_tests": ns / ne, "oracle_box_tests": c["n_aabb"] / float(c["samples"]),
                           "oracle_sphere_tests": c["n_sphere"] / float(c["samples"])}
                 bps_walked = 32.0 * walked["box_tests"] + 16.0 * walked["sphere_tests"] + 16.0 * c["n_closest"] / float(c["samples"]) + 12.0 / spp
+            if walked is None and (info.features & 0x10):       # scenes with instances: see physical_bounds
+                import emu_ffi
+                emu_ffi.take_visit_counts()
+                pe = hs.params(cw, 1, depth, seed=2)
+                _, ps_e, _, _ = emu_ffi.render_samples(hs.desc, cam, pe, threads=cores)
+                nb, _ns = emu_ffi.take_visit_counts()
+                walked = {"box_tests": nb / float(ps_e.shape[0]), "oracle_box_tests": c["n_aabb"] / float(c["samples"])}
+                bps_walked = bps - 32.0 * (walked["oracle_box_tests"] - walked["box_tests"])
             k_ms = float(np.mean(kernel_ms)) if kernel_ms else None
             # measured HBM traffic and instruction counts per launch: PMC counters cannot be collected from inside this
             # process, so they come from the committed rocprofv3 passes of this same command (profiles/, tests/prof_r02.sh):

@@ -70,7 +70,8 @@ static void trace_one(const DScene &S, const GlobalMem &M0, const RenderConsts &
     for (;;) {
         uint64_t nb = 0, ns = 0;
         while (traversing(L)) {
-            if (has_prim_work(L)) ns += ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && L.pend2) ? 2u : 1u; else nb++;
+            if (has_prim_work(L)) ns += ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && L.pend2) ? 2u : 1u;
+            else if (L.i < L.end) nb++;       // (a step at the end of an instance's range reads no item: it leaves the instance)
             traverse_step<F, Mem>(L, S, M);
             if (steps) (*steps)++;
         }
