@@ -68,7 +68,7 @@ struct LinearizeOptions {
 
 // ---- exact re-treeing: the arithmetic behind the soundness of the rebuilt tree's gates ("Gate lemma").
 // Sphere::hit in f32 (hittable.rs:65-95) reports hit points that need not lie on the sphere: with u = 2^-24 and rho = |o - c|, the point
-// o + t d of an accepted root t lies within rt_eta(rho, R) of the sphere's surface (forward error analysis: K <= 30; measured <= 6;
+// o + t d of an accepted root t lies within rt_eta(rho, R) of the sphere's surface (forward error analysis: K <= 30; measured <= 7;
 // RT_KAPPA = 32 u).  A unit's gate box is the reference's box grown by rt_unit_growth(): then, for every ray origin inside the trusted
 // ball `dom`, the gate passes whenever the reference could have accepted one of the unit's spheres — because the hit point lies inside
 // the grown box (near origins) or because it precedes the box entry by less than the gate's relative padding RT_PAD (far origins).
