@@ -133,12 +133,10 @@ def test_the_constructed_ray(variant, lem, oracle):
     # does not pass T (1 + 1/16): WRONG
     desc.contents.flags = ffi.VK_SCENE_EMPIRICAL_TREES
     t, prim, redone = emu_hit(lem, desc, EMU_GLOBAL_VARIANT=variant, VK_GATE_PROOF="0")
-    if variant == "1":
-        assert prim == 2 and abs(t - T_Z) < 1e-2 and not redone
-    else:
-        # staged in LDS the box test is the fused one, whose margin grows with |o / d|: for a ray this close to parallel to an axis every
-        # winner counts as unsafe and the tree as handed over decides — right answer, by the margin, not by the gate
-        assert (t, prim) == (h["t"], 0) and redone
+    # (in both of the device's forms.  Until the safe-winner test got its exact second level — the reference's own AxisBB::hit of the
+    # winner's box where the fast arithmetic's margin is inconclusive — the LDS form, whose fused box test has a margin that grows
+    # with |o / d|, called every winner of a ray this close to parallel to an axis unsafe and was right by accident.)
+    assert prim == 2 and abs(t - T_Z) < 1e-2 and not redone
 
 
 def window_setup(flags):

@@ -626,7 +626,17 @@ VK_HD bool segment_unsafe(const Lane &L, const DScene &S, const Mem &M) {
         const float hi = fminf(ex, L.T * S.gate_scale);
         const bool passes = (hi - entry > __builtin_fmaf(fabsf(hi), 4.0e-6f, L.xnan)) &&     // (false for a NaN margin)
                             (ex - S.tmin_gate > __builtin_fmaf(fabsf(ex), 4.0e-6f, L.xnan));
-        unsafe = unsafe || !passes || !(sp.r > 0.0f);
+        bool ok = passes;
+        if (!ok && L.xnan == L.xnan) {
+            // inside the fast arithmetic's margin: the reference's own AxisBB::hit of the sphere's box with tmax = the winner's t.
+            // No margin is needed there: the boxes around the sphere in the tree as handed over contain its own, fl((b - o) / d) is
+            // monotone in b and the test is monotone in tmax, so they pass whenever this one does.  (A third of the segments the
+            // margin alone calls unsafe are; the rest need no second walk / second launch.)
+            DItem own;
+            own.mnx = bx0; own.mxx = bx1; own.mny = by0; own.mxy = by1; own.mnz = bz0; own.mxz = bz1; own.w0 = 0u; own.w1 = 0u;
+            ok = slab_exact(own, L.o, L.d, T_MIN, L.T);
+        }
+        unsafe = unsafe || !ok || !(sp.r > 0.0f);
     }
     return unsafe;
 }
