@@ -75,3 +75,15 @@ def test_a_len1_node_on_the_gpu(with_medium, device, oracle):
     img_d, ps_d = device_samples(ds, cam, p)
     compare_samples(ps_o, ps_d, img_o, img_d)
     ds.close()
+
+
+def test_the_final_scenes_cluster_is_entered_once(oracle, emu, host_scenes):
+    """BASELINE's C3 world (scene seed 1): the 1 000-sphere cluster under Translate(RotateY) is alone in a slice of BVHNode::new, i.e. both
+    children of a len-1 node.  One instance record, 173 instead of 213 steps per sample, every sample the oracle's (which makes both calls)."""
+    hs, cam = host_scenes("final_scene")
+    p = hs.params(48, 4, 50)
+    img_o, ps_o = oracle.render_samples(hs.desc, cam, p)
+    img_e, ps_e, steps, info = emu.render_samples(hs.desc, cam, p)
+    compare(ps_o, ps_e, img_o, img_e)
+    assert info[2] == 1, info
+    assert steps / ps_e.shape[0] < 195.0, steps / ps_e.shape[0]
