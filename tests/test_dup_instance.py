@@ -39,6 +39,8 @@ def _scene(with_medium, n=40, seed=7, bare=None):
         cluster, bb = d.medium(d.sphere((0.0, 0.0, 0.0), 1.5, glass), 0.8, iso), (np.full(3, -1.5), np.full(3, 1.5))
     inst = d.translate(d.rotate(cluster, 1, 15.0), (5.0, 5.0, 5.0))
     lo, hi = bb[0] - 1.0 + 5.0, bb[1] + 1.0 + 5.0
+    if bare == "bvh":                   # the len-1 node's object is the BVHNode itself (a world list may hold one: scene.rs boxes1)
+        inst, lo, hi = cluster, bb[0], bb[1]
     dup = d.bvh_node(inst, inst, tuple(lo.astype(np.float32)), tuple(hi.astype(np.float32)))          # the len == 1 node
     lref = d.xz_rect(2.0, 8.0, 2.0, 8.0, 9.5, light)
     world = d.bvh_node(dup, Desc.flip(lref), (-1.0, -1.0, -1.0), (11.0, 11.0, 11.0))
@@ -53,6 +55,20 @@ def test_a_len1_node_enters_a_draw_free_instance_once(with_medium, oracle, emu, 
     img_e, ps_e, steps, info = emu.render_samples(desc, cam, p)
     compare(ps_o, ps_e, img_o, img_e)
     assert info[2] == (2 if with_medium else 1), info      # instance records: one per call the device makes
+
+
+def test_a_len1_node_over_a_bvh_walks_it_once(oracle, emu, built):
+    sizes = {}
+    for with_medium in (False, True):
+        desc, cam, p = _scene(with_medium, bare="bvh")
+        p = params(40, 30, 8, max_depth=50, seed=11)
+        cam = camera((0.0, 0.5, -11.0), (0, 0, 0), vfov=45.0)
+        img_o, ps_o = oracle.render_samples(desc, cam, p)
+        img_e, ps_e, steps, info = emu.render_samples(desc, cam, p)
+        compare(ps_o, ps_e, img_o, img_e)
+        sizes[with_medium] = info[0]
+    # 40 spheres: 50 items when the subtree is emitted once; with a ConstantMedium inside (41 objects) it is emitted twice
+    assert sizes[False] <= 52 and sizes[True] >= 2 * sizes[False] - 4, sizes
 
 
 @pytest.mark.parametrize("bare,records", [("sphere", 1), ("medium", 2)])

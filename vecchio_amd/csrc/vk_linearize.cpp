@@ -841,8 +841,15 @@ struct Builder {
             }
             if (fr.stage == 1 || fr.stage == 2) {
                 vk_ref child = fr.stage == 1 ? n.left : n.right;
+                const bool second = fr.stage == 2;
                 fr.stage += 1;
                 uint32_t cf = fr.flip ^ ((child & VK_REF_FLIP) ? DREF_FLIP : 0u);
+                if (second && n.left == n.right && VK_REF_KIND(child) == VK_KIND_BVH) {
+                    // a len-1 node over a BVHNode in which nothing draws: the second call returns None (see draw_free_instance)
+                    const uint32_t ci = VK_REF_INDEX(child);
+                    if (simple_count.empty() || simple_count[ci] == -2) { if (!classify(ci)) return false; }
+                    if (simple_count[ci] >= 0) continue;
+                }
                 if (VK_REF_KIND(child) == VK_KIND_BVH) {
                     Frame nf{VK_REF_INDEX(child), cf, 0, 0};
                     st.push_back(nf);   // (fr is invalid after this)
