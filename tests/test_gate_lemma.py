@@ -9,7 +9,10 @@ works; in f32 a hit can lie off the sphere by eta = 32 u (rho + R)^2 / R and pre
   * part B aims rays at the worst configuration (grazing the sphere where it touches its box, nearly parallel to that face, long units)
     and checks the gate itself: the GROWN gates of the proven form never fail, the bare ones of the empirical form do;
   * part C builds a scene around one such ray: the empirical form returns the WRONG sphere (that is why it is opt-in,
-    VK_SCENE_EMPIRICAL_TREES), the default returns the reference's.
+    VK_SCENE_EMPIRICAL_TREES), the default returns the reference's;
+  * part D (round 5) REFUTES the shortcut "gate every sphere by its OWN box grown by the lemma's growth" (docs/gate_lemma.md section 6):
+    from hundreds of radii away Sphere::hit reports roots for lines that miss the sphere's grown own box altogether, and the reference,
+    whose unit box such a line does pass, accepts them.
 """
 import ctypes as C
 import os
@@ -29,6 +32,8 @@ def lem(emu, built):
     lib.emu_lemma_residual.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
     lib.emu_gate_soundness.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_float, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     lib.emu_hit.argtypes = [C.POINTER(ffi.SceneDesc), ffi.F3, ffi.F3, C.POINTER(C.c_float * 3)]
+    lib.emu_own_gate_soundness.argtypes = [C.c_uint64, C.c_uint64, C.c_float, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    lib.emu_own_gate_ray.argtypes = [C.c_float * 3, C.c_float, C.c_float * 3, C.c_float * 3, C.c_float, C.c_double, C.POINTER(C.c_float)]
     return lib
 
 
@@ -175,3 +180,31 @@ def test_a_window_of_rays_around_it(emu, oracle, built, monkeypatch):
     wrong = int((ps_o[:, :3] != ps_e[:, :3]).any(axis=1).sum())
     print(f"{red} of 4096 rays hit X in the reference; the empirical form gets {wrong} of them wrong")
     assert wrong > 0
+
+
+# ---- part D: gates made of the spheres' OWN boxes are not sound (the refutation of VERDICT r4's item 1, docs/gate_lemma.md section 6)
+def test_own_box_gates_are_not_sound(lem):
+    """A sphere's own box grown by rt_unit_growth (d* = sqrt 3 (R + g): growth 5e-4 R) is passed by every ray whose hit point lies
+    within the growth of the box or precedes the ray's ENTRY into it — but a line that passes a 0.2-sphere at 1.15 radii from 450 units
+    away never enters that box, and the f32 quadratic still reports a root for it.  The reference's unit box (a leaf's box around TWO
+    spheres) is what such a line passes; gating by it is what round 4 proves, and what stays."""
+    for r0 in (500.0, 2000.0, 20000.0):
+        cnt = (C.c_uint64 * 2)(); v = (C.c_float * 12)()
+        lem.emu_own_gate_soundness(400_000, 3, 0.25, r0, cnt, v)
+        print(f"trusted ball {r0}: {cnt[0]} rays with a candidate, own-box gate closed for {cnt[1]}; worst: the line misses the sphere by "
+              f"{v[11]:.2f} radii from {np.linalg.norm(np.array(v[4:7]) - np.array(v[0:3])):.0f} away")
+        assert cnt[0] > 50_000 and cnt[1] > 100
+
+
+def test_the_ray_that_refuted_them(lem):
+    """found on the 1 M-sphere stress scene (emulator, 96 x 54 x 2 spp: 14 of 18 432 samples differed from the tree as handed over with
+    own-box gates): a PRIMARY ray, 446.7 from sphere 284 099, whose line passes the centre at 0.2301 = 1.15 R (exact arithmetic) — 0.228 in
+    z alone, outside the grown own box — and for which Sphere::hit reports t = 41.5557; the reference's walk, whose boxes the ray passes,
+    takes that hit, the own-box walk returned the ground sphere at t = 41.7669."""
+    f3 = C.c_float * 3
+    out = (C.c_float * 4)()
+    rc = lem.emu_own_gate_ray(f3(-224.58372497558594, 0.20000000298023224, 87.19125366210938), 0.20000000298023224,
+                              f3(206.818161, 109.090912, 47.727272), f3(-10.3778687, -2.61903381, 0.954879761), 0.25, 20000.0, out)
+    assert rc == 0
+    has, t, passes, growth = list(out)
+    assert has == 1.0 and abs(t - 41.5557022) < 1e-4 and passes == 0.0 and 1e-4 < growth < 1e-3

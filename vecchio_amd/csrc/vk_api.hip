@@ -882,10 +882,16 @@ int linearize_desc(const vk_scene_desc *desc, std::shared_ptr<const LinearScene>
     std::string err;
     LinearizeOptions opt;
     opt.retree = EnvSwitches::read().retree;
-    if (const char *e = getenv("VK_GATE_GROW")) opt.gate_grow = e[0] != '0';      // (tests: see LinearizeOptions)
+    // VK_GATE_PROOF=0: among the trees the description allows, prefer the empirical form (comparisons, the constructed counter-example on
+    // the device).  It does NOT allow an unproven tree by itself: that takes VK_SCENE_EMPIRICAL_TREES in the description.
+    if (const char *e = getenv("VK_GATE_PROOF")) opt.want_proof = e[0] != '0';
+#ifdef VK_DEBUG_LIB
+    // unsound test switches (LinearizeOptions): the debug build only; the product's trees are the proven one, the handed-over one, or
+    // what the description's flags opt into
+    if (const char *e = getenv("VK_GATE_GROW")) opt.gate_grow = e[0] != '0';
     if (const char *e = getenv("VK_T_PAD")) opt.t_pad = (float)atof(e);
-    if (const char *e = getenv("VK_GATE_PROOF")) { opt.want_proof = e[0] != '0'; if (!opt.want_proof) opt.allow_empirical = true; }
     if (const char *e = getenv("VK_EMPIRICAL_TREES")) opt.allow_empirical = e[0] == '1';
+#endif
     int rc = linearize(desc, *h, err, opt);
     if (rc != VK_OK) return fail(rc, err);
     out = h;

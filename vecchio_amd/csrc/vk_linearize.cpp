@@ -623,8 +623,10 @@ struct Builder {
 
     // Exact re-treeing: the trusted origin ball and the growth of every unit's gate box (vk_linearize.h rt_unit_growth).  The ball is
     // centred on the component-wise median of the sphere centres and reaches eight times as far as the spheres of ordinary size do
-    // (a ground sphere thousands of times larger than the rest does not count towards the extent: rays start on its near side);
-    // it shrinks until every unit's far-origin check holds.
+    // (a ground sphere thousands of times larger than the rest does not count towards the extent: rays start on its near side) and,
+    // beyond that, as far as the far side of every sphere.  It is ONE radius, never shrunk: a unit whose far-origin check fails for it
+    // counts as long (a smaller ball does not help where it matters — on the 1 M-sphere stress scene a ball of 1.7e4, the largest that
+    // every compact unit passes, still leaves 71 000 of 524 000 units long by their growth alone).
     // The growth goes with the square of a unit's size, and BVHNode::new's units can be long (random axis, median split; a scene whose
     // spheres all share one coordinate wastes every split on that axis: one unit in a hundred of the 1 M-sphere stress scene is
     // longer than 100 sphere diameters).  Grown, such units would overlap everything around them.  A unit is LONG when its growth
@@ -674,8 +676,7 @@ struct Builder {
         // there to the depth limit — 0.4 % of the InOneWeekend scene's samples, 5 % of its segments, all starting up to two ground radii
         // away.  (A unit whose far-origin check fails for so large a ball counts as long.)
         dom.r0 = std::max(8.0 * ext, 1.05 * reach);
-        double long_thr = RT_LONG_GROWTH;
-        if (const char *e = getenv("VK_LONG_THR")) long_thr = atof(e);
+        const double long_thr = RT_LONG_GROWTH;
         std::vector<double> grow(objs.size());
         std::vector<char> is_long(objs.size(), 0);
         for (size_t i = 0; i < objs.size(); i++) {
@@ -761,6 +762,9 @@ struct Builder {
         if (ok && retree_units) {
             all_units = objs;
             proven = want_proof && rt_grow_units(objs);
+            // (the test switches gate_grow = false / another padding leave a tree the lemma does not cover: it is never reported as proven
+            // and, like any unproven tree, takes VK_SCENE_EMPIRICAL_TREES)
+            if (!gate_grow || gate_pad != RT_PAD) proven = false;
             if (!proven && proof_only) ok = false;      // (no VK_SCENE_EMPIRICAL_TREES: the tree as handed over rather than an unproven one)
         }
         const std::vector<RtObj> &sized = all_units.empty() ? objs : all_units;

@@ -57,13 +57,15 @@ struct LinearizeOptions {
     //      over riding along for the samples that need it (vk_trace.h segment_unsafe): results are the reference's
     //  -1  as vk_scene_desc.flags says: VK_SCENE_FAST_ACCEL -> 1, VK_SCENE_REFERENCE_TREE -> 0, else 2
     int retree = -1;
-    // test switches of exact re-treeing (environment VK_GATE_GROW=0, VK_T_PAD=x through vk_api.hip / tests/emu): the unit boxes as handed
-    // over instead of grown ones, another relative padding of the gate (0 = RT_PAD).  Neither is sound; they exist so that the
-    // counter-examples of the gate lemma can be shown to bite.
+    // test switches of exact re-treeing (environment VK_GATE_GROW=0, VK_T_PAD=x: read by tests/emu and by the DEBUG build of the library
+    // only, never by the product): the unit boxes as handed over instead of grown ones, another relative padding of the gate
+    // (0 = RT_PAD).  Neither is sound: a tree built with either is never reported as proven and takes allow_empirical.  They exist so
+    // that the counter-examples of the gate lemma can be shown to bite.
     bool gate_grow = true;
     float t_pad = 0.0f;
-    bool want_proof = true;     // VK_GATE_PROOF=0: the empirical form even where the proven one is cheap (comparisons)
-    bool allow_empirical = false;   // VK_EMPIRICAL_TREES=1: as vk_scene_desc.flags & VK_SCENE_EMPIRICAL_TREES
+    bool want_proof = true;     // VK_GATE_PROOF=0: the empirical form even where the proven one is cheap (comparisons; an unproven tree
+                                // still takes VK_SCENE_EMPIRICAL_TREES in the description)
+    bool allow_empirical = false;   // tests/emu and the debug library, VK_EMPIRICAL_TREES=1: as vk_scene_desc.flags & VK_SCENE_EMPIRICAL_TREES
 };
 
 // ---- exact re-treeing: the arithmetic behind the soundness of the rebuilt tree's gates ("Gate lemma").
