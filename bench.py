@@ -165,14 +165,15 @@ def measure_counters_live(workload, timeout_s=75):
     return got, None
 
 
-def verify_against_oracle(O, hs, cam, img, width, spp, depth, budget_samples=1.5e6):
+def verify_against_oracle(O, hs, cam, img, width, spp, depth, budget_samples=1.5e6, min_pixels=1024):
     """Compares a sparse subset of 8x8 tiles of `img` (numpy, (h, w, 3), y up) with the oracle's render of exactly
     those pixels at the same seed and the FULL spp.  Every k-th tile (k prime, so the subset wanders over the
     whole frame) such that the oracle traces about `budget_samples` samples."""
     import numpy as np
     height = img.shape[0]
     tiles = ((width + 7) // 8) * ((height + 7) // 8)
-    want_tiles = max(2, int(budget_samples / (64.0 * spp)))
+    # (at least min_pixels pixels whatever the spp: C3's 10 000 spp left the budget 128 pixels)
+    want_tiles = max(2, (min_pixels + 63) // 64, int(budget_samples / (64.0 * spp)))
     k = max(1, tiles // want_tiles)
     while k > 1 and any(k % d == 0 for d in range(2, int(k ** 0.5) + 1)):
         k += 1
@@ -432,7 +433,7 @@ def main():
                 bps_walked = bps - 32.0 * (walked["oracle_box_tests"] - walked["box_tests"])
             k_ms = float(np.mean(kernel_ms)) if kernel_ms else None
             # measured HBM traffic and instruction counts per launch: PMC counters cannot be collected from inside this
-            # process, so they come from the committed rocprofv3 passes of this same command (profiles/, tests/prof_r02.sh):
+            # process, so they come from the committed rocprofv3 passes of this same command (profiles/, tools/experiments/prof_r02.sh):
             # WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950: FETCH_SIZE counts half the bytes of wide reads -> upper bound)
             traffic, issue, prof_path = None, None, None
             t_read = t_write = scratch_share = scratch_detail = None
@@ -509,7 +510,8 @@ def main():
             res = {"value": round(value, 2), "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
                    "physical": physical, "kernel_ms": k_ms, "requeued_samples": ds.last_requeued_samples(),
                    "label": label, "integrator": "scatter" if hs.integrator else "pdf", "bvh_items": info.n_items, "tree": TREE_NAMES.get(info.tree),
-                   "scene_in_lds": bool(info.lds_bytes), "verified": verified, "roofline": roof, "cpu_baseline": cpu}
+                   "scene_in_lds": bool(info.lds_bytes), "verified": verified, "roofline": roof, "cpu_baseline": cpu,
+                   "tree_code": info.tree, "_frame": final}
         if world > 1:
             # what a driver needs to see that N ranks really ran: every rank's device, and the gathered image against ONE device's
             # render of the whole frame (bit-identical by construction: order-independent fixed-point pixel sums)
@@ -547,16 +549,39 @@ def main():
                             handed_over_tree=args.reference_tree, empirical=args.empirical_trees)
     also = []
     handed_over = None
+    frames = {}            # workload -> its frame on the tree as handed over
+    exact_mismatch = []    # a tree that claims the handed-over tree's results and does not deliver them
     if n_gpus == 1 and not args.no_also and not args.spp and not args.reference_tree and rank == 0:
         # the same workload on the tree of the description alone: the number the rebuilt tree has to be read against
         r = run_workload(args.workload, 1, 1, 0, handed_over_tree=True)
+        # ... and the frame the default has to EQUAL, bit for bit: the last timed frame of the headline against this one (exact re-treeing
+        # claims BVHNode::hit's results on the tree as handed over, accel.rs:58-83; pixel sums are order independent)
+        frames[args.workload] = r.pop("_frame")
+        same = bool(np.array_equal(main_res["_frame"].view(np.uint32), frames[args.workload].view(np.uint32)))
         handed_over = {"value": r["value"], "unit": "Msamples/s", "ms_per_step": r["ms_per_step"], "kernel_ms": r["kernel_ms"], "steps": 1, "warmup": 1,
-                       "workload": r["label"], "verified": r["verified"]}
+                       "workload": r["label"], "verified": r["verified"], "frame_bit_identical": same,
+                       "frame_bit_identical_note": "the headline's last timed frame (tree: %s) == this frame, all %d x %d x 3 floats" % (
+                           main_res["tree"], frames[args.workload].shape[1], frames[args.workload].shape[0])}
+        if not same:
+            exact_mismatch.append(f"{args.workload} default ({main_res['tree']}) differs from the tree as handed over in "
+                                  f"{int((main_res['_frame'] != frames[args.workload]).any(axis=2).sum())} pixels")
     if n_gpus == 1 and not args.no_also and args.workload == "C2" and not args.spp:
         for name, spp_o, fa, ho, emp in (("C4", 0, False, False, False), ("C3", 0, False, False, False), ("C5", 0, False, False, False),
                                          ("C5", 0, False, False, True), ("C2", 0, False, False, True), ("C2", 0, True, False, False)):
             r = run_workload(name, 1, 0, spp_o, fast_accel=fa, handed_over_tree=ho, empirical=emp)
+            frame = r.pop("_frame")
+            ident = None
+            if r["tree_code"] == 0:
+                frames.setdefault(name, frame)                # (walked as handed over: C5's default, C3, C4)
+            elif name in frames:
+                ident = bool(np.array_equal(frame.view(np.uint32), frames[name].view(np.uint32)))
+                if not ident and r["tree_code"] == 1:
+                    exact_mismatch.append(f"{r['label']} ({r['tree']}) differs from the tree as handed over")
+            del frame
             also.append({"workload": r["label"], "tree": r["tree"], "Msamples_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": 1,
+                         # rebuilt trees only: this frame == the same workload's frame on the tree as handed over (proven trees must; the
+                         # empirical form and VK_SCENE_FAST_ACCEL are measured)
+                         "frame_bit_identical_to_handed_over": ident,
                          # one step, no warm-up: `Msamples_per_s` includes the variant's first-use costs (code-object load, buffer
                          # allocation); the kernel-time rate does not and is the one comparable with the headline
                          "requeued_samples": r["requeued_samples"],
@@ -566,6 +591,7 @@ def main():
                          "issue_frac": (r["roofline"] or {}).get("issue", None) and r["roofline"]["issue"]["frac"]})
     if rank == 0:
         r = main_res
+        r.pop("_frame", None)
         mode = "one process per GPU" if not args.in_library else "one process, vk_scene_create_multi (in-library tile deal + gather)"
         out = {
             "metric": "Msamples/sec (pixels x spp)", "value": r["value"], "unit": "Msamples/s", "n_gpus": n_gpus,
@@ -588,6 +614,9 @@ def main():
         print(json.dumps(out), flush=True)
         if r["verified"] and not r["verified"].get("ok", False):
             print("bench.py: the timed framebuffer does NOT match the oracle", file=sys.stderr)
+            sys.exit(3)
+        if exact_mismatch:
+            print("bench.py: " + "; ".join(exact_mismatch), file=sys.stderr)
             sys.exit(3)
     if world > 1:
         dist.barrier()

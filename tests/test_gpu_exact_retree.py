@@ -58,6 +58,26 @@ def test_exact_retree_image_is_the_handed_over_trees(name, w, spp, in_lds, flags
     assert rq_p <= rq
 
 
+def test_the_headline_frame_at_full_size_is_the_handed_over_trees(device):
+    """BASELINE C2 exactly as bench.py renders it — 1920 x 1080 x 1024 spp, depth 50, scene seed 1, render seed 2: the default (exact
+    re-treeing, proven form) against VK_SCENE_REFERENCE_TREE, all 2.1 G samples, bit for bit (main.rs:181-198; 0.6 s of GPU)."""
+    def frame(flags):
+        hs = HostScene("random_spheres_iow", 1)
+        hs.desc.contents.flags = flags
+        cam = hs.next_camera()
+        ds = DeviceScene(hs.desc)
+        img, st = ds.render(cam, hs.params(1920, 1024, 50, seed=2))
+        info = ds.info()
+        ds.close(); hs.close()
+        return img, st, info
+    ref, st_r, info_r = frame(ffi.VK_SCENE_REFERENCE_TREE)
+    img, st, info = frame(0)
+    assert img.shape == (1080, 1920, 3) and st.samples == 1920 * 1080 * 1024 == st_r.samples
+    assert info_r.tree == ffi.VK_TREE_HANDED_OVER and info.tree == ffi.VK_TREE_REBUILT_PROVEN
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), int((img != ref).any(axis=2).sum())
+    assert st.clamped_samples == 0 and np.isfinite(img).all()
+
+
 def test_stress_scenes_are_walked_as_handed_over_by_default(device):
     ref, _, _, info_r = render("stress_spheres:30", 256, 8, ffi.VK_SCENE_REFERENCE_TREE)
     img, _, rq, info = render("stress_spheres:30", 256, 8, 0)

@@ -593,7 +593,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             __syncthreads();
         }
     }
-#ifdef VK_WAVE_TIMES          // (diagnostic builds only, tests/build_exp.sh -DVK_WAVE_TIMES: the stores cost the production kernels 1 %)
+#ifdef VK_WAVE_TIMES          // (diagnostic builds only, tools/experiments/build_exp.sh -DVK_WAVE_TIMES: the stores cost the production kernels 1 %)
     { KArgsC P = kargs_fresh(); unsigned long long *wt = KARG(P, wave_times);
       if (wt && lane == 0) wt[3u * ((blockIdx.x + (blockDim.x == 1024u ? 0u : gridDim.x)) * 16u + wave)] = wall_clock64(); }
 #endif
