@@ -254,6 +254,8 @@ def main():
                          "(opt-in; not the headline: see include/vecchio_amd.h)")
     ap.add_argument("--rgb8", action="store_true", help="N ranks: gather RGB8 slabs (Vec3::to_color fused into the pack, vec3.rs:54-61) "
                     "instead of f32 ones")
+    ap.add_argument("--rccl-gather", action="store_true", help="--in-library: set VK_SCENE_RCCL_GATHER (the library moves the tile slabs by "
+                    "grouped ncclSend / ncclRecv instead of hipMemcpyPeerAsync)")
     ap.add_argument("--in-library", action="store_true",
                     help="N GPUs from ONE process through vk_scene_create_multi (the library deals tiles, gathers on device 0) "
                          "instead of one process per GPU; run without torchrun")
@@ -329,6 +331,10 @@ def main():
             from vecchio_amd import ffi
             hs.desc.contents.flags = ffi.VK_SCENE_EMPIRICAL_TREES
             label += " [VK_SCENE_EMPIRICAL_TREES]"
+        if args.in_library and args.rccl_gather:
+            from vecchio_amd import ffi
+            hs.desc.contents.flags |= ffi.VK_SCENE_RCCL_GATHER
+            label += " [VK_SCENE_RCCL_GATHER]"
         cam = hs.next_camera()
         params = hs.params(width, spp, depth, seed=2, tile_rank=rank, tile_world=world)   # render seed 2
         height = params.height
@@ -512,6 +518,25 @@ def main():
                    "label": label, "integrator": "scatter" if hs.integrator else "pdf", "bvh_items": info.n_items, "tree": TREE_NAMES.get(info.tree),
                    "scene_in_lds": bool(info.lds_bytes), "verified": verified, "roofline": roof, "cpu_baseline": cpu,
                    "tree_code": info.tree, "_frame": final}
+        if args.in_library and rank == 0:
+            # The same self-diagnosing block for ONE process driving N devices (vk_scene_create_multi): what ran where — every share's
+            # device, PCI bus id, whether it can address devices[0] (else its slab goes through host memory), its kernel time in the last
+            # timed frame — how the slabs travelled, and the gathered frame against ONE device's render of the whole frame.
+            from vecchio_amd import ffi
+            parts = ds.parts()
+            ds1 = DeviceScene(hs.desc, device=in_lib_devices[0])
+            ref, _ = ds1.render(cam, hs.params(width, spp, depth, seed=2))
+            ds1.close()
+            same = bool(np.array_equal(final.view(np.uint32), ref.view(np.uint32)))
+            res["in_library"] = {"devices": in_lib_devices, "distinct_devices": len(set(in_lib_devices)), "parts": parts,
+                                 "gather": {ffi.VK_GATHER_NONE: "none (one device)", ffi.VK_GATHER_PEER_COPY: "hipMemcpyPeerAsync",
+                                            ffi.VK_GATHER_RCCL: "RCCL (grouped ncclSend / ncclRecv)"}.get(info.gather),
+                                 "gather_backends": {"peer_copy": True, "rccl_loadable": bool(ffi.load_device_lib().vk_gather_backends() & 2)},
+                                 "slowest_part_kernel_ms": max(p["kernel_ms"] for p in parts),
+                                 "gathered_image_equals_one_gpu_render": same}
+            print(f"bench.py: in-library, {len(parts)} parts on {len(set(in_lib_devices))} device(s), gather by {res['in_library']['gather']}, "
+                  f"gathered image bit-identical to the 1-GPU render: {same}", file=sys.stderr)
+            assert same, "the in-library multi-device image differs from the one-GPU render"
         if world > 1:
             # what a driver needs to see that N ranks really ran: every rank's device, and the gathered image against ONE device's
             # render of the whole frame (bit-identical by construction: order-independent fixed-point pixel sums)
@@ -611,6 +636,8 @@ def main():
         }
         if r.get("distributed"):
             out["distributed"] = r["distributed"]
+        if r.get("in_library"):
+            out["in_library"] = r["in_library"]
         print(json.dumps(out), flush=True)
         if r["verified"] and not r["verified"].get("ok", False):
             print("bench.py: the timed framebuffer does NOT match the oracle", file=sys.stderr)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VK_ABI_VERSION 5   /* 5: rebuilt trees by default only where their exactness is proven; VK_SCENE_EMPIRICAL_TREES; vk_scene_info.tree */
+#define VK_ABI_VERSION 6   /* 6: VK_SCENE_RCCL_GATHER, vk_scene_info.gather, vk_gather_backends; 5: rebuilt trees by default only where their exactness is proven; VK_SCENE_EMPIRICAL_TREES; vk_scene_info.tree */
 
 /* ---- status codes (reference convention is panic!/unwrap, main.rs:166,202) ---------- */
 enum {
@@ -203,8 +203,13 @@ typedef struct vk_scene_desc {
  * as here, whose own tree is random (accel.rs:99-100).  Measured: the InOneWeekend scene's full 1920x1080x1024-spp frame is
  * bit-identical with and without the flag; on the 1 M-sphere stress scene 0.19 % of the samples differ — as many as between two
  * reference-style trees over the same world (profiles/r03/tree_variation.log).  Does not match a seeded reference run sample for
- * sample. */
-enum { VK_SCENE_FAST_ACCEL = 1, VK_SCENE_REFERENCE_TREE = 2, VK_SCENE_EMPIRICAL_TREES = 4 };
+ * sample.
+ * VK_SCENE_RCCL_GATHER (ABI 6; vk_scene_create_multi only, no effect on a pixel): the tile slabs travel to devices[0] by RCCL — one
+ * communicator per device (ncclCommInitAll), one grouped ncclSend / ncclRecv pair per device and frame, on the devices' own streams —
+ * instead of hipMemcpyPeerAsync.  librccl.so is loaded when the flag is first used, never linked; if it cannot be loaded, or a device
+ * is listed twice (one communicator rank per device), the scene falls back to peer copies and says so on stderr
+ * (vk_scene_info.gather tells which). */
+enum { VK_SCENE_FAST_ACCEL = 1, VK_SCENE_REFERENCE_TREE = 2, VK_SCENE_EMPIRICAL_TREES = 4, VK_SCENE_RCCL_GATHER = 8 };
 
 /* ---- camera: the ten fields of main.rs:57-68, computed by Camera::new on the host --- */
 typedef struct vk_camera {
@@ -269,6 +274,9 @@ int vk_abi_version(void);
 int vk_device_count(void);
 /* replaces: panic!/unwrap messages (main.rs:166,202); thread-local, never NULL */
 const char *vk_last_error(void);
+/* how a multi-device scene can move its tile slabs: bit 0 = peer copies (always), bit 1 = RCCL (librccl.so loads and exports what
+ * VK_SCENE_RCCL_GATHER needs).  Touches no device.  replaces: nothing */
+int vk_gather_backends(void);
 
 /* replaces: the ownership hand-off at main.rs:168-169 (Arc::new(BVHNode::new(..)),
  * Arc::new(config.lights)): deep-copies the described graph, linearises it and uploads it
@@ -281,7 +289,8 @@ int vk_scene_create(const vk_scene_desc *desc, int device, vk_scene **out);
 /* same, uploaded to EVERY device in devices[0..n_devices) ("uploads to every participating
  * GPU").  vk_render / vk_render_device on such a scene deal this call's 8x8 tiles round-robin over the
  * devices, render each share on that device's own stream, move the tile slabs to devices[0] with peer
- * copies over xGMI (one message per device: the path's only exchange), de-interleave them
+ * copies over xGMI — or, with VK_SCENE_RCCL_GATHER, with RCCL send / receive pairs — (one message per device: the path's only
+ * exchange), de-interleave them
  * on devices[0] and, for vk_render, do ONE device-to-host copy.  The image is bit-identical to the
  * one-device image.  A device may be listed more than once (shares run concurrently on it).       */
 int vk_scene_create_multi(const vk_scene_desc *desc, const int *devices, int n_devices, vk_scene **out);
@@ -339,7 +348,9 @@ typedef struct vk_scene_info {
      * of its samples to the tree as handed over anyway, or more than the queues between the two launches hold, pauses the rebuilt tree
      * for 32 frames, twice as long at every relapse; 0 = in use.  As of the last frame whose end the library has seen. */
     uint32_t tree_suspended_frames;
+    uint32_t gather;           /* VK_GATHER_*: how a multi-device scene moves its tile slabs to devices[0] (ABI 6) */
 } vk_scene_info;
+enum { VK_GATHER_NONE = 0 /* one device */, VK_GATHER_PEER_COPY = 1 /* hipMemcpyPeerAsync over xGMI */, VK_GATHER_RCCL = 2 };
 enum {
     VK_TREE_HANDED_OVER = 0,        /* the tree of the description, item for item */
     VK_TREE_REBUILT_PROVEN = 1,     /* exact re-treeing with grown gates: results proven to be the handed-over tree's */
@@ -347,6 +358,20 @@ enum {
     VK_TREE_REBUILT_FAST = 3        /* VK_SCENE_FAST_ACCEL */
 };
 int vk_scene_get_info(const vk_scene *scene, vk_scene_info *out);
+
+/* One part of a scene — a multi-device scene has one per entry of devices[], an ordinary scene one — for a host that wants to SAY what
+ * ran where (bench.py --in-library): the device's index, name and PCI bus id, whether it can address devices[0]'s memory (if not, its
+ * tile slab travels through host memory), and the HIP-event time of the part's launches in the last frame (waits for them; -1 before
+ * the first frame).  replaces: nothing (ABI 6) */
+typedef struct vk_part_info {
+    uint32_t n_parts;
+    int32_t device;
+    char name[64];
+    char pci_bus_id[32];
+    uint32_t can_access_landing_device;
+    double kernel_ms;
+} vk_part_info;
+int vk_scene_part_info(vk_scene *scene, int part, vk_part_info *out);
 
 /* HIP-event time (ms) of the launches enqueued by the last vk_render / vk_render_device on
  * this scene, on the stream they were launched on; waits for their end event.  (For a

@@ -13,14 +13,17 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
-def built():
+def built(request):
     """Build (if stale) every native library; hipcc cross-compiles gfx950 without a GPU."""
     from vecchio_amd import build
     build.build_host()
     build.build_oracle()
     build.build_emu()
     build.build_device()
-    build.build_device_debug()
+    # the debug library (instrumented kernels, arithmetic probe) only serves -m gpu tests: a CPU-only run does not compile the device
+    # sources a second time (ffi.load_debug_lib builds it on first use anyway)
+    if "not gpu" not in (request.config.getoption("-m") or ""):
+        build.build_device_debug()
     return True
 
 

@@ -50,7 +50,7 @@ def test_struct_layout_matches_header(built, tmp_path):
              "vk_list": ffi.List, "vk_medium": ffi.Medium, "vk_translate": ffi.Translate, "vk_rotate": ffi.Rotate,
              "vk_material": ffi.Material, "vk_texture": ffi.Texture, "vk_image": ffi.Image, "vk_perlin": ffi.Perlin,
              "vk_scene_desc": ffi.SceneDesc, "vk_camera": ffi.Camera, "vk_render_params": ffi.RenderParams,
-             "vk_stats": ffi.Stats, "vk_scene_info": ffi.SceneInfo}
+             "vk_stats": ffi.Stats, "vk_scene_info": ffi.SceneInfo, "vk_part_info": ffi.PartInfo}
     src = tmp_path / "sz.c"
     body = "\n".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names)
     src.write_text(f'#include <stdio.h>\n#include "{HEADER}"\nint main(){{ {body} return 0; }}\n')
@@ -61,6 +61,18 @@ def test_struct_layout_matches_header(built, tmp_path):
     for n, T in names.items():
         assert C.sizeof(T) == sizes[n], f"{n}: ctypes {C.sizeof(T)} vs C {sizes[n]}"
     assert sizes["vk_bvh_node"] == 32      # the canonical 32-byte node record
+
+
+def test_rccl_gather_backend_resolves_without_being_linked(built):
+    """VK_SCENE_RCCL_GATHER (ABI 6): the in-library gather of a multi-device scene as grouped ncclSend / ncclRecv (north_star: "RCCL over
+    xGMI only for the final framebuffer gather").  librccl.so is loaded on request — the product library must not depend on it — and
+    every entry point the code path calls must resolve (the compile-and-link check of a path no one-GPU box can run)."""
+    import subprocess
+    lib = ffi.load_device_lib()
+    assert lib.vk_gather_backends() & 1
+    assert lib.vk_gather_backends() & 2, "librccl.so (or one of ncclCommInitAll/ncclSend/ncclRecv/...) does not resolve on this image"
+    needed = subprocess.run(["ldd", ffi.device_lib_path()], capture_output=True, text=True).stdout
+    assert "rccl" not in needed and "nccl" not in needed, needed
 
 
 def test_no_cpu_fallback(built):

@@ -103,3 +103,46 @@ def test_the_final_scenes_cluster_is_entered_once(oracle, emu, host_scenes):
     compare(ps_o, ps_e, img_o, img_e)
     assert info[2] == 1, info
     assert steps / ps_e.shape[0] < 195.0, steps / ps_e.shape[0]
+
+
+@pytest.mark.parametrize("under_chain", [False, True])
+def test_a_len1_node_over_coplanar_rects_is_entered_twice(under_chain, oracle, emu, built):
+    """ADVICE r4: the "second call returns None" argument is Sphere::hit's strict `t < tmax` (hittable.rs:75).  Rect::hit accepts
+    t == tmax (hittable.rs:232), so over a BVHNode of Rects the second call of a len-1 node does return hits — of whichever of several
+    coplanar Rects its boxes still let through at tmax = t0 — and the lineariser must not drop it: a subtree that is not spheres only is
+    emitted (or, under a Translate / Rotate chain, entered) twice, and every sample is the oracle's, which makes both calls."""
+    r = np.random.default_rng(5)
+    d = Desc()
+    mats = [d.light(*c) for c in ((1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (0, 1, 1), (1, 0, 1))]
+
+    def tree(objs):
+        if len(objs) == 1:
+            return objs[0]
+        k = len(objs) // 2
+        (l, lb), (rr, rb) = tree(objs[:k]), tree(objs[k:])
+        lo, hi = np.minimum(lb[0], rb[0]), np.maximum(lb[1], rb[1])
+        return d.bvh_node(l, rr, tuple(lo.astype(np.float32)), tuple(hi.astype(np.float32))), (lo, hi)
+
+    rects = []
+    for i in range(12):                                     # overlapping quads in ONE plane (y = 1), six materials: every overlap is a tie
+        x0, z0 = r.uniform(-2, 1, 2)
+        w, h = r.uniform(0.8, 2.0, 2)
+        ref = d.xz_rect(float(x0), float(x0 + w), float(z0), float(z0 + h), 1.0, mats[i % 6])
+        rects.append((ref, (np.array([x0, 1.0 - 1e-4, z0]), np.array([x0 + w, 1.0 + 1e-4, z0 + h]))))
+    sub, bb = tree(rects)
+    lo, hi = bb
+    if under_chain:
+        sub = d.translate(sub, (0.5, 0.0, 0.25)); lo, hi = lo + [0.5, 0, 0.25], hi + [0.5, 0, 0.25]
+    dup = d.bvh_node(sub, sub, tuple(lo.astype(np.float32)), tuple(hi.astype(np.float32)))
+    floor = d.xz_rect(-5.0, 5.0, -5.0, 5.0, 3.0, d.lambertian(0.5, 0.5, 0.5))
+    world = d.bvh_node(dup, floor, (-6.0, 0.0, -6.0), (6.0, 4.0, 6.0))
+    desc = d.finish(world, [rects[0][0]])
+    cam = camera((0.0, -4.0, 0.3), (0, 1, 0), vfov=50.0)
+    p = params(48, 36, 6, max_depth=4, seed=3, integrator=ffi.VK_INTEGRATOR_SCATTER, background=ffi.VK_BACKGROUND_SKY)
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    img_e, ps_e, steps, info = emu.render_samples(desc, cam, p)
+    compare(ps_o, ps_e, img_o, img_e)
+    if under_chain:
+        assert info[2] == 2, info                            # two instance records: the chain is entered twice
+    else:
+        assert info[1] == 2 * 12 + 1, info                   # primitive slots: the 12 Rects twice + the floor

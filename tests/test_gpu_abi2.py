@@ -86,6 +86,40 @@ def test_multi_device_scene_is_bit_identical(name, w, spp, device, host_scenes):
     single.close()
 
 
+def test_rccl_gather_flag(device, host_scenes, capfd):
+    """VK_SCENE_RCCL_GATHER on the one-GPU box: over ONE device the communicator initialises (ncclCommInitAll of one rank) and the frame is
+    the one-device frame; a device listed twice cannot be two communicator ranks: the scene says so and moves its slabs by peer copies.
+    (Slabs really travelling by ncclSend / ncclRecv takes two physical devices: the driver's multi-GPU run.)"""
+    hs, cam = host_scenes("cornell_box")
+    p = hs.params(96, 32, 50)
+    single = DeviceScene(hs.desc)
+    want, _ = single.render(cam, p)
+    assert single.info().gather == ffi.VK_GATHER_NONE
+    single.close()
+    old = hs.desc.contents.flags
+    try:
+        hs.desc.contents.flags = old | ffi.VK_SCENE_RCCL_GATHER
+        one = DeviceScene(hs.desc, devices=[0])
+        assert one.info().gather == ffi.VK_GATHER_RCCL
+        got, _ = one.render(cam, p)
+        assert np.array_equal(got, want)
+        got, _ = one.render(cam, p)
+        assert np.array_equal(got, want)
+        one.close()
+        capfd.readouterr()
+        two = DeviceScene(hs.desc, devices=[0, 0])
+        assert two.info().gather == ffi.VK_GATHER_PEER_COPY
+        assert "listed more than once" in capfd.readouterr().err
+        got, _ = two.render(cam, p)
+        assert np.array_equal(got, want)
+        two.close()
+    finally:
+        hs.desc.contents.flags = old
+    plain = DeviceScene(hs.desc, devices=[0, 0])
+    assert plain.info().gather == ffi.VK_GATHER_PEER_COPY
+    plain.close()
+
+
 def test_multi_device_render_device_and_errors(device, host_scenes):
     import torch
     hs, cam = host_scenes("cornell_box")

@@ -141,6 +141,32 @@ def test_scene_with_mostly_early_winners_suspends_the_rebuilt_tree(device):
     assert "renders on the tree as handed over for the next 32 frames" in r.stderr and "next 64 frames" in r.stderr, r.stderr
 
 
+def test_a_pipelined_caller_that_never_polls_still_gets_the_rebuilt_tree_suspended(device):
+    """vk_render_device frames enqueued back to back on one stream, frame N + 1 always before frame N has finished, and nothing
+    ever asked of the library in between.  The verdict on a frame must not depend on the MOST RECENT frame having finished: the scene of the
+    test above (mostly unsafe winners) has to be suspended after a few frames all the same, and every frame is the handed-over tree's."""
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
+            "import numpy as np, torch\n"
+            "from vecchio_amd import DeviceScene, HostScene, ffi\n"
+            "hs = HostScene('stress_spheres:12', 1); cam = hs.next_camera(); p = hs.params(512, 64, 50, seed=4)\n"
+            "hs.desc.contents.flags = ffi.VK_SCENE_REFERENCE_TREE; r = DeviceScene(hs.desc); ref = r.render(cam, p)[0]; r.close()\n"
+            "hs.desc.contents.flags = ffi.VK_SCENE_EMPIRICAL_TREES; ds = DeviceScene(hs.desc)\n"
+            "st = torch.cuda.Stream(); n = 12\n"
+            "fbs = [torch.zeros((p.height, p.width, 3), dtype=torch.float32, device='cuda') for _ in range(n)]\n"
+            "torch.cuda.synchronize(); evs = []\n"
+            "for k in range(n):\n"
+            "    if k >= 2: evs[k - 2].synchronize()\n"              # a pipeline two frames deep: frame k - 1 is still in flight here
+            "    ds.render_device(cam, p, fbs[k].data_ptr(), st.cuda_stream)\n"
+            "    e = torch.cuda.Event(); e.record(st); evs.append(e)\n"
+            "susp = ds.info().tree_suspended_frames\n"
+            "st.synchronize()\n"
+            "print('EQUAL', all(np.array_equal(f.cpu().numpy().view(np.uint32), ref.view(np.uint32)) for f in fbs), 'SUSPENDED', susp)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "EQUAL True" in r.stdout, r.stdout + r.stderr
+    assert int(r.stdout.split()[-1]) >= 16, r.stdout + r.stderr        # suspended while the caller was still enqueueing: never polled
+    assert "renders on the tree as handed over for the next 32 frames" in r.stderr, r.stderr
+
+
 def test_the_constructed_counter_example_on_the_device(device, oracle, monkeypatch):
     """tests/test_gate_lemma.py part C through the C ABI: 4096 primary rays around a ray that grazes a sphere where it touches its
     (long) unit's box.  Default (a world with a long unit is not rebuilt) and VK_SCENE_REFERENCE_TREE: the oracle's samples.  The

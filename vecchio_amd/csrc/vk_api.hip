@@ -32,6 +32,8 @@
 // device or returns an error.
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // declarations only: librccl.so is loaded on request (VK_SCENE_RCCL_GATHER), never linked
 
 #include <algorithm>
 #include <chrono>
@@ -58,6 +60,44 @@ int fail(int code, const std::string &m) { g_err = m; return code; }
     do {                                                                                               \
         hipError_t _e = (expr);                                                                        \
         if (_e != hipSuccess) return fail(VK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// ---- RCCL, loaded on first use (VK_SCENE_RCCL_GATHER: the in-library gather of a multi-device scene as grouped ncclSend / ncclRecv).
+// Not linked: a single-device host never maps librccl.so.
+struct RcclApi {
+    void *handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string why;
+    bool ok() const { return handle && CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString; }
+};
+const RcclApi &rccl_api() {
+    static const RcclApi api = [] {
+        RcclApi a;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            a.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (a.handle) break;
+        }
+        if (!a.handle) { const char *e = dlerror(); a.why = std::string("librccl.so could not be loaded: ") + (e ? e : "?"); return a; }
+#define VK_RCCL_SYM(field, sym) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.handle, #sym))
+        VK_RCCL_SYM(CommInitAll, ncclCommInitAll); VK_RCCL_SYM(CommDestroy, ncclCommDestroy); VK_RCCL_SYM(GroupStart, ncclGroupStart);
+        VK_RCCL_SYM(GroupEnd, ncclGroupEnd); VK_RCCL_SYM(Send, ncclSend); VK_RCCL_SYM(Recv, ncclRecv);
+        VK_RCCL_SYM(GetErrorString, ncclGetErrorString);
+#undef VK_RCCL_SYM
+        if (!a.ok()) a.why = "librccl.so lacks one of ncclCommInitAll / ncclCommDestroy / ncclGroupStart / ncclGroupEnd / ncclSend / ncclRecv";
+        return a;
+    }();
+    return api;
+}
+#define RCCL_TRY(expr)                                                                                                              \
+    do {                                                                                                                            \
+        ncclResult_t _r = (expr);                                                                                                   \
+        if (_r != ncclSuccess) return fail(VK_ERR_HIP, std::string(#expr) + ": " + rccl_api().GetErrorString(_r));                  \
     } while (0)
 
 // nothing may unwind across the C boundary: every entry point that can allocate runs through this
@@ -165,8 +205,15 @@ struct vk_scene {
     // from `plan_host` (pinned; copied behind the frame's last kernel) when the NEXT frame is enqueued, without waiting, or where the
     // caller synchronises anyway (vk_scene_last_requeued_samples).
     uint64_t frame_no = 0, exact_resume = 0, exact_pause = 32;
-    uint32_t *plan_host = nullptr;     // [4] the last frame's redo_plan
-    bool plan_pending = false;         // a frame with a second launch has been enqueued and its plan not judged yet
+    // Two verdict slots, used in turn: [4] words of a frame's redo_plan each, an event recorded right behind the copy, the samples of the
+    // partition the frame covered.  A caller that always enqueues frame N + 1 before frame N has finished (vk_render_device in a
+    // pipeline) still has frame N - 1's verdict taken when it enqueues frame N + 1: the verdict does not wait for the MOST RECENT frame.
+    uint32_t *plan_host = nullptr;     // [2][4]
+    hipEvent_t ev_plan[2] = {nullptr, nullptr};
+    bool plan_pending[2] = {false, false};      // a frame with a second launch has been enqueued and its plan not judged yet
+    uint64_t plan_samples[2] = {0, 0};
+    int plan_last = 0;                 // the slot of the last frame with a second launch
+    bool plan_copied = false;          // ... whose plan did travel to that slot
     uint64_t redo_last_samples = 0;    // samples of the partition the last render covered
     unsigned long long *phase_stats = nullptr;   // device, 16 counters (diagnostic kernel build)
     bool want_phase_stats = false;
@@ -190,6 +237,8 @@ struct vk_scene {
     uint8_t *landing = nullptr; size_t landing_bytes = 0; int landing_device = 0;
     hipEvent_t ev_landed = nullptr;
     hipEvent_t ev_begin = nullptr;               // group: recorded on the caller's stream at the start of a frame
+    // group, VK_SCENE_RCCL_GATHER: one communicator per part (rank j = devices[j]); empty = peer copies
+    std::vector<ncclComm_t> comms;
 };
 
 namespace {
@@ -416,16 +465,17 @@ uint32_t choose_chunks(const vk_scene *s, const vk_render_params *p) {
     return n;
 }
 
-// The verdict on the last frame with a second launch (its plan has arrived in plan_host): see vk_scene::exact_resume.
-void judge_last_frame(vk_scene *s) {
-    s->plan_pending = false;
-    const uint32_t requeued = s->plan_host[1], lost = s->plan_host[2];
-    const bool heavy = (uint64_t)requeued * 4u > s->redo_last_samples && s->redo_last_samples >= (1u << 20);
+// The verdict on a frame with a second launch (its plan has arrived in slot b of plan_host): see vk_scene::exact_resume.
+void judge_frame(vk_scene *s, int b) {
+    s->plan_pending[b] = false;
+    const uint32_t requeued = s->plan_host[4 * b + 1], lost = s->plan_host[4 * b + 2];
+    const uint64_t frame_samples = s->plan_samples[b];
+    const bool heavy = (uint64_t)requeued * 4u > frame_samples && frame_samples >= (1u << 20);
     if (lost != 0u || heavy) {
         s->exact_resume = s->frame_no + s->exact_pause;
         fprintf(stderr, "vecchio_amd: exact re-treeing %s (%u of %llu samples requeued, %u did not fit); this scene renders on the tree as "
             "handed over for the next %llu frames\n", lost ? "overflowed its queues and the frame was rendered again" : "sent over a quarter of "
-            "a frame through the second launch", requeued, (unsigned long long)s->redo_last_samples, lost, (unsigned long long)s->exact_pause);
+            "a frame through the second launch", requeued, (unsigned long long)frame_samples, lost, (unsigned long long)s->exact_pause);
         s->exact_pause = std::min<uint64_t>(s->exact_pause * 2u, 4096u);
     } else if (s->exact_pause > 32u) {
         s->exact_pause /= 2u;           // a clean frame on the rebuilt tree: relapses are forgiven step by step
@@ -440,8 +490,12 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     KArgs A;
     memset(&A, 0, sizeof(A));
     A.S = s->dev;
-    // the last frame's verdict, if it has finished (never waits)
-    if (s->plan_pending && hipEventQuery(s->ev1) == hipSuccess) judge_last_frame(s);
+    // the verdicts that have arrived (never waits): the older slot first
+    for (int k = 1; k <= 2; k++) {
+        const int b = (s->plan_last + k) & 1;
+        if (s->plan_pending[b] && hipEventQuery(s->ev_plan[b]) == hipSuccess) judge_frame(s, b);
+    }
+    (void)hipGetLastError();      // (hipErrorNotReady of a query is not an error of this call)
     s->frame_no++;
     bool exact = s->exact && !s->want_phase_stats && s->frame_no >= s->exact_resume;     // (the diagnostic builds have no second launch)
     A.C.cam = *cam;
@@ -664,8 +718,16 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         Fb.shade_defer = SHADE_DEFER; Fb.prim_weight = B.prim_weight;
         rc = launch_by_features(s, F, Fb, lds, dim3(grid), shmem, st, false);
         if (rc != VK_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(s->plan_host, plan, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        s->redo_last = true; s->plan_pending = true;
+        // the plan travels to the slot the previous frame did not use — unless that slot's verdict is still in flight (two frames behind and
+        // not finished: the caller runs far ahead), then this frame goes unjudged rather than overwriting it
+        const int b = s->plan_last ^ 1;
+        s->redo_last = true;
+        if (!s->plan_pending[b]) {
+            HIP_TRY(hipMemcpyAsync(s->plan_host + 4 * b, plan, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(s->ev_plan[b], st));
+            s->plan_pending[b] = true; s->plan_samples[b] = s->redo_last_samples; s->plan_last = b;
+            s->plan_copied = true;
+        } else s->plan_copied = false;
     }
     {
         uint32_t blocks = (uint32_t)((n_pixels + 255) / 256);
@@ -703,6 +765,7 @@ int enqueue_render_multi(vk_scene *grp, const vk_camera *cam, const vk_render_pa
     HIP_TRY(hipEventRecord(grp->ev_begin, st0));      // the parts start after whatever the caller's stream held before this frame
     uint64_t samples = 0; uint32_t launches = 0;
     std::vector<TileGeom> geoms;
+    std::vector<size_t> slab_size;
     for (uint32_t j = 0; j < n; j++) {
         vk_scene *q = grp->parts[j];
         vk_render_params pj = *p;
@@ -729,17 +792,43 @@ int enqueue_render_multi(vk_scene *grp, const vk_camera *cam, const vk_render_pa
             if (rc != VK_OK) return rc;
             HIP_TRY(hipSetDevice(q->device));
         }
-        if (bytes) HIP_TRY(hipMemcpyPeerAsync(q->landing, grp->device, q->slab, q->device, bytes, q->stream));
-        HIP_TRY(hipEventRecord(q->ev_landed, q->stream));
+        slab_size.push_back(bytes);
+        if (grp->comms.empty()) {
+            if (bytes) HIP_TRY(hipMemcpyPeerAsync(q->landing, grp->device, q->slab, q->device, bytes, q->stream));
+            HIP_TRY(hipEventRecord(q->ev_landed, q->stream));
+        }
+    }
+    if (!grp->comms.empty()) {
+        // The same exchange as ONE RCCL group: part j sends its slab on its own stream (behind its render and pack), devices[0] receives
+        // the slabs on the group's receive stream, which waits for nothing but the start of the frame (the previous frame's unpack
+        // kernels have read the landing buffers by then) — so the transfers overlap devices[0]'s own render.  ncclSend / ncclRecv pairs
+        // inside one ncclGroupStart / ncclGroupEnd progress together; the receives complete in that stream's order, so ONE event says
+        // that every slab has landed.  Part 0's slab is on devices[0] already and is unpacked where it lies.
+        const RcclApi &R = rccl_api();
+        vk_scene *q0 = grp->parts[0];
+        HIP_TRY(hipSetDevice(q0->device));
+        HIP_TRY(hipEventRecord(q0->ev_landed, q0->stream));
+        HIP_TRY(hipStreamWaitEvent(grp->stream, grp->ev_begin, 0));
+        RCCL_TRY(R.GroupStart());
+        for (uint32_t j = 1; j < n; j++) {
+            vk_scene *q = grp->parts[j];
+            if (!slab_size[j]) continue;
+            RCCL_TRY(R.Send(q->slab, slab_size[j], ncclUint8, 0, grp->comms[j], q->stream));
+            RCCL_TRY(R.Recv(q->landing, slab_size[j], ncclUint8, (int)j, grp->comms[0], grp->stream));
+        }
+        RCCL_TRY(R.GroupEnd());
+        HIP_TRY(hipSetDevice(grp->device));
+        HIP_TRY(hipEventRecord(grp->ev_landed, grp->stream));
     }
     HIP_TRY(hipSetDevice(grp->device));
     for (uint32_t j = 0; j < n; j++) {
         vk_scene *q = grp->parts[j];
         vk_render_params pj = *p;
         pj.tile_rank = geoms[j].rank; pj.tile_world = geoms[j].world;
-        HIP_TRY(hipStreamWaitEvent(st0, q->ev_landed, 0));
-        int rc = u8 ? tile_move<TM_UNPACK_U8>(q->landing, d_out, &pj, geoms[j], st0) : tile_move<TM_UNPACK_F32>(q->landing, d_out, &pj,
-            geoms[j], st0);
+        const bool rccl = !grp->comms.empty();
+        HIP_TRY(hipStreamWaitEvent(st0, (rccl && j != 0u ? grp : q)->ev_landed, 0));
+        const void *from = rccl && j == 0u ? q->slab : q->landing;
+        int rc = u8 ? tile_move<TM_UNPACK_U8>(from, d_out, &pj, geoms[j], st0) : tile_move<TM_UNPACK_F32>(from, d_out, &pj, geoms[j], st0);
         if (rc != VK_OK) return rc;
     }
     grp->last_timed = true;
@@ -763,6 +852,7 @@ int enqueue_render(vk_scene *s, const vk_camera *cam, const vk_render_params *p,
 
 void destroy_one(vk_scene *s) {
     if (!s) return;
+    for (ncclComm_t c : s->comms) if (c) (void)rccl_api().CommDestroy(c);
     for (vk_scene *q : s->parts) destroy_one(q);
     (void)hipSetDevice(s->device);
     for (void *p : s->allocs) (void)hipFree(p);
@@ -772,7 +862,7 @@ void destroy_one(vk_scene *s) {
         if (p) (void)hipFree(p);
     if (s->plan_host) (void)hipHostFree(s->plan_host);
     if (s->landing) { (void)hipSetDevice(s->landing_device); (void)hipFree(s->landing); (void)hipSetDevice(s->device); }
-    for (hipEvent_t e : {s->ev0, s->ev1, s->ev_landed, s->ev_begin, s->ev_fork, s->ev_join})
+    for (hipEvent_t e : {s->ev0, s->ev1, s->ev_landed, s->ev_begin, s->ev_fork, s->ev_join, s->ev_plan[0], s->ev_plan[1]})
         if (e) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     if (s->stream2) (void)hipStreamDestroy(s->stream2);
@@ -865,8 +955,10 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
         s->ref_view.ref_items = nullptr; s->ref_view.n_ref_items = 0; s->ref_view.t_pad = 0.0f; s->ref_view.gate_scale = 1.0f;
         s->ref_view.tmin_gate = T_MIN; s->ref_view.tie_rank = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->redo_count), (REDO_REGIONS * REDO_COUNT_STRIDE + 16) * sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->plan_host), 4 * sizeof(uint32_t), hipHostMallocDefault));
-        memset(s->plan_host, 0, 4 * sizeof(uint32_t));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->plan_host), 8 * sizeof(uint32_t), hipHostMallocDefault));
+        memset(s->plan_host, 0, 8 * sizeof(uint32_t));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_plan[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->ev_plan[1], hipEventDisableTiming));
     }
     if (s->dual_launch) {
         HIP_TRY(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
@@ -916,6 +1008,8 @@ int vk_device_count(void) {
 }
 
 const char *vk_last_error(void) { return g_err.c_str(); }
+
+int vk_gather_backends(void) { return 1 | (rccl_api().ok() ? 2 : 0); }
 
 int vk_scene_create(const vk_scene_desc *desc, int device, vk_scene **out) {
     if (!out) return fail(VK_ERR_BAD_ARG, "null out pointer");
@@ -971,6 +1065,30 @@ int vk_scene_create_multi(const vk_scene_desc *desc, const int *devices, int n_d
             }
             grp->parts.push_back(part.release());
         }
+        const bool want_rccl = (desc->flags & VK_SCENE_RCCL_GATHER) != 0u || (getenv("VK_MULTI_GATHER") && !strcmp(getenv("VK_MULTI_GATHER"), "rccl"));
+        if (want_rccl) {
+            // one communicator rank per DEVICE: a device listed twice (the one-GPU test shape) cannot take part
+            bool distinct = true;
+            for (int a = 0; a < n_devices; a++) for (int b = a + 1; b < n_devices; b++) distinct = distinct && devices[a] != devices[b];
+            const RcclApi &R = rccl_api();
+            if (!R.ok()) fprintf(stderr, "vecchio_amd: VK_SCENE_RCCL_GATHER: %s; the tile slabs travel by peer copies\n", R.why.c_str());
+            else if (!distinct) fprintf(stderr, "vecchio_amd: VK_SCENE_RCCL_GATHER: a device is listed more than once (one communicator rank per "
+                "device); the tile slabs travel by peer copies\n");
+            else {
+                grp->comms.assign((size_t)n_devices, nullptr);
+                ncclResult_t r = R.CommInitAll(grp->comms.data(), n_devices, devices);
+                if (r != ncclSuccess) {
+                    fprintf(stderr, "vecchio_amd: ncclCommInitAll over %d devices failed (%s); the tile slabs travel by peer copies\n", n_devices,
+                        R.GetErrorString(r));
+                    grp->comms.clear();
+                }
+            }
+            if (!grp->comms.empty()) {       // the receive stream of devices[0] and the event behind the frame's last receive
+                HIP_TRY(hipSetDevice(devices[0]));
+                HIP_TRY(hipStreamCreateWithFlags(&grp->stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&grp->ev_landed, hipEventDisableTiming));
+            }
+        }
         HIP_TRY(hipSetDevice(devices[0]));
         HIP_TRY(hipEventCreateWithFlags(&grp->ev_begin, hipEventDisableTiming));
         grp->lds_bytes = grp->parts[0]->lds_bytes; grp->hot_bytes = grp->parts[0]->hot_bytes;
@@ -998,6 +1116,7 @@ int vk_scene_get_info(const vk_scene *s, vk_scene_info *out) {
     out->features = pick_variant(one);
     out->tree = !H.ref_items.empty() ? (H.proven ? VK_TREE_REBUILT_PROVEN : VK_TREE_REBUILT_EMPIRICAL)
                                      : (!H.tie_rank.empty() ? VK_TREE_REBUILT_FAST : VK_TREE_HANDED_OVER);
+    out->gather = s->parts.empty() ? VK_GATHER_NONE : (s->comms.empty() ? VK_GATHER_PEER_COPY : VK_GATHER_RCCL);
     out->tree_suspended_frames = 0;
     for (const vk_scene *q : (s->parts.empty() ? std::vector<vk_scene *>{const_cast<vk_scene *>(s)} : s->parts))
         if (q->exact_resume > q->frame_no + 1u) out->tree_suspended_frames = std::max<uint32_t>(out->tree_suspended_frames,
@@ -1014,6 +1133,32 @@ int vk_render_device(vk_scene *scene, const vk_camera *cam, const vk_render_para
 
 // HIP-event time (ms) of the launches enqueued by the last vk_render_device / vk_render on
 // this scene; synchronises on their end event.  Multi-device: the slowest part.
+int vk_scene_part_info(vk_scene *s, int part, vk_part_info *out) {
+    if (!s || !out) return fail(VK_ERR_BAD_ARG, "null argument");
+    const int n = s->parts.empty() ? 1 : (int)s->parts.size();
+    if (part < 0 || part >= n) return fail(VK_ERR_BAD_ARG, "part index out of range");
+    vk_scene *q = s->parts.empty() ? s : s->parts[(size_t)part];
+    memset(out, 0, sizeof(*out));
+    out->n_parts = (uint32_t)n;
+    out->device = q->device;
+    hipDeviceProp_t pr;
+    HIP_TRY(hipGetDeviceProperties(&pr, q->device));
+    snprintf(out->name, sizeof(out->name), "%s", pr.name);
+    if (hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof(out->pci_bus_id), q->device) != hipSuccess) { (void)hipGetLastError(); out->pci_bus_id[0] = 0; }
+    const int landing = s->parts.empty() ? q->device : s->device;
+    int can = 1;
+    if (q->device != landing) HIP_TRY(hipDeviceCanAccessPeer(&can, q->device, landing));
+    out->can_access_landing_device = (uint32_t)can;
+    out->kernel_ms = -1.0;
+    if (q->last_timed) {
+        double ms = 0.0;
+        int rc = vk_scene_last_kernel_ms(q, &ms);
+        if (rc != VK_OK) return rc;
+        out->kernel_ms = ms;
+    }
+    return VK_OK;
+}
+
 int vk_scene_last_kernel_ms(vk_scene *s, double *ms_out) {
     if (!s || !ms_out) return fail(VK_ERR_BAD_ARG, "null argument");
     if (!s->last_timed) return fail(VK_ERR_BAD_ARG, "no render enqueued yet");
@@ -1109,8 +1254,19 @@ int vk_scene_last_requeued_samples(vk_scene *s, uint64_t *out) {
     if (!s->redo_last) return VK_OK;
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipEventSynchronize(s->ev1));
-    *out = s->plan_host[2] != 0u ? s->redo_last_samples : s->plan_host[1];
-    if (s->plan_pending) judge_last_frame(s);
+    if (!s->plan_copied) {      // (the caller ran more than two frames ahead: this frame's plan was not copied; read it now)
+        uint32_t plan[4];
+        HIP_TRY(hipMemcpy(plan, s->redo_count + REDO_REGIONS * REDO_COUNT_STRIDE, sizeof(plan), hipMemcpyDeviceToHost));
+        *out = plan[2] != 0u ? s->redo_last_samples : plan[1];
+        return VK_OK;
+    }
+    const int b = s->plan_last;
+    *out = s->plan_host[4 * b + 2] != 0u ? s->redo_last_samples : s->plan_host[4 * b + 1];
+    for (int k = 1; k <= 2; k++) {
+        const int c = (b + k) & 1;
+        if (s->plan_pending[c] && hipEventQuery(s->ev_plan[c]) == hipSuccess) judge_frame(s, c);
+    }
+    (void)hipGetLastError();
     return VK_OK;
 }
 

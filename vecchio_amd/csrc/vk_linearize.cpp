@@ -319,11 +319,42 @@ struct Builder {
     }
 
     // A `len == 1` node (accel.rs:108-111: both children the same Arc) calls its object twice, the second time with tmax = the first
-    // call's hit.  For an object in which nothing draws the second call returns None: every box it passes it passed in the first call
-    // (AxisBB::hit is monotone in tmax, and the second call's tmax is the first call's final one), so every sphere it tests was tested
-    // then with a larger tmax, and a root below the final t would have been accepted.  That holds under a Translate / Rotate chain as
-    // well (hittable.rs:507-524,578-624 pass tmin and tmax through): an instance whose child holds no ConstantMedium is entered once.
-    // (The final scene's 1 000-sphere cluster sits in such a node: 213 -> 173 steps per sample, C3 +26 %.)
+    // call's hit.  When is the second call unobservable?
+    //  * ONE object in which nothing draws (Sphere, Rect, list, Boxy; also under a Translate / Rotate chain, which passes tmin and tmax
+    //    through, hittable.rs:507-524,578-624): the second call returns None (Sphere::hit and the list scan are strict in tmax,
+    //    hittable.rs:75,386) or the SAME object at the same t (Rect::hit accepts t == tmax, hittable.rs:232): the node's result is the
+    //    first call's either way.
+    //  * a BVHNode (directly or under such a chain) over SPHERES only: every box the second call passes it passed in the first call
+    //    (AxisBB::hit is monotone in tmax, and the second call's tmax is the first call's final one), so every sphere it tests was tested
+    //    then with a larger tmax, and a root below the final t would have been accepted: None.
+    //    (The final scene's 1 000-sphere cluster sits in such a node: 213 -> 173 steps per sample, C3 +17 %.)
+    //  * a BVHNode over Rects, lists or Boxys is NOT covered: two coplanar Rects tie at t0, the first call ends with the later one, and
+    //    the second call — whose boxes are tested against tmax = t0 — can lose exactly that one to a box whose entry rounds to t0 and
+    //    return the other: same t, another material.  Such a node is entered twice, as the reference does (round 4 skipped it: ADVICE
+    //    r4; tests/test_dup_instance.py has the coplanar case).
+    std::vector<int8_t> spheres_only_memo;      // per vk_bvh_node: 1 / 0, -1 unknown
+    bool spheres_only_subtree(uint32_t root, bool &yes) {
+        if (spheres_only_memo.empty()) spheres_only_memo.assign(d->n_bvh, -1);
+        std::vector<uint32_t> st{root}, seen;
+        yes = true;
+        size_t guard = 0;
+        while (!st.empty() && yes) {
+            if (++guard > (size_t)8 * (d->n_bvh + 16) + 1024) return fail(VK_ERR_BAD_ARG, "BVH graph is cyclic");
+            const uint32_t ni = st.back(); st.pop_back();
+            if (spheres_only_memo[ni] == 1) continue;
+            if (spheres_only_memo[ni] == 0) { yes = false; break; }
+            seen.push_back(ni);
+            const vk_bvh_node &n = d->bvh[ni];
+            for (vk_ref c : {n.left, n.right}) {
+                if (!check_ref(c)) return false;
+                if (VK_REF_KIND(c) == VK_KIND_BVH) st.push_back(VK_REF_INDEX(c));
+                else if (VK_REF_KIND(c) != VK_KIND_SPHERE) yes = false;
+            }
+        }
+        if (yes) for (uint32_t ni : seen) spheres_only_memo[ni] = 1;
+        else spheres_only_memo[root] = 0;
+        return true;
+    }
     bool draw_free_instance(uint32_t idx, bool &yes) {
         yes = false;
         const DInstance &I = L.instances[idx];
@@ -333,11 +364,7 @@ struct Builder {
             return true;
         }
         for (const Pending &p : pending)
-            if (p.inst == (int32_t)idx) {
-                if (simple_count.empty() || simple_count[p.bvh_index] == -2) { if (!classify(p.bvh_index)) return false; }
-                yes = simple_count[p.bvh_index] >= 0;
-                return true;
-            }
+            if (p.inst == (int32_t)idx) return spheres_only_subtree(p.bvh_index, yes);
         return true;
     }
     static bool draw_free(uint32_t dref) { uint32_t k = VKD_KIND(dref);
@@ -849,10 +876,10 @@ struct Builder {
                 fr.stage += 1;
                 uint32_t cf = fr.flip ^ ((child & VK_REF_FLIP) ? DREF_FLIP : 0u);
                 if (second && n.left == n.right && VK_REF_KIND(child) == VK_KIND_BVH) {
-                    // a len-1 node over a BVHNode in which nothing draws: the second call returns None (see draw_free_instance)
-                    const uint32_t ci = VK_REF_INDEX(child);
-                    if (simple_count.empty() || simple_count[ci] == -2) { if (!classify(ci)) return false; }
-                    if (simple_count[ci] >= 0) continue;
+                    // a len-1 node over a BVHNode of spheres only: the second call returns None (see draw_free_instance)
+                    bool skip = false;
+                    if (!spheres_only_subtree(VK_REF_INDEX(child), skip)) return false;
+                    if (skip) continue;
                 }
                 if (VK_REF_KIND(child) == VK_KIND_BVH) {
                     Frame nf{VK_REF_INDEX(child), cf, 0, 0};

@@ -181,6 +181,19 @@ VK_HD double k_cos(double r) {
     return (1.0 - 0.5 * z) + z * p;
 }
 
+#if defined(VK_MATH_LIBM) && !defined(__HIP_DEVICE_COMPILE__)
+// The INDEPENDENT variant (oracle/Makefile target `libm`, tests/test_oracle_libm.py): the seven functions from glibc's f32
+// libm instead of the kernels below.  Everything that is compiled into oracle, emulator and device alike shares these kernels, so an
+// error in them would be common-mode; this build of the oracle bounds how many paths a last-bit difference in them moves.
+VK_COLD float sinf_(float x) { return ::sinf(x); }
+VK_COLD float cosf_(float x) { return ::cosf(x); }
+struct SinCos { float s, c; };
+VK_COLD SinCos sincosf_(float x) { SinCos o; o.s = ::sinf(x); o.c = ::cosf(x); return o; }
+VK_COLD float logf_(float x) { return ::logf(x); }
+VK_COLD float atan2f_(float y, float x) { return ::atan2f(y, x); }
+VK_COLD float asinf_(float x) { return ::asinf(x); }
+VK_HD float pow5f_(float x) { return ::powf(x, 5.0f); }
+#else
 VK_COLD float sinf_(float xf) {
     double x = (double)xf;
     if (!(x > -1.0e9 && x < 1.0e9)) return xf - xf;  // inf/NaN -> NaN; |x|>=1e9 unsupported -> 0
@@ -331,6 +344,7 @@ VK_HD float pow5f_(float x) {
     double d2 = d * d;
     return (float)((d2 * d2) * d);   // f64 product rounded once: agrees with a correctly rounded powf
 }
+#endif      // VK_MATH_LIBM
 
 }  // namespace vk
 #endif

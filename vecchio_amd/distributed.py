@@ -90,7 +90,9 @@ class DeviceFramebufferGather:
         self.fmt = ffi.VK_OUTPUT_RGB8 if rgb8 else ffi.VK_OUTPUT_F32
         self.stage_on_cpu = stage_on_cpu
         lib = ffi.load_device_lib()
-        self.slab_bytes = int(lib.vk_tile_slab_bytes(width, height, self.fmt, world, world))     # the largest rank's
+        # the largest rank's; at least one byte: an image with fewer 8x8 tiles than ranks leaves some ranks (or all but one) without a
+        # tile, and a zero-sized tensor has a null data pointer, which vk_pack_tiles_device rejects
+        self.slab_bytes = max(1, int(lib.vk_tile_slab_bytes(width, height, self.fmt, world, world)))
         self.slab = torch.zeros(self.slab_bytes, dtype=torch.uint8, device=device)
         xdev = "cpu" if stage_on_cpu else device
         self.xslab = torch.zeros(self.slab_bytes, dtype=torch.uint8, device=xdev) if stage_on_cpu else self.slab

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 ASSETS_DIR = os.path.join(os.path.dirname(_HERE), "tests", "golden", "assets")
 
-VK_ABI_VERSION = 5
+VK_ABI_VERSION = 6
 VK_OK, VK_ERR_BAD_ARG, VK_ERR_UNSUPPORTED, VK_ERR_HIP, VK_ERR_NO_DEVICE, VK_ERR_OOM = range(6)
 
 (VK_KIND_NONE, VK_KIND_BVH, VK_KIND_SPHERE, VK_KIND_MOVING_SPHERE, VK_KIND_RECT, VK_KIND_LIST,
@@ -28,6 +28,7 @@ VK_OUTPUT_F32, VK_OUTPUT_RGB8 = 0, 1
 VK_SCENE_FAST_ACCEL = 1
 VK_SCENE_REFERENCE_TREE = 2
 VK_SCENE_EMPIRICAL_TREES = 4
+VK_SCENE_RCCL_GATHER = 8
 
 
 def make_ref(kind, index, flip=False):
@@ -131,10 +132,16 @@ class Stats(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("n_items", C.c_uint32), ("n_prims", C.c_uint32), ("n_instances", C.c_uint32),
                 ("device_bytes", C.c_uint64), ("lds_bytes", C.c_uint32), ("features", C.c_uint32), ("tree", C.c_uint32),
-                ("tree_suspended_frames", C.c_uint32)]
+                ("tree_suspended_frames", C.c_uint32), ("gather", C.c_uint32)]
+
+
+class PartInfo(C.Structure):
+    _fields_ = [("n_parts", C.c_uint32), ("device", C.c_int32), ("name", C.c_char * 64), ("pci_bus_id", C.c_char * 32),
+                ("can_access_landing_device", C.c_uint32), ("kernel_ms", C.c_double)]
 
 
 VK_TREE_HANDED_OVER, VK_TREE_REBUILT_PROVEN, VK_TREE_REBUILT_EMPIRICAL, VK_TREE_REBUILT_FAST = range(4)
+VK_GATHER_NONE, VK_GATHER_PEER_COPY, VK_GATHER_RCCL = range(3)
 
 
 _host = None
@@ -188,9 +195,9 @@ def load_host_lib():
 
 
 DEVICE_SYMBOLS = [
-    "vk_abi_version", "vk_device_count", "vk_last_error", "vk_scene_create", "vk_scene_destroy",
+    "vk_abi_version", "vk_device_count", "vk_last_error", "vk_gather_backends", "vk_scene_create", "vk_scene_destroy",
     "vk_render", "vk_render_device", "vk_to_color_device", "vk_scene_get_info", "vk_scene_create_multi",
-    "vk_scene_last_kernel_ms", "vk_scene_last_clamped_samples", "vk_scene_last_requeued_samples",
+    "vk_scene_last_kernel_ms", "vk_scene_last_clamped_samples", "vk_scene_last_requeued_samples", "vk_scene_part_info",
     "vk_tile_slab_bytes", "vk_pack_tiles_device", "vk_unpack_tiles_device",
 ]
 
@@ -203,6 +210,7 @@ def device_lib_path():
 def _bind(lib):
     """restype / argtypes of every entry point of include/vecchio_amd.h"""
     lib.vk_abi_version.restype = C.c_int
+    lib.vk_gather_backends.restype = C.c_int
     lib.vk_device_count.restype = C.c_int
     lib.vk_last_error.restype = C.c_char_p
     lib.vk_scene_create.restype = C.c_int
@@ -216,6 +224,8 @@ def _bind(lib):
     lib.vk_scene_last_clamped_samples.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.vk_scene_last_requeued_samples.restype = C.c_int
     lib.vk_scene_last_requeued_samples.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.vk_scene_part_info.restype = C.c_int
+    lib.vk_scene_part_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(PartInfo)]
     lib.vk_render.restype = C.c_int
     lib.vk_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]
     lib.vk_render_device.restype = C.c_int

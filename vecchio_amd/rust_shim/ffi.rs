@@ -11,10 +11,11 @@ use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
 pub type vk_ref = u32;
-pub const VK_ABI_VERSION: u32 = 5;
+pub const VK_ABI_VERSION: u32 = 6;
 pub const VK_SCENE_FAST_ACCEL: u32 = 1;
 pub const VK_SCENE_REFERENCE_TREE: u32 = 2;
 pub const VK_SCENE_EMPIRICAL_TREES: u32 = 4;
+pub const VK_SCENE_RCCL_GATHER: u32 = 8;
 pub const VK_REF_FLIP: u32 = 0x0800_0000;
 pub const VK_KIND_BVH: u32 = 1;
 pub const VK_KIND_SPHERE: u32 = 2;

@@ -112,6 +112,18 @@ class DeviceScene:
         check(self._lib, self._lib.vk_scene_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def parts(self):
+        """one record per device share of the scene (vk_scene_part_info): device, name, PCI bus id, peer access to devices[0], the kernel
+        time of its launches in the last frame (waits for them)"""
+        out = []
+        pi = ffi.PartInfo()
+        check(self._lib, self._lib.vk_scene_part_info(self._h, 0, C.byref(pi)))
+        for j in range(pi.n_parts):
+            check(self._lib, self._lib.vk_scene_part_info(self._h, j, C.byref(pi)))
+            out.append({"part": j, "device_index": pi.device, "device": pi.name.decode(), "pci_bus_id": pi.pci_bus_id.decode(),
+                        "can_access_devices0": bool(pi.can_access_landing_device), "kernel_ms": round(pi.kernel_ms, 3)})
+        return out
+
     def last_requeued_samples(self):
         """Exact re-treeing: samples of the last render that went through the second launch, on the tree as handed over (waits)."""
         n = C.c_uint64()
