@@ -25,11 +25,12 @@ int vk_debug_render_samples(vk_scene *scene, const vk_camera *cam, const vk_rend
  * counters: [0] box steps (wave level) [1] lanes with box work summed over them [2] PRIM phases
  * [3] lanes with primitive work in them [4] SHADE+REFILL phases [5] lanes in them [6] rounds
  * [7] heavy-primitive phases; wave clocks spent in [8] BOX [9] light PRIM [10] heavy PRIM
- * [11] SHADE+REFILL phases, [12] total wave clocks, [13..15] SHADE split (material / refill / install).
+ * [11] SHADE+REFILL phases, [12] total wave clocks, [13..15] SHADE split (material / refill / install), [16] the cooperative Perlin
+ * turbulence ahead of the material code, [17] the cold-state load of the shading lanes; [18..23] reserved (0).
  * Sphere-only builds have no PRIM phases of their own (sphere tests run inside the box loop) and reuse four slots for the
  * box loop's exit tests: [2] exit tests, [7] live lanes, [9] lanes with a pending test, [10] lanes waiting for shading, each
  * summed over the exit tests.                                                                                   */
-int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, uint64_t out[16]);
+int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, uint64_t out[24]);
 /* evaluate the shared host/device arithmetic ON THE DEVICE (host arrays in/out):
  * op 0 sin, 1 cos, 2 ln, 3 asin, 4 atan2(a,b), 5 pow5, 6 a/b, 7 sqrt(a), 8 draws, 9 a*b+a  */
 int vk_debug_math(int device, int op, const float *a, const float *b, float *out, size_t n);

@@ -146,14 +146,14 @@ def test_multi_device_render_device_and_errors(device, host_scenes):
     dd = DeviceScene(hs.desc, lib=dbg)
     dbg.vk_debug_phase_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     assert dbg.vk_debug_phase_stats(dd._h, None, None, None) == ffi.VK_ERR_BAD_ARG          # used to dereference params first
-    dbg.vk_debug_phase_stats.argtypes = [C.c_void_p, C.POINTER(ffi.Camera), C.POINTER(ffi.RenderParams), C.POINTER(C.c_uint64 * 16)]
+    dbg.vk_debug_phase_stats.argtypes = [C.c_void_p, C.POINTER(ffi.Camera), C.POINTER(ffi.RenderParams), C.POINTER(C.c_uint64 * 24)]
     dd.close()
     # (instrumented builds exist for the sphere-only/scatter and the full/PDF variants)
     from vecchio_amd import HostScene
     hs2 = HostScene("random_spheres_iow", 1)
     cam2 = hs2.next_camera()
     dd = DeviceScene(hs2.desc, lib=dbg)
-    out = (C.c_uint64 * 16)()
+    out = (C.c_uint64 * 24)()
     ps = hs2.params(96, 8, 20)
     assert dbg.vk_debug_phase_stats(dd._h, C.byref(cam2), C.byref(ps), C.byref(out)) == 0, dbg.vk_last_error()
     assert out[0] > 0 and out[12] > 0

@@ -78,9 +78,9 @@ def main():
     # phase scheduler statistics (instrumented kernel build)
     lib = ffi.load_debug_lib()
     lib.vk_debug_phase_stats.restype = C.c_int
-    lib.vk_debug_phase_stats.argtypes = [C.c_void_p, C.POINTER(ffi.Camera), C.POINTER(ffi.RenderParams), C.POINTER(C.c_uint64 * 16)]
+    lib.vk_debug_phase_stats.argtypes = [C.c_void_p, C.POINTER(ffi.Camera), C.POINTER(ffi.RenderParams), C.POINTER(C.c_uint64 * 24)]
     p = hs.params(1920, 64, 50)
-    out = (C.c_uint64 * 16)()
+    out = (C.c_uint64 * 24)()
     ds.close(); ds = DeviceScene(hs.desc, lib=lib)
     if lib.vk_debug_phase_stats(ds._h, C.byref(cam), C.byref(p), C.byref(out)) == 0:
         v = list(out)

@@ -215,7 +215,7 @@ struct vk_scene {
     int plan_last = 0;                 // the slot of the last frame with a second launch
     bool plan_copied = false;          // ... whose plan did travel to that slot
     uint64_t redo_last_samples = 0;    // samples of the partition the last render covered
-    unsigned long long *phase_stats = nullptr;   // device, 16 counters (diagnostic kernel build)
+    unsigned long long *phase_stats = nullptr;   // device, 24 counters (diagnostic kernel build)
     bool want_phase_stats = false;
     // heavy-first tile order: per-tile times of the probe launch and the order derived from them
     uint32_t *tile_cost = nullptr, *tile_order = nullptr, *order_hist = nullptr;
@@ -666,8 +666,8 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         const uint32_t FULLPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
         if (F != 0u && F != FULLPDF)
             return fail(VK_ERR_UNSUPPORTED, "phase statistics are only built for the sphere-only/scatter and the full/PDF variants");
-        if (!s->phase_stats) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->phase_stats), 16 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(s->phase_stats, 0, 16 * sizeof(unsigned long long), st));
+        if (!s->phase_stats) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->phase_stats), 24 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(s->phase_stats, 0, 24 * sizeof(unsigned long long), st));
         A.phase_stats = s->phase_stats;
         auto go = [&](auto kernel) -> int {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -1395,7 +1395,7 @@ int vk_to_color_device(vk_scene *scene, const void *d_rgb, uint32_t width, uint3
 
 #ifdef VK_DEBUG_LIB      // libvecchio_amd_debug.so only (build.py build_device_debug): the product library holds production kernels only
 // diagnostic: render with the instrumented kernel build and return the phase scheduler's counters (vecchio_amd_debug.h)
-int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, uint64_t out[16]) {
+int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_params *params, uint64_t out[24]) {
     if (!out) return fail(VK_ERR_BAD_ARG, "null argument");
     int rc = check_render_args(scene, cam, params);
     if (rc != VK_OK) return rc;
@@ -1410,7 +1410,7 @@ int vk_debug_phase_stats(vk_scene *scene, const vk_camera *cam, const vk_render_
         scene->want_phase_stats = false;
         if (rc2 != VK_OK) return rc2;
         HIP_TRY(hipStreamSynchronize(nullptr));
-        HIP_TRY(hipMemcpy(out, scene->phase_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out, scene->phase_stats, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         return VK_OK;
     });
 }

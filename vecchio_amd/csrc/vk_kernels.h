@@ -52,7 +52,7 @@ struct KArgs {
     uint32_t shade_defer;    // SHADE + REFILL runs when its lanes outnumber box and primitive lanes this many times (see SHADE_DEFER)
     uint32_t prim_weight;    // pending primitive tests run when prim_weight x their lanes outnumber the box lanes
     uint32_t lds_items, lds_spheres, lds_boxes;   // record counts staged into LDS (LDS variant)
-    unsigned long long *phase_stats;   // optional (diagnostic build of the kernel): 16 counters, see vk_debug_phase_stats
+    unsigned long long *phase_stats;   // optional (diagnostic build of the kernel): 24 counters, see vk_debug_phase_stats
     // Exact re-treeing (vk_trace.h): samples dropped by the first launch (the winner of one of their segments may depend on the visiting
     // order) are queued here, REDO_REGIONS queues of redo_region_cap entries {x | y << 16, sample}, one counter per region (64 bytes
     // apart); a workgroup appends to the region of its block index.  The second launch (list_mode = 1, S = the scene as handed over)
@@ -314,7 +314,7 @@ __device__ __forceinline__ PreTurb cooperative_turb(const Lane &L, const DScene 
 // samples to the lanes without a path.  Leaves `fresh` lanes with a new ray parked in L.wo / L.wd / L.time, which the caller
 // installs with ONE begin_segment (its three exact reciprocals are ~60 instructions per call site). Used inline by the lean variants and
 // through shade_refill_call (below) by the everything-variants.
-struct PhaseClocks { unsigned long long mat = 0, refill = 0, t1 = 0; };
+struct PhaseClocks { unsigned long long mat = 0, refill = 0, t1 = 0, turb = 0, cold = 0; };
 template <uint32_t F, bool LDS_SCENE, bool STATS, bool COST>
 __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool early, bool &active, bool &need, bool &fresh, bool &touched,
                                                   bool &rearm,
@@ -328,7 +328,9 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool e
     (void)st_t_mat; (void)st_t_refill; (void)st_t1; (void)cost_t0;
     fresh = false;                // lanes that leave this phase with a new ray to install; it is parked in the
                                   // (dead) world-ray fields L.wo / L.wd / L.time, so it costs no registers
+    if (STATS) st_t1 = clock64();
     const PreTurb pre_turb = cooperative_turb<F, Mem>(L, S, M, is_shade, lane);
+    if (STATS) clk.turb += clock64() - st_t1;
     rearm = false;
     // `early` (exact re-treeing): the winner of this lane's segment may depend on the visiting order (vk_trace.h segment_unsafe,
     // asked by the caller, which holds the segment's reciprocals)
@@ -364,7 +366,9 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool e
     }
     touched = is_shade;
     if (is_shade) {
+        if (STATS) st_t1 = clock64();
         cold_load_path<F>(cold, lane, L);
+        if (STATS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); clk.cold += clock64() - st_t1; }
         if (STATS) st_t1 = clock64();
         V3 no, nd; float nt;
         bool cont = shade_core<F, Mem>(L, S, M, C, no, nd, nt, pre_turb);
@@ -553,7 +557,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
     unsigned long long st_box_steps = 0, st_box_lanes = 0, st_prim_execs = 0, st_prim_lanes = 0, st_shade_execs = 0, st_shade_lanes = 0,
         st_sched = 0;
     unsigned long long st_t_box = 0, st_t_light = 0, st_t_heavy = 0, st_t_shade = 0, st_heavy_execs = 0, st_t0 = 0, st_t_total = 0,
-        st_t_mat = 0, st_t_refill = 0, st_t_install = 0, st_t1 = 0;
+        st_t_mat = 0, st_t_refill = 0, st_t_install = 0, st_t1 = 0, st_t_turb = 0, st_t_cold = 0;
     if (STATS) st_t_total = clock64();
 
     if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && LDS_SCENE) {      // the fallback launch of exact re-treeing: nothing to do, nearly always
@@ -777,7 +781,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 shade_refill_body<F, LDS_SCENE, STATS, COST>(L, is_shade, early, active, need, fresh, touched, rearm, cost_t0,
                     kargs_fresh(), cold,
                     tile_sum, wstate, lane, lds_items, clk);
-                if (STATS) { st_t_mat += clk.mat; st_t_refill += clk.refill; st_t1 = clock64(); }
+                if (STATS) { st_t_mat += clk.mat; st_t_refill += clk.refill; st_t_turb += clk.turb; st_t_cold += clk.cold; st_t1 = clock64(); }
                 if (fresh | rearm) {
                     KArgsC P = kargs_fresh();
                     DScene S = KARG(P, S);
@@ -811,6 +815,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             atomicAdd(&ps[8], st_t_box); atomicAdd(&ps[9], st_t_light); atomicAdd(&ps[10], st_t_heavy); atomicAdd(&ps[11], st_t_shade);
             atomicAdd(&ps[12], (unsigned long long)(clock64() - st_t_total));
             atomicAdd(&ps[13], st_t_mat); atomicAdd(&ps[14], st_t_refill); atomicAdd(&ps[15], st_t_install);
+            atomicAdd(&ps[16], st_t_turb); atomicAdd(&ps[17], st_t_cold);
         }
     }
 }

@@ -258,7 +258,7 @@ def load_debug_lib():
     lib = C.CDLL(path)
     _bind(lib)
     lib.vk_debug_phase_stats.restype = C.c_int
-    lib.vk_debug_phase_stats.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.POINTER(C.c_uint64 * 16)]
+    lib.vk_debug_phase_stats.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.POINTER(C.c_uint64 * 24)]
     lib.vk_debug_math.restype = C.c_int
     lib.vk_debug_math.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     _dbg = lib
