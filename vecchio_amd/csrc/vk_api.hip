@@ -664,8 +664,9 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
 #ifdef VK_DEBUG_LIB
     if (s->want_phase_stats) {
         const uint32_t FULLPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
-        if (F != 0u && F != FULLPDF)
-            return fail(VK_ERR_UNSUPPORTED, "phase statistics are only built for the sphere-only/scatter and the full/PDF variants");
+        const uint32_t CORNELLPDF = VKF_RECT | VKF_LIST | VKF_INSTANCE | VKF_BOX | VKF_INTEG_PDF;
+        if (F != 0u && F != FULLPDF && F != CORNELLPDF)
+            return fail(VK_ERR_UNSUPPORTED, "phase statistics are only built for the sphere-only/scatter, the Cornell-type/PDF and the full/PDF variants");
         if (!s->phase_stats) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->phase_stats), 24 * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(s->phase_stats, 0, 24 * sizeof(unsigned long long), st));
         A.phase_stats = s->phase_stats;
@@ -675,6 +676,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
             return VK_OK;
         };
         if (F == 0u) rc = lds ? go(&render_kernel<0u, true, 6, true>) : go(&render_kernel<0u, false, 6, true>);
+        else if (F == CORNELLPDF) rc = lds ? go(&render_kernel<CORNELLPDF, true, 6, true>) : go(&render_kernel<CORNELLPDF, false, 6, true>);
         else rc = lds ? go(&render_kernel<FULLPDF, true, 4, true>) : go(&render_kernel<FULLPDF, false, 4, true>);
         if (rc != VK_OK) return rc;
         HIP_TRY(hipGetLastError());
