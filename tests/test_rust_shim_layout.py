@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = open(os.path.join(ROOT, "include", "vecchio_amd.h")).read()
 SHIM = open(os.path.join(ROOT, "vecchio_amd", "rust_shim", "ffi.rs")).read()
 
-SCALAR = {"uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "float": "f32", "double": "f64", "vk_ref": "vk_ref", "int": "c_int"}
+SCALAR = {"uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "float": "f32", "double": "f64", "vk_ref": "vk_ref", "int": "c_int",
+          "int32_t": "i32", "char": "c_char"}
 
 
 def c_structs():
@@ -70,7 +71,7 @@ def test_every_c_struct_has_an_identical_repr_c_twin():
     c, r = c_structs(), rust_structs()
     assert {"vk_scene_desc", "vk_camera", "vk_render_params", "vk_stats", "vk_bvh_node", "vk_perlin"} <= set(c)
     for name, fields in c.items():
-        if name == "vk_scene_info":                # introspection for bench/tests, not bound by the shim
+        if name in ("vk_scene_info", "vk_part_info"):      # introspection for bench/tests, not bound by the shim
             continue
         assert name in r, f"{name} missing from rust_shim/ffi.rs"
         assert r[name] == fields, f"{name}:\n  header {fields}\n  ffi.rs {r[name]}"

@@ -280,6 +280,13 @@ size_t per_wave_lds_bytes(uint32_t F) {   // cold lane state of one wave + its t
     return ((F & VKF_INSTANCE) ? wave_block_floats<VKF_INSTANCE>() : wave_block_floats<0u>()) * sizeof(float);
 }
 
+// Waves per SIMD the variants with heavy primitives are built for (their __launch_bounds__): 80 VGPRs = 6, 96 = 5.
+#ifndef VK_ALL_MINW
+#define VK_ALL_MINW 6
+#endif
+#ifndef VK_CORNELL_MINW
+#define VK_CORNELL_MINW 6
+#endif
 // LDS residency plan.  `hot` = bytes of items + spheres + boxes.  Measured on MI355X with the VALU-bound
 // kernel: at EQUAL occupancy a scene staged in LDS beats the same scene read through L1/L2 by only 7 % (C2:
 // 4.06 vs 3.77 Gsamples/s at 24 waves/CU; C4: no difference), while occupancy is worth much more (C3: the
@@ -291,7 +298,8 @@ void plan_residency(vk_scene *s, size_t hot) {
     const size_t pw = per_wave_lds_bytes(pick_variant(s));
     uint32_t best_waves = 0, best_wg = 0, best_n = 0;
     const bool spheres_only = pick_variant(s) == 0u;
-    const uint32_t per_simd = spheres_only ? s->sphere_waves : 6u;          // = MINW of launch_variant
+    const uint32_t per_simd = spheres_only ? s->sphere_waves : (pick_variant(s) == (uint32_t)VKF_ALL_SCENE ? (uint32_t)VK_ALL_MINW
+                                                                                                           : (uint32_t)VK_CORNELL_MINW);   // = MINW of launch_variant
     uint32_t cap = 4 * per_simd;                                             // waves per CU the variant's register budget admits
     // Workgroups hold a multiple of 4 waves that divides evenly over the CU's four SIMDs: the dispatcher deals a workgroup's waves
     // round-robin, so e.g. two 10-wave workgroups land 3+3+2+2 twice and the second one does not fit beside the first at 5 per SIMD
@@ -301,7 +309,8 @@ void plan_residency(vk_scene *s, size_t hot) {
         size_t budget = LDS_PER_CU / n_wg;
         if (hot + 4 * pw > budget) break;
         uint32_t w = (uint32_t)std::min<size_t>(std::min<uint32_t>(max_wg_waves, cap / n_wg), (budget - hot) / pw);
-        if (w < 1) break;
+        w &= ~3u;                          // (a multiple of four: see above)
+        if (w < 4) break;
         if (w * n_wg > best_waves) { best_waves = w * n_wg; best_wg = w; best_n = n_wg; }
     }
     // Seven waves per SIMD (the sphere-only kernels need 72 VGPRs): 28 waves per CU cannot be two EQUAL workgroups — 14 waves land
@@ -318,7 +327,7 @@ void plan_residency(vk_scene *s, size_t hot) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = best_wg * 64; s->wgs_per_cu = best_n;
     } else {
         // 28 (sphere-only: seven 4-wave workgroups, 7 waves/SIMD) or 24 waves per CU
-        s->lds_bytes = 0; s->wg_threads = 256; s->wgs_per_cu = spheres_only ? 7 : 6;
+        s->lds_bytes = 0; s->wg_threads = 256; s->wgs_per_cu = spheres_only ? 7 : per_simd;
     }
 }
 
@@ -331,7 +340,8 @@ int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shme
     // registers at 6, 80 at 7, shading inline; out of line 5 340 at 6); C3, which waits for memory 44 % of the time, 642 / 695 / 726 at 4 /
     // 5 / 6
     // (13 spilled registers, 25 scratch instructions outside the box loop, shading out of line) and 695 at 7 (27 registers, 154).
-    constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? MINW_SPHERES : 6;
+    constexpr int MINW = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) ? MINW_SPHERES
+                                                                : ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE ? VK_ALL_MINW : VK_CORNELL_MINW);
     // Sphere-only scenes traversed from GLOBAL memory (C5, 49 MB of items and spheres): every box step is a dependent gather there, so
     // waves in flight pay.  On the tree handed over 8 waves per SIMD / 64 VGPRs with the shading phase out of line were best (629 -> 685
     // Msamples/s over 6); on the rebuilt tree of exact re-treeing the walks are half as long and the 64-VGPR build's spills (72 B of
