@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2.0   # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles, 2.4 GHz max clock
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 WORKLOADS = {
     # name: (scene builder, width, spp, max_depth, label)
@@ -111,7 +111,7 @@ def physical_bounds(c, samples, seconds, scene_in_lds, issue, walked=None):
 
 def pmc_summary(workload):
     """the committed rocprofv3 PMC summary of this workload's bench command (profiles/<round>/), or None"""
-    for rnd in (PROFILE_ROUND, "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r04", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", rnd, f"{workload.lower()}_pmc_summary.json")
         if os.path.exists(path) and os.path.getsize(path) > 0:
             try:
