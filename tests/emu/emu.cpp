@@ -543,6 +543,39 @@ int emu_own_gate_ray(const float c[3], float r, const float o[3], const float d[
     return 0;
 }
 
+// The device-only arithmetic of the sphere test (vk_trace.h refined_rcp / div_by_a: quotients by |d|^2 through a shared reciprocal) exists
+// under __HIP_DEVICE_COMPILE__ only, because it starts from v_rcp_f32, whose bits the ISA does not specify beyond "within 1 ulp".  What CAN
+// be checked on the host is the algorithm's claim: for ANY starting reciprocal within 1 ulp of 1/a, one Newton step and the two
+// fma corrections yield the correctly rounded quotient n / a, for a in the range set_space admits (3e-12 .. 3e12) and |n| < 2^54.
+// Returns the number of (n, a, perturbation) triples out of `cases` x 3 whose result differs from n / a; worst[] = {n, a, got, want}.
+uint64_t emu_div_by_a_model(uint64_t cases, uint64_t seed, float worst[4]) {
+    Lcg g(seed);
+    uint64_t bad = 0;
+    for (uint64_t it = 0; it < cases; it++) {
+        const float a = (float)g.log_uni(3.0e-12, 3.0e12);
+        float n = (float)(g.log_uni(1.0e-12, 1.0e16) * (g.uni() < 0.5 ? -1.0 : 1.0));
+        if (g.uni() < 0.1) n = a * (float)(g.uni() * 4.0 - 2.0);              // quotients near 1: the sphere test's t ~ 1 cases
+        const float want = n / a;
+        if (!std::isfinite(want) || std::fabs(want) < 1.0e-30f) continue;       // (underflowing quotients are below tmin either way)
+        const float y0 = 1.0f / a;
+        for (int p = -1; p <= 1; p++) {
+            float y = vk::bits_f32(vk::f32_bits(y0) + (uint32_t)p);             // what v_rcp_f32 may return
+            const float e = __builtin_fmaf(-a, y, 1.0f);
+            y = __builtin_fmaf(e, y, y);                                        // refined_rcp
+            float q = n * y;                                                    // div_by_a
+            float r = __builtin_fmaf(-a, q, n);
+            q = __builtin_fmaf(r, y, q);
+            r = __builtin_fmaf(-a, q, n);
+            q = __builtin_fmaf(r, y, q);
+            if (vk::f32_bits(q) != vk::f32_bits(want)) {
+                if (bad == 0 && worst) { worst[0] = n; worst[1] = a; worst[2] = q; worst[3] = want; }
+                bad++;
+            }
+        }
+    }
+    return bad;
+}
+
 // closest hit of ONE segment as the device decides it (rebuilt walk, segment_unsafe, the tree as handed over where needed):
 // out = {T, best_prim (bits), 1 if the tree as handed over decided}
 int emu_hit(const vk_scene_desc *desc, const float o[3], const float d[3], float out[3]) {

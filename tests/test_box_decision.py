@@ -106,3 +106,17 @@ def test_tmax_clamp_is_fminf_for_every_tmax_the_walk_can_hold(emu):
     lib.emu_min_with_tmax(a.ctypes.data, t.ctypes.data, len(a), out.ctypes.data)
     want = np.fmin(a, t)                                            # fminf: NaN operands are dropped
     assert (out.view(np.uint32) == want.view(np.uint32)).all()
+
+
+def test_shared_reciprocal_division_is_exact_for_any_one_ulp_reciprocal(emu):
+    """vk_trace.h div_by_a (the sphere test's quotients by |d|^2 on the device: v_rcp_f32, one Newton step, two fma corrections) is compiled
+    for the device only — the ISA specifies v_rcp_f32 to 1 ulp, not to the bit — so the emulator divides.  The algorithm's claim is checked
+    here instead: from ANY reciprocal within 1 ulp of 1/a the sequence ends on the correctly rounded n / a, over the operand ranges
+    set_space admits.  (The GPU test test_gpu_parity.py compares the real instruction on 2^26 pairs.)"""
+    import ctypes as C
+    lib = emu.load()
+    lib.emu_div_by_a_model.restype = C.c_uint64
+    lib.emu_div_by_a_model.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_float * 4)]
+    worst = (C.c_float * 4)()
+    bad = lib.emu_div_by_a_model(4_000_000, 11, C.byref(worst))
+    assert bad == 0, f"{bad} quotients differ, e.g. n={worst[0]!r} a={worst[1]!r}: got {worst[2]!r}, n/a = {worst[3]!r}"
