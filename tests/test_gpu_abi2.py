@@ -3,6 +3,9 @@ multi-device scenes (vk_scene_create_multi: SURVEY §8b "uploads to every partic
 devices[0] + de-interleave + one D2H), the fused output stage (VK_OUTPUT_RGB8 = Vec3::to_color vec3.rs:44-61 +
 top-down rows main.rs:209) and the MAX_DEPTH = 0 corner (main.rs:126-128)."""
 import ctypes as C
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -11,6 +14,7 @@ import golden_checks as G
 from vecchio_amd import DeviceScene, HostScene, ffi
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_to_color_kernel_against_numpy_restatement(device, host_scenes):
@@ -118,6 +122,40 @@ def test_rccl_gather_flag(device, host_scenes, capfd):
     plain = DeviceScene(hs.desc, devices=[0, 0])
     assert plain.info().gather == ffi.VK_GATHER_PEER_COPY
     plain.close()
+
+
+def test_rccl_gather_orchestration_with_a_test_double(device):
+    """The ORCHESTRATION of VK_SCENE_RCCL_GATHER — sends on the parts' streams behind render and pack, receives on devices[0]'s receive
+    stream, ONE event behind the group, part 0 unpacked from its own slab — run on the one-GPU box: the DEBUG build of the library loads
+    tests/mock_rccl (VK_RCCL_LIB: ncclSend / ncclRecv as event-ordered device copies, pairs matched inside ncclGroupEnd) and is allowed
+    to list the device several times.  Three shares: the frames must be the one-device frames bit for bit, f32 and RGB8, frame after
+    frame, whole frame and as one rank of an outer partition, and the double must have moved two slabs per frame.  (Real RCCL over
+    two physical devices: the driver's multi-GPU run.)  In a child process: the library reads the switches once."""
+    from vecchio_amd import build
+    mock = build.build_mock_rccl()
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from vecchio_amd import DeviceScene, HostScene, ffi\n"
+            "dbg = ffi.load_debug_lib(); mock = C.CDLL(%r); mock.mock_rccl_pairs.restype = C.c_ulonglong\n"
+            "hs = HostScene('cornell_box', 1); cam = hs.next_camera()\n"
+            "p = hs.params(200, 48, 50); p8 = hs.params(200, 48, 50, output_format=ffi.VK_OUTPUT_RGB8)\n"
+            "one = DeviceScene(hs.desc, lib=dbg); want = one.render(cam, p)[0]; want8 = one.render(cam, p8)[0]; one.close()\n"
+            "hs.desc.contents.flags |= ffi.VK_SCENE_RCCL_GATHER\n"
+            "m = DeviceScene(hs.desc, devices=[0, 0, 0], lib=dbg)\n"
+            "assert m.info().gather == ffi.VK_GATHER_RCCL, m.info().gather\n"
+            "ok = []\n"
+            "for k in range(3): ok.append(np.array_equal(m.render(cam, p)[0], want))\n"
+            "ok.append(np.array_equal(m.render(cam, p8)[0], want8))\n"
+            "acc = np.zeros_like(want)\n"
+            "for r in range(2): m.render(cam, hs.params(200, 48, 50, tile_rank=r, tile_world=2), out=acc)\n"
+            "ok.append(np.array_equal(acc, want))\n"
+            "parts = m.parts(); m.close()\n"
+            "print('OK', all(ok), ok, 'PAIRS', mock.mock_rccl_pairs(), 'PARTS', len(parts))\n") % (ROOT, mock)
+    env = dict(os.environ, VK_RCCL_LIB=mock, VK_RCCL_ALLOW_DUPLICATE_DEVICES="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "OK True" in r.stdout, r.stdout + r.stderr
+    w = r.stdout.split()
+    assert int(w[w.index("PAIRS") + 1]) == 2 * 6 and int(w[w.index("PARTS") + 1]) == 3, r.stdout      # six frames, two travelling slabs each
 
 
 def test_multi_device_render_device_and_errors(device, host_scenes):

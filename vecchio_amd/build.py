@@ -205,8 +205,22 @@ def build_emu(force=False):
     return out
 
 
+def build_mock_rccl(force=False):
+    """Test double of librccl.so (tests/mock_rccl): the library's RCCL gather on a one-GPU box, through the DEBUG build only."""
+    mdir = os.path.join(ROOT, "tests", "mock_rccl")
+    out = os.path.join(mdir, "_build", "librccl_mock.so")
+    src = os.path.join(mdir, "mock_rccl.cpp")
+    flags = ["-O2", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
+    if force or _newer(out, [src], flags):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        _run([CXX] + flags + ["-shared", "-o", out, src, "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+        _stamp(out, [src], flags)
+    return out
+
+
 def build_all(force=False):
-    return [build_host(force), build_device(force), build_device_debug(force), build_oracle(force), build_emu(force), build_cli(force)]
+    return [build_host(force), build_device(force), build_device_debug(force), build_oracle(force), build_emu(force), build_cli(force),
+            build_mock_rccl(force)]
 
 
 if __name__ == "__main__":

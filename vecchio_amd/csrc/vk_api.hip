@@ -79,9 +79,13 @@ struct RcclApi {
 const RcclApi &rccl_api() {
     static const RcclApi api = [] {
         RcclApi a;
+#ifdef VK_DEBUG_LIB
+        // the DEBUG build may be pointed at a test double (tests/mock_rccl: the gather's orchestration on a one-GPU box)
+        if (const char *e = getenv("VK_RCCL_LIB")) a.handle = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+#endif
         for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            a.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (a.handle) break;
+            a.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!a.handle) { const char *e = dlerror(); a.why = std::string("librccl.so could not be loaded: ") + (e ? e : "?"); return a; }
 #define VK_RCCL_SYM(field, sym) a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.handle, #sym))
@@ -1082,6 +1086,9 @@ int vk_scene_create_multi(const vk_scene_desc *desc, const int *devices, int n_d
             // one communicator rank per DEVICE: a device listed twice (the one-GPU test shape) cannot take part
             bool distinct = true;
             for (int a = 0; a < n_devices; a++) for (int b = a + 1; b < n_devices; b++) distinct = distinct && devices[a] != devices[b];
+#ifdef VK_DEBUG_LIB
+            if (getenv("VK_RCCL_ALLOW_DUPLICATE_DEVICES")) distinct = true;      // (with the test double of VK_RCCL_LIB only: real RCCL refuses)
+#endif
             const RcclApi &R = rccl_api();
             if (!R.ok()) fprintf(stderr, "vecchio_amd: VK_SCENE_RCCL_GATHER: %s; the tile slabs travel by peer copies\n", R.why.c_str());
             else if (!distinct) fprintf(stderr, "vecchio_amd: VK_SCENE_RCCL_GATHER: a device is listed more than once (one communicator rank per "
