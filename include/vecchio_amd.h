@@ -355,7 +355,10 @@ enum {
     VK_TREE_HANDED_OVER = 0,        /* the tree of the description, item for item */
     VK_TREE_REBUILT_PROVEN = 1,     /* exact re-treeing with grown gates: results proven to be the handed-over tree's */
     VK_TREE_REBUILT_EMPIRICAL = 2,  /* exact re-treeing without them (VK_SCENE_EMPIRICAL_TREES): measured, not proven */
-    VK_TREE_REBUILT_FAST = 3        /* VK_SCENE_FAST_ACCEL */
+    VK_TREE_REBUILT_FAST = 3,       /* VK_SCENE_FAST_ACCEL */
+    VK_TREE_REBUILT_NEAR = 4        /* exact re-treeing, near form (ABI 6): every sphere behind its own box, a segment's result taken only
+                                       where no sphere beyond that box's trusted radius can matter, else walked again on the tree handed
+                                       over: proven like VK_TREE_REBUILT_PROVEN; worlds whose leaf units are too long for that form */
 };
 int vk_scene_get_info(const vk_scene *scene, vk_scene_info *out);
 

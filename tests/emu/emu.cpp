@@ -32,6 +32,7 @@ static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string
     if (const char *e = getenv("VK_T_PAD")) opt.t_pad = (float)atof(e);
     if (const char *e = getenv("VK_GATE_PROOF")) opt.want_proof = e[0] != '0';      // (as the library: prefers, does not allow)
     if (const char *e = getenv("VK_EMPIRICAL_TREES")) opt.allow_empirical = e[0] == '1';
+    if (const char *e = getenv("VK_NEAR_FORM")) opt.near_form = e[0] != '0';
     return linearize(desc, LS, err, opt);
 }
 // EMU_GLOBAL_VARIANT=1: scenes of spheres only as the device runs them from GLOBAL memory (unfused box test; exact re-treeing with both
@@ -39,11 +40,12 @@ static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string
 static bool global_variant() { const char *e = getenv("EMU_GLOBAL_VARIANT"); return e && e[0] == '1'; }
 static DScene scene_view(const LinearScene &LS, std::vector<DItem> &both) {
     DScene S = LS.host_view();
-    if (global_variant() && !LS.ref_items.empty()) {
+    if ((global_variant() || LS.near_form) && !LS.ref_items.empty()) {      // (the near form: both trees in items[], as the device keeps it)
         uint32_t ws = 0;
         both = LS.combined_items(ws);
         S.items = both.data(); S.n_items = (uint32_t)both.size(); S.n_world_items = (uint32_t)both.size(); S.walk_start = ws;
         S.ref_items = nullptr; S.n_ref_items = 0;
+        if (const char *e = getenv("EMU_PRIMARY_REF")) S.primary_ref = e[0] == '1';       // (what vk_api.hip decides per frame)
     }
     return S;
 }
@@ -66,7 +68,8 @@ static void trace_one(const DScene &S, const GlobalMem &M0, const RenderConsts &
     Mem M; static_cast<GlobalMem &>(M) = M0;
     Lane L;
     start_sample<F, Mem>(L, S, C, pixel % C.width, pixel / C.width, sample);
-    bool on_ref = false;      // the segment just walked was walked on the tree as handed over
+    // the segment just walked was walked on the tree as handed over (a primary ray under DScene::primary_ref starts there: begin_segment)
+    bool on_ref = S.primary_ref != 0u && S.walk_start != 0u && spheres_only<F>();
     for (;;) {
         uint64_t nb = 0, ns = 0;
         while (traversing(L)) {
@@ -181,7 +184,7 @@ static const uint32_t FPDF = VKF_ALL_SCENE | VKF_INTEG_PDF;
 static void trace_any(const DScene &S, const GlobalMem &M, const RenderConsts &C, uint32_t integrator, uint32_t pixel, uint32_t sample,
     V3 &rgb, uint32_t &draws, uint64_t *steps) {
     bool lean = S.features == 0u && !getenv("VK_FORCE_FULL_VARIANT");
-    const bool glob = lean && global_variant();
+    const bool glob = lean && (global_variant() || S.walk_start != 0u);      // (both trees in items[]: the device's global-memory form)
     if (integrator == VK_INTEGRATOR_PDF) {
         if (glob) trace_one<VKF_INTEG_PDF, GlobalMem>(S, M, C, pixel, sample, rgb, draws, steps);
         else if (lean) trace_one<VKF_INTEG_PDF, FusedMem>(S, M, C, pixel, sample, rgb, draws, steps);
@@ -576,6 +579,111 @@ uint64_t emu_div_by_a_model(uint64_t cases, uint64_t seed, float worst[4]) {
     return bad;
 }
 
+// Part E (round 5): the NEAR form's three claims (vk_linearize.cpp rt_grow_near), each attacked with the kernel's own arithmetic.
+// mode 0 — NEAR GATES ARE SOUND: a sphere of radius R (1e-2 .. 1e2, anywhere within 1e3 of the coordinate origin), its own box grown by
+//   1.25 eta(rho_near) + 8 ulps, rho_near = sqrt(0.8 growth R^2 / kappa) - R as the lineariser sets it; rays from rho <= rho_near (inside the
+//   sphere, on it, grazing it where it touches its box, nearly parallel to a face).  Every ray with a candidate must pass the gate with
+//   tmax = next(t) (1 + RT_PAD_NEAR).          counts = {candidates, gates closed}
+// mode 1 — REACH: rays from rho_near .. 1e5 away that pass the sphere at up to 1 + 64 u (rho / R)^2 radii (where false roots live): a
+//   candidate's distance t |d| must exceed reach = rho_near - (R + eta(rho_near)).          counts = {candidates, t |d| <= reach}
+// mode 2 — CLEARANCE: centres anywhere in a box, a ray that satisfies segment_unsafe's clear test for that box (outward slope >= 2e-3 on
+//   an axis, its point at distance `reach` clear_margin outside): no sphere with rho > rho_near may hold a candidate.  Spheres are placed
+//   where they hurt: on the box's face the ray leaves through, under the ray.          counts = {rays x spheres tried, candidates}
+int emu_near_form_claims(int mode, uint64_t n, uint64_t seed, uint64_t counts[2], float viol[12]) {
+    Lcg g(seed);
+    counts[0] = counts[1] = 0;
+    const double U24 = 1.0 / 16777216.0;
+    for (uint64_t it = 0; it < n; it++) {
+        const float R = (float)g.log_uni(1e-2, 1e2);
+        const double rho_near = std::sqrt(0.8 * RT_NEAR_GROWTH * (double)R * R / RT_KAPPA) - R;
+        const double eta_near = rt_eta(rho_near, R);
+        const double reach = (rho_near - (R + eta_near)) * (1.0 - 1e-5);
+        float c[3] = {(float)((g.uni() - .5) * 2e3), (float)((g.uni() - .5) * 2e3), (float)((g.uni() - .5) * 2e3)};
+        if (mode == 2) { c[0] = (float)((g.uni() - .5) * 1e3); c[1] = 0.2f; c[2] = (float)((g.uni() - .5) * 1e3); }
+        double maxabs = 0.0;
+        for (int a = 0; a < 3; a++) maxabs = std::max(maxabs, std::fabs((double)c[a]) + R);
+        const float gg = std::nextafter((float)(1.25 * eta_near + 8.0 * U24 * maxabs), INFINITY);
+        DItem G; memset(&G, 0, sizeof(G));
+        G.mnx = std::nextafter(c[0] - R - gg, -INFINITY); G.mxx = std::nextafter(c[0] + R + gg, INFINITY);
+        G.mny = std::nextafter(c[1] - R - gg, -INFINITY); G.mxy = std::nextafter(c[1] + R + gg, INFINITY);
+        G.mnz = std::nextafter(c[2] - R - gg, -INFINITY); G.mxz = std::nextafter(c[2] + R + gg, INFINITY);
+        V3 o, d;
+        if (mode <= 1) {
+            const double rho = mode == 0 ? (g.uni() < 0.2 ? g.uni() * 1.2 * R : g.log_uni(0.5 * R, rho_near * 0.9999))
+                                         : g.log_uni(rho_near * 1.0001, 1e5 * R);
+            double od[3] = {g.uni() - .5, g.uni() - .5, g.uni() - .5};
+            if (g.uni() < 0.3) od[(int)(g.uni() * 3) % 3] *= 1e-4;                  // origins in a face's plane
+            const double on = std::sqrt(od[0] * od[0] + od[1] * od[1] + od[2] * od[2]) + 1e-30;
+            o = v3((float)(c[0] + od[0] / on * rho), (float)(c[1] + od[1] / on * rho), (float)(c[2] + od[2] / on * rho));
+            // aim at a point at (1 + delta) R from the centre, on a direction perpendicular to the origin's
+            double e1[3] = {g.uni() - .5, g.uni() - .5, g.uni() - .5};
+            if (g.uni() < 0.5) { const int a = (int)(g.uni() * 3) % 3; e1[0] = e1[1] = e1[2] = 0.0; e1[a] = 1.0; }      // the box's face centres
+            const double dp = (e1[0] * od[0] + e1[1] * od[1] + e1[2] * od[2]) / (on * on);
+            for (int a = 0; a < 3; a++) e1[a] -= dp * od[a];
+            const double en = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) + 1e-30;
+            const double wob = 64.0 * U24 * (rho / R) * (rho / R) + 1e-6;
+            const double delta = (g.uni() < 0.5 ? 1.0 : -1.0) * g.log_uni(1e-9, 1.0) * (mode == 0 ? 0.05 : wob) + (g.uni() < 0.2 ? -g.uni() : 0.0);
+            double dd[3];
+            for (int a = 0; a < 3; a++) dd[a] = c[a] + e1[a] / en * R * (1.0 + delta) - o.x * (a == 0) - o.y * (a == 1) - o.z * (a == 2);
+            const double dn = std::sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]) + 1e-30, dl = g.log_uni(1e-2, 1e2);
+            d = v3((float)(dd[0] / dn * dl), (float)(dd[1] / dn * dl), (float)(dd[2] / dn * dl));
+            {   // ordinary rays only (set_space): the others are never trusted
+                const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+                if (!(ax > 1e-6f && ax < 1e6f && ay > 1e-6f && ay < 1e6f && az > 1e-6f && az < 1e6f)) continue;
+            }
+            float t;
+            if (!candidate(c, R, o, d, t)) continue;
+            counts[0]++;
+            bool bad;
+            if (mode == 0) {
+                const double ox = (double)o.x - c[0], oy = (double)o.y - c[1], oz = (double)o.z - c[2];
+                if (std::sqrt(ox * ox + oy * oy + oz * oz) > rho_near) { counts[0]--; continue; }       // (after rounding of o)
+                bad = !slab_exact(G, o, d, T_MIN, nextafter_up(t) * (1.0f + (float)RT_PAD_NEAR));
+            } else {
+                bad = (double)t * std::sqrt((double)length2(d)) <= reach;
+            }
+            if (bad) {
+                if (counts[1] == 0 && viol) { const float v[12] = {c[0], c[1], c[2], R, o.x, o.y, o.z, d.x, d.y, d.z, t, (float)rho_near}; memcpy(viol, v, sizeof(v)); }
+                counts[1]++;
+            }
+            continue;
+        }
+        // ---- mode 2: a slab of centres y = 0.2, |x|, |z| <= 500; the ray leaves upwards (or sideways) as segment_unsafe's test demands
+        const float clo[3] = {-500.0f, 0.2f, -500.0f}, chi[3] = {500.0f, 0.2f, 500.0f};
+        const double b = std::sqrt(RT_KAPPA);
+        // (mode 3: the control — a quarter of the margin: candidates DO appear, the test has teeth)
+        const float margin = (float)((((double)R * (1.0 + b) + b * reach) / (1.0 - b) * 1.02 + 64.0 * U24 * (500.0 + reach)) * (mode == 3 ? 0.25 : 1.0));
+        const double slope = g.log_uni(2.0e-3, 1.0);
+        double dir[3] = {g.uni() - .5, 0.0, g.uni() - .5};
+        const double hn = std::sqrt(dir[0] * dir[0] + dir[2] * dir[2]) + 1e-30;
+        dir[0] /= hn; dir[2] /= hn; dir[1] = slope / std::sqrt(1.0 - std::min(slope * slope, 0.999999));      // dy / |d| = slope
+        const double dn = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]), dl = g.log_uni(1e-2, 1e2);
+        // origin such that the point at distance reach is just clear: y(reach) = chi_y + margin (1 + tiny)
+        const double y0 = 0.2 + (double)margin * (1.0 + g.log_uni(1e-6, 1.0)) - reach * dir[1] / dn;
+        o = v3((float)((g.uni() - .5) * 800.0), (float)y0, (float)((g.uni() - .5) * 800.0));
+        d = v3((float)(dir[0] / dn * dl), (float)(dir[1] / dn * dl), (float)(dir[2] / dn * dl));
+        {   // segment_unsafe's own test, on the +y axis
+            const float dnf = sqrtf(length2(d)), k = (float)reach / dnf, py = o.y + d.y * k;
+            if (!(d.y >= 2.0e-3f * dnf && py - chi[1] >= margin)) continue;
+        }
+        // spheres under the ray, beyond rho_near: where the ray passes closest to the slab of centres
+        for (int k = 0; k < 4; k++) {
+            const double s = g.log_uni(std::max(reach, 1e-3), 2e3);                       // distance along the ray
+            float cc[3] = {(float)(o.x + dir[0] / dn * s + (g.uni() - .5) * 2.0 * R), 0.2f, (float)(o.z + dir[2] / dn * s + (g.uni() - .5) * 2.0 * R)};
+            if (!(cc[0] >= clo[0] && cc[0] <= chi[0] && cc[2] >= clo[2] && cc[2] <= chi[2])) continue;
+            const double ox = (double)o.x - cc[0], oy = (double)o.y - cc[1], oz = (double)o.z - cc[2];
+            if (std::sqrt(ox * ox + oy * oy + oz * oz) <= rho_near) continue;             // (a near sphere: behind a sound gate)
+            counts[0]++;
+            float t;
+            if (candidate(cc, R, o, d, t)) {
+                if (counts[1] == 0 && viol) { const float v[12] = {cc[0], cc[1], cc[2], R, o.x, o.y, o.z, d.x, d.y, d.z, t, (float)rho_near}; memcpy(viol, v, sizeof(v)); }
+                counts[1]++;
+            }
+        }
+    }
+    return 0;
+}
+
 // closest hit of ONE segment as the device decides it (rebuilt walk, segment_unsafe, the tree as handed over where needed):
 // out = {T, best_prim (bits), 1 if the tree as handed over decided}
 int emu_hit(const vk_scene_desc *desc, const float o[3], const float d[3], float out[3]) {
@@ -585,7 +693,7 @@ int emu_hit(const vk_scene_desc *desc, const float o[3], const float d[3], float
     if (LS.features != 0u) { g_err = "emu_hit: scenes of spheres only"; return VK_ERR_UNSUPPORTED; }
     std::vector<DItem> both;
     DScene S = scene_view(LS, both);
-    const bool glob = global_variant();
+    const bool glob = global_variant() || S.walk_start != 0u;
     auto run = [&](auto mem_tag) {
         using Mem = decltype(mem_tag);
         Mem M; static_cast<GlobalMem &>(M) = GlobalMem{S.items, S.spheres, S.sphere_mat, S.boxes};

@@ -33,6 +33,7 @@ def lem(emu, built):
     lib.emu_gate_soundness.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_float, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     lib.emu_hit.argtypes = [C.POINTER(ffi.SceneDesc), ffi.F3, ffi.F3, C.POINTER(C.c_float * 3)]
     lib.emu_own_gate_soundness.argtypes = [C.c_uint64, C.c_uint64, C.c_float, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    lib.emu_near_form_claims.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
     lib.emu_own_gate_ray.argtypes = [C.c_float * 3, C.c_float, C.c_float * 3, C.c_float * 3, C.c_float, C.c_double, C.POINTER(C.c_float)]
     return lib
 
@@ -208,3 +209,27 @@ def test_the_ray_that_refuted_them(lem):
     assert rc == 0
     has, t, passes, growth = list(out)
     assert has == 1.0 and abs(t - 41.5557022) < 1e-4 and passes == 0.0 and 1e-4 < growth < 1e-3
+
+
+# ---- part E: the NEAR form (round 5; vk_linearize.cpp rt_grow_near, docs/gate_lemma.md section 7).  Own-box gates are sound for origins
+# NEAR the sphere (part D refutes them for far ones); a segment's result is taken only if its hit lies within `reach` of its origin, or
+# if the ray runs clear of every small sphere beyond that — the two conditions under which no far sphere can hold a closer candidate.
+@pytest.mark.parametrize("mode,what", [(0, "near gates closed"), (1, "candidates of far spheres within reach"),
+                                       (2, "candidates of far spheres under a ray that tested clear")])
+def test_near_form_claims(mode, what, lem):
+    total = [0, 0]
+    for seed in (1, 2, 3):
+        cnt = (C.c_uint64 * 2)(); v = (C.c_float * 12)()
+        lem.emu_near_form_claims(mode, 1_500_000, seed, cnt, v)
+        total[0] += cnt[0]; total[1] += cnt[1]
+        assert cnt[1] == 0, f"{what}: {cnt[1]} of {cnt[0]}, e.g. centre {list(v[0:3])} R {v[3]} o {list(v[4:7])} d {list(v[7:10])} t {v[10]} rho_near {v[11]}"
+    print(f"{what}: 0 of {total[0]}")
+    assert total[0] > 200_000
+
+
+def test_the_clearance_margin_is_not_idle(lem):
+    """control of mode 2: with a quarter of the clearance margin, rays that "test clear" do pass spheres close enough for candidates"""
+    cnt = (C.c_uint64 * 2)(); v = (C.c_float * 12)()
+    lem.emu_near_form_claims(3, 1_500_000, 1, cnt, v)
+    print(f"a quarter of the margin: {cnt[1]} candidates in {cnt[0]} pairs")
+    assert cnt[1] > 100

@@ -114,9 +114,9 @@ def test_retree_cuts_the_box_tests_of_the_headline_scene(emu, built):
     assert steps_x < 0.8 * steps_r
 
 
-@pytest.mark.parametrize("variant", ["lds", "global"])
+@pytest.mark.parametrize("form,variant", [("empirical", "lds"), ("empirical", "global"), ("near", "global")])
 @pytest.mark.parametrize("grid_half", [40, 130])
-def test_exact_retree_gives_the_handed_over_trees_samples_on_far_small_spheres(grid_half, variant, oracle, emu, built, monkeypatch):
+def test_exact_retree_gives_the_handed_over_trees_samples_on_far_small_spheres(grid_half, form, variant, oracle, emu, built, monkeypatch):
     """The default for a scene of spheres only (vk_trace.h segment_unsafe): a tree rebuilt over the reference's leaf units; where the
     winner of a segment could depend on the visiting order, the tree as handed over decides — for the whole sample (scenes the device
     stages in LDS: a second launch) or for that segment (scenes it traverses from global memory: both trees in one array).  Thousands
@@ -129,9 +129,16 @@ def test_exact_retree_gives_the_handed_over_trees_samples_on_far_small_spheres(g
     cam = hs.next_camera()
     p = hs.params(72, 2, 50, seed=5)
     img_o, ps_o = oracle.render_samples(hs.desc, cam, p)                    # the recursive restatement on the tree handed over
-    # (BVHNode::new's units are long on this scene: grown gates would be too dear, so the default walks the tree as handed over and the
-    # rebuilt walk is the opt-in, empirical form: include/vecchio_amd.h)
-    hs.desc.contents.flags = ffi.VK_SCENE_EMPIRICAL_TREES
+    # BVHNode::new's units are long on this scene: grown UNIT gates would be too dear.  The default is the NEAR form (round 5: own-box
+    # gates, a segment's result taken where its hit lies within reach or the ray runs clear of the field, else walked again on the tree as
+    # handed over; primary rays start there, as the library decides for this camera); the unit form with bare gates is the opt-in,
+    # empirical one (include/vecchio_amd.h; VK_GATE_PROOF=0 prefers it)
+    if form == "empirical":
+        hs.desc.contents.flags = ffi.VK_SCENE_EMPIRICAL_TREES
+        monkeypatch.setenv("VK_GATE_PROOF", "0")
+    else:
+        hs.desc.contents.flags = 0
+        monkeypatch.setenv("EMU_PRIMARY_REF", "1")
     emu_ffi.take_redo_stats()
     img_x, ps_x, steps_x, info = emu.render_samples(hs.desc, cam, p)
     redone, segments = emu_ffi.take_redo_stats()

@@ -321,13 +321,14 @@ void plan_residency(vk_scene *s, size_t hot) {
     // 4+4+3+3 on the four SIMDs and the second workgroup does not fit beside the first — but they can be 16 + 12: a 1024-thread
     // workgroup (4 per SIMD) and a 768-thread one (3 per SIMD), from two concurrent launches.  Needs two LDS copies of the scene.
     s->dual_launch = false;
-    if (spheres_only && !s->env.no_lds_scene && s->env.max_waves_per_cu == 0 && !getenv("VK_NO_DUAL_LAUNCH") &&
+    // (the near form of exact re-treeing walks a failed segment again in place: both trees in items[], i.e. global memory)
+    if (spheres_only && !s->env.no_lds_scene && !s->host->near_form && s->env.max_waves_per_cu == 0 && !getenv("VK_NO_DUAL_LAUNCH") &&
         2 * hot + 28 * pw <= LDS_PER_CU) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = 768; s->wgs_per_cu = 2;      // (the single-launch shape: probe, STATS, tiny frames)
         s->dual_launch = true;
         return;
     }
-    if (best_waves >= cap && !s->env.no_lds_scene) {
+    if (best_waves >= cap && !s->env.no_lds_scene && !s->host->near_form) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = best_wg * 64; s->wgs_per_cu = best_n;
     } else {
         // 28 (sphere-only: seven 4-wave workgroups, 7 waves/SIMD) or 24 waves per CU
@@ -512,6 +513,25 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     (void)hipGetLastError();      // (hipErrorNotReady of a query is not an error of this call)
     s->frame_no++;
     bool exact = s->exact && !s->want_phase_stats && s->frame_no >= s->exact_resume;     // (the diagnostic builds have no second launch)
+    // The near form: primary rays start on the tree as handed over when the camera (its lens included) is farther than `reach` from every
+    // sphere — their walk on the rebuilt tree could not stand (vk_trace.h begin_segment).  Decided from the box around the small spheres
+    // and the surfaces of the few big ones; when in doubt: no.
+    if (s->host->near_form && A.S.walk_start != 0u && s->host->n_big != 0xFFFFFFFFu) {
+        const LinearScene &H = *s->host;
+        const double reach = (double)H.reach + (double)fabsf(cam->lens_radius) * 1.5 + 1e-3 * (double)H.reach;
+        double d2 = 0.0;
+        for (int k = 0; k < 3; k++) {
+            const double o = cam->origin[k], e = o < H.small_lo[k] ? H.small_lo[k] - o : (o > H.small_hi[k] ? o - H.small_hi[k] : 0.0);
+            d2 += e * e;
+        }
+        bool far_from_all = d2 > reach * reach;
+        for (uint32_t b = 0; b < H.n_big && far_from_all; b++) {
+            double q = 0.0;
+            for (int k = 0; k < 3; k++) q += ((double)cam->origin[k] - H.big[b][k]) * ((double)cam->origin[k] - H.big[b][k]);
+            far_from_all = fabs(sqrt(q) - (double)H.big[b][3]) > reach;
+        }
+        A.S.primary_ref = far_from_all ? 1u : 0u;
+    }
     A.C.cam = *cam;
     A.C.width = p->width; A.C.height = p->height; A.C.spp = p->samples_per_pixel; A.C.max_depth = p->max_depth;
     A.C.seed = p->seed; A.C.integrator = p->integrator; A.C.background = p->background;
@@ -926,8 +946,9 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
         // (`exact`).  Traversed from global memory: both trees in one array, early segments are walked again in place (DScene::walk_start).
         const DScene hv = H.host_view();
         D.t_pad = hv.t_pad; D.gate_scale = hv.gate_scale; D.tmin_gate = hv.tmin_gate;
-        for (int k = 0; k < 3; k++) D.trust_c0[k] = hv.trust_c0[k];
+        for (int k = 0; k < 3; k++) { D.trust_c0[k] = hv.trust_c0[k]; D.small_clo[k] = hv.small_clo[k]; D.small_chi[k] = hv.small_chi[k]; }
         D.trust_r0sq = hv.trust_r0sq;
+        D.reach = hv.reach; D.clear_margin = hv.clear_margin;
         if (s->lds_bytes != 0) {
             UP(items, items); UP(ref_items, ref_items);
             D.n_ref_items = hv.n_ref_items; D.n_items = (uint32_t)H.items.size(); D.n_world_items = H.world_items;
@@ -999,6 +1020,7 @@ int linearize_desc(const vk_scene_desc *desc, std::shared_ptr<const LinearScene>
     if (const char *e = getenv("VK_GATE_GROW")) opt.gate_grow = e[0] != '0';
     if (const char *e = getenv("VK_T_PAD")) opt.t_pad = (float)atof(e);
     if (const char *e = getenv("VK_EMPIRICAL_TREES")) opt.allow_empirical = e[0] == '1';
+    if (const char *e = getenv("VK_NEAR_FORM")) opt.near_form = e[0] != '0';
 #endif
     int rc = linearize(desc, *h, err, opt);
     if (rc != VK_OK) return fail(rc, err);
@@ -1133,7 +1155,7 @@ int vk_scene_get_info(const vk_scene *s, vk_scene_info *out) {
     out->device_bytes = b;
     out->lds_bytes = one->lds_bytes;
     out->features = pick_variant(one);
-    out->tree = !H.ref_items.empty() ? (H.proven ? VK_TREE_REBUILT_PROVEN : VK_TREE_REBUILT_EMPIRICAL)
+    out->tree = !H.ref_items.empty() ? (H.near_form ? VK_TREE_REBUILT_NEAR : (H.proven ? VK_TREE_REBUILT_PROVEN : VK_TREE_REBUILT_EMPIRICAL))
                                      : (!H.tie_rank.empty() ? VK_TREE_REBUILT_FAST : VK_TREE_HANDED_OVER);
     out->gather = s->parts.empty() ? VK_GATHER_NONE : (s->comms.empty() ? VK_GATHER_PEER_COPY : VK_GATHER_RCCL);
     out->tree_suspended_frames = 0;

@@ -131,6 +131,18 @@ struct DScene {
     // rebuilt tree], walk_start = index of the rebuilt tree's first item (0: items[] is one tree).  A segment whose winner is early
     // is then walked again right away, from item 0, instead of its sample being queued (vk_trace.h begin_segment).
     uint32_t walk_start;
+    // The near form of exact re-treeing (vk_linearize.cpp rt_grow_near): a segment walked on the rebuilt tree stands only if its hit lies
+    // within `reach` of its origin (T |d| <= reach; a miss never does): then every sphere that could hold a closer candidate is within
+    // the radius its own-box gate is sound for.  0 = no such condition (the unit form, whose gates are sound for the whole ball).
+    float reach;
+    // ... or if, beyond `reach`, the ray runs CLEAR of every small sphere: on some axis it moves outward (|d_a| / |d| >= 2e-3) and its
+    // point at distance `reach` is already clear_margin outside the box [small_clo, small_chi] of the small spheres' centres.  A sphere
+    // farther than rho_near then has no candidate at all (its hit points lie within sqrt(R^2 + 32 u (rho + R)^2) of its centre: a
+    // margin that grows by 1.4e-3 per unit travelled), so a MISS, or a far hit on a big sphere, stands too.
+    float small_clo[3], small_chi[3], clear_margin;
+    // ... and, decided per frame by the host: primary rays (depth 1) start on the tree as handed over (the camera is farther than
+    // `reach` from everything, so their rebuilt walk could never stand)
+    uint32_t primary_ref;
 };
 
 }  // namespace vkd

@@ -756,7 +756,12 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                 if (S.t_pad > 0.0f) {      // (wave-uniform)
                     Mem M = make_mem<F, LDS_SCENE>(S, lds_items);
                     bool on_ref = false;   // the lane has just walked the tree as handed over: its answer stands
-                    if constexpr (!LDS_SCENE) on_ref = (__float_as_uint(cold[CF_DEPTH * 64 + lane]) >> 31) != 0u;
+                    if constexpr (!LDS_SCENE) {
+                        // (bit 31 of the depth word: walked again after an early winner; depth 1 under DScene::primary_ref: a primary ray
+                        // that begin_segment started on the tree as handed over)
+                        const uint32_t dw = __float_as_uint(cold[CF_DEPTH * 64 + lane]);
+                        on_ref = (dw >> 31) != 0u || (S.primary_ref != 0u && S.walk_start != 0u && dw == 1u);
+                    }
                     if (is_shade && !on_ref) early = segment_unsafe<F, Mem>(L, S, M);
                 }
             }

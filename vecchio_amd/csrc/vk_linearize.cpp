@@ -37,6 +37,9 @@ DScene LinearScene::host_view() const {
     s.tmin_gate = s.t_pad > 0.0f ? 0.001f * s.gate_scale * 0.999999f : 0.001f;     // (T_MIN of vk_trace.h)
     for (int k = 0; k < 3; k++) s.trust_c0[k] = trust_c0[k];
     s.trust_r0sq = trust_r0 * trust_r0;
+    s.reach = ref_items.empty() ? 0.0f : reach; s.primary_ref = 0u;
+    for (int k = 0; k < 3; k++) { s.small_clo[k] = small_clo[k]; s.small_chi[k] = small_chi[k]; }
+    s.clear_margin = clear_margin;
     s.fast_div = 1u;
     for (const DSphere &sp : spheres)
         if (!(fabsf(sp.cx) < 1073741824.0f && fabsf(sp.cy) < 1073741824.0f && fabsf(sp.cz) < 1073741824.0f && fabsf(sp.r) < 1073741824.0f)) s.fast_div = 0u;
@@ -421,7 +424,10 @@ struct Builder {
         float mn[3], mx[3], c[3];
         uint32_t dref; uint32_t dref2 = 0; uint32_t parent = 0xFFFFFFFFu; uint32_t rank = 0, rank2 = 0;
     };
-    bool retree_units = false;              // LinearizeOptions::retree == 2 (see rt_collect)
+    bool retree_units = false;              // LinearizeOptions::retree == 2: exact re-treeing asked for (see rt_collect)
+    // ... collected object by object, every sphere behind its OWN box (the near form, rt_grow_near), instead of unit by unit
+    bool own_gates = false;
+    bool unit_form() const { return retree_units && !own_gates; }
     static float rt_half_area(const float *mn, const float *mx) {
         float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
         return dx * dy + dy * dz + dz * dx;
@@ -517,7 +523,8 @@ struct Builder {
                 const vk_bvh_node &pn = d->bvh[fr.parent];
                 for (int a = 0; a < 3; a++)
                     if (!(pn.bb_min[a] <= o.mn[a] && o.mx[a] <= pn.bb_max[a]) && o.mn[a] <= o.mx[a]) { ok = false; return true; }
-                memcpy(o.mn, pn.bb_min, 12); memcpy(o.mx, pn.bb_max, 12);
+                // unit form: the object is gated by its unit's box; near form: by its own (grown in rt_grow_near)
+                if (unit_form()) { memcpy(o.mn, pn.bb_min, 12); memcpy(o.mx, pn.bb_max, 12); }
             }
             for (int a = 0; a < 3; a++) {
                 // NaN / inverted box: keep the reference's tree
@@ -527,7 +534,7 @@ struct Builder {
             uint32_t dref;
             if (!convert_object(fr.ref, fr.flip, inst, dref)) return false;
             // the second object child of the same node (they are visited back to back): same unit
-            if (retree_units && !out.empty() && out.back().parent == fr.parent && out.back().dref2 == 0u) {
+            if (unit_form() && !out.empty() && out.back().parent == fr.parent && out.back().dref2 == 0u) {
                 out.back().dref2 = dref; out.back().rank2 = rank++;
                 continue;
             }
@@ -555,14 +562,14 @@ struct Builder {
                 memcpy(mn, objs[fr.begin].mn, 12); memcpy(mx, objs[fr.begin].mx, 12);
                 for (size_t i = fr.begin + 1; i < fr.end; i++) rt_grow(mn, mx, objs[i].mn, objs[i].mx);
                 it.mnx = mn[0]; it.mny = mn[1]; it.mnz = mn[2]; it.mxx = mx[0]; it.mxy = mx[1]; it.mxz = mx[2];
-                if (retree_units && len == 1) {          // one unit per leaf: the reference's box, its objects in the reference's order
+                if (unit_form() && len == 1) {          // one unit per leaf: the reference's box, its objects in the reference's order
                     it.w0 = objs[fr.begin].dref; it.w1 = objs[fr.begin].dref2;
                     L.items.push_back(it);
                     L.n_prims += it.w1 ? 2u : 1u;
                     st.pop_back();
                     continue;
                 }
-                if (!retree_units && len <= 2) {
+                if (!unit_form() && len <= 2) {
                     size_t a = fr.begin, b = fr.begin + 1;
                     // the larger object first: its hit's t culls more of what follows in this fixed-order walk
                     if (len == 2 && rt_half_area(objs[b].mn, objs[b].mx) > rt_half_area(objs[a].mn, objs[a].mx)) std::swap(a, b);
@@ -746,6 +753,131 @@ struct Builder {
         return true;
     }
 
+    // ---- The NEAR form of exact re-treeing (round 5; docs/gate_lemma.md section 7).  Where the unit form is not eligible (long units),
+    // every sphere is gated by its OWN box — which section 6 of that note refutes for origins FAR from the sphere, and which the near
+    // rule alone proves for origins NEAR it: for rho = |o - c| <= rho_near the point of an accepted root lies within eta(rho_near) of the
+    // sphere, hence inside the own box grown by g >= 1.25 eta(rho_near), and the gate passes for every T above the candidate.  No
+    // far-origin rule, no padding to speak of (RT_PAD_NEAR only pads the test's own rounding).  The gates of spheres farther than rho_near
+    // from a ray's origin are NOT sound — so the walk's result is only taken when no such sphere can matter:
+    //   REACH LEMMA.  The point H of a candidate lies within D(rho) = sqrt(R^2 + 32 u (rho + R)^2) <= R + eta(rho) of the centre, and
+    //   |H - o| = cand |d|, so rho <= cand |d| + D(rho); rho - D(rho) is increasing in rho (D' <= sqrt(32 u) < 1).  Hence a sphere with
+    //   rho > rho_near has cand |d| > rho_near - D(rho_near) >= reach := rho_near - max (R + eta(rho_near)): if the rebuilt walk ends with
+    //   T_f |d| <= reach, every sphere holding a candidate below T_f is within rho_near of the origin, i.e. behind a sound gate, and
+    //   Lemma 1's induction gives T_f <= T*; the safe-winner test (Lemma 2) does the rest as in the unit form.
+    // A segment whose hit lies beyond `reach` — or that misses — is walked again on the tree as handed over (vk_trace.h segment_unsafe;
+    // both trees in items[]: scenes traversed from global memory).  Spheres whose gate can be made sound for EVERY origin of the trusted
+    // ball at a growth of RT_NEAR_BIG_GROWTH of their radius (a ground sphere: eta(rho) ~ 4 u rho^2 / R is small against a large R) are
+    // "big": always sound, they do not enter `reach`.  The ball reaches RT_NEAR_BALL extents of the ordinary spheres; segments that
+    // start outside it are the handed-over tree's from the start (begin_segment).
+    float near_reach = 0.0f, near_radius = 0.0f;
+    bool near_form = false, allow_near = true;
+    bool rt_grow_near(std::vector<RtObj> &objs) {
+        if (objs.empty()) return false;
+        const size_t n = objs.size();
+        const double U24 = 1.0 / 16777216.0;
+        std::vector<float> cx(n), cy(n), cz(n), rr(n);
+        for (size_t i = 0; i < n; i++) {
+            const DSphere &sp = L.spheres[VKD_INDEX(objs[i].dref)];
+            cx[i] = sp.cx; cy[i] = sp.cy; cz[i] = sp.cz; rr[i] = sp.r;
+            if (!(std::fabs(cx[i]) < 1073741824.0f && std::fabs(cy[i]) < 1073741824.0f && std::fabs(cz[i]) < 1073741824.0f &&
+                  rr[i] < 1073741824.0f && rr[i] > 9.0949470177292824e-13f)) return false;      // (rt_eta's range, as rt_grow_units)
+        }
+        auto median = [](std::vector<float> v) { std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end()); return (double)v[v.size() / 2]; };
+        RtDomain dom;
+        dom.c0[0] = median(cx); dom.c0[1] = median(cy); dom.c0[2] = median(cz);
+        const double r_med = median(rr);
+        std::vector<double> dist(n);
+        double ext = 0.0, far_side = 0.0;
+        for (size_t i = 0; i < n; i++) {
+            const double dx = cx[i] - dom.c0[0], dy = cy[i] - dom.c0[1], dz = cz[i] - dom.c0[2];
+            dist[i] = std::sqrt(dx * dx + dy * dy + dz * dz);
+            far_side = std::max(far_side, dist[i] + (double)rr[i]);
+            if ((double)rr[i] <= 64.0 * r_med) ext = std::max(ext, dist[i] + (double)rr[i]);
+        }
+        if (!(ext > 0.0) || !std::isfinite(far_side)) return false;
+        // The ball only bounds what the BIG spheres' gates must cover (a small sphere's soundness is a matter of rho_near): as far as the far
+        // side of every sphere — paths inside a ground sphere start there — when the big spheres stay big at that size, else
+        // RT_NEAR_BALL extents
+        dom.r0 = std::max(RT_NEAR_BALL * ext, 1.05 * far_side);
+        {
+            bool ok_wide = true;
+            for (size_t i = 0; i < n && ok_wide; i++) {
+                const bool big_narrow = 1.25 * rt_eta(dist[i] + RT_NEAR_BALL * ext, rr[i]) <= RT_NEAR_BIG_GROWTH * (double)rr[i];
+                const bool big_wide = 1.25 * rt_eta(dist[i] + dom.r0, rr[i]) <= RT_NEAR_BIG_GROWTH * (double)rr[i];
+                ok_wide = big_wide || !big_narrow;
+            }
+            if (!ok_wide) dom.r0 = RT_NEAR_BALL * ext;
+        }
+        // big spheres: sound for every origin of the ball (the near rule at the ball's far end) at a small relative growth
+        std::vector<char> big(n, 0);
+        std::vector<double> grow(n, 0.0);
+        std::vector<float> small_r;
+        for (size_t i = 0; i < n; i++) {
+            const double g_all = 1.25 * rt_eta(dist[i] + dom.r0, rr[i]);
+            if (g_all <= RT_NEAR_BIG_GROWTH * (double)rr[i]) { big[i] = 1; grow[i] = g_all; } else small_r.push_back(rr[i]);
+        }
+        double rho_near = INFINITY, reach = INFINITY;
+        if (!small_r.empty()) {
+            // eta(rho_near) = 0.8 RT_NEAR_GROWTH R for the median small sphere
+            const double rs = median(small_r);
+            rho_near = std::sqrt(0.8 * RT_NEAR_GROWTH * rs * rs / RT_KAPPA) - rs;
+            double worst = 0.0;
+            for (size_t i = 0; i < n; i++) {
+                if (big[i]) continue;
+                const double eta = rt_eta(rho_near, rr[i]);
+                grow[i] = 1.25 * eta;
+                if (grow[i] > 0.25 * (double)rr[i]) return false;          // (a sphere far smaller than the rest: its gate would be dear)
+                worst = std::max(worst, (double)rr[i] + eta);
+            }
+            reach = rho_near - worst;
+            if (!(reach > 8.0 * rs)) return false;                          // (not even the neighbours are within reach)
+        }
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        double r_max_small = 0.0;
+        L.n_big = 0;
+        for (size_t i = 0; i < n; i++) {
+            double maxabs = 0.0;
+            for (int a = 0; a < 3; a++) maxabs = std::max(maxabs, std::max(std::fabs((double)objs[i].mn[a]), std::fabs((double)objs[i].mx[a])));
+            const float g = std::nextafter((float)(grow[i] + 8.0 * U24 * maxabs), INFINITY);
+            if (big[i]) {
+                if (L.n_big != 0xFFFFFFFFu) {
+                    if (L.n_big < 8u) { float *b = L.big[L.n_big++]; b[0] = cx[i]; b[1] = cy[i]; b[2] = cz[i]; b[3] = rr[i]; }
+                    else L.n_big = 0xFFFFFFFFu;
+                }
+            } else {
+                for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], objs[i].mn[a]); hi[a] = fmaxf(hi[a], objs[i].mx[a]); }
+                const float cc[3] = {cx[i], cy[i], cz[i]};
+                for (int a = 0; a < 3; a++) { clo[a] = fminf(clo[a], cc[a]); chi[a] = fmaxf(chi[a], cc[a]); }
+                r_max_small = std::max(r_max_small, (double)rr[i]);
+            }
+            if (gate_grow)
+                for (int a = 0; a < 3; a++) {
+                    objs[i].mn[a] = std::nextafter(objs[i].mn[a] - g, -INFINITY); objs[i].mx[a] = std::nextafter(objs[i].mx[a] + g, INFINITY);
+                    if (!std::isfinite(objs[i].mn[a]) || !std::isfinite(objs[i].mx[a])) return false;
+                }
+            for (int a = 0; a < 3; a++) objs[i].c[a] = 0.5f * objs[i].mn[a] + 0.5f * objs[i].mx[a];
+        }
+        for (int a = 0; a < 3; a++) { L.small_lo[a] = lo[a]; L.small_hi[a] = hi[a]; L.trust_c0[a] = (float)dom.c0[a];
+            L.small_clo[a] = clo[a]; L.small_chi[a] = chi[a]; }
+        {   // CLEARANCE (DScene::clear_margin).  A far sphere's hit point P(s) satisfies |P(s) - c| <= D <= (R (1 + b) + b s) / (1 - b),
+            // b = sqrt(32 u) = 1.381e-3 (from D <= R + b (rho + R) and rho <= s + D), and s >= reach: the margin at s = reach, with 2 % and
+            // the boxes' rounding on top; beyond, an outward slope of 2e-3 outruns the margin's 1.383e-3
+            const double b = std::sqrt(RT_KAPPA);
+            double maxabs = 0.0;
+            for (int a = 0; a < 3; a++) maxabs = std::max(maxabs, std::max(std::fabs((double)clo[a]), std::fabs((double)chi[a])));
+            const double m = (r_max_small * (1.0 + b) + b * (std::isfinite(reach) ? reach : 0.0)) / (1.0 - b);
+            L.clear_margin = small_r.empty() ? 0.0f : (float)(m * 1.02 + 64.0 * U24 * (maxabs + (std::isfinite(reach) ? reach : 0.0)));
+        }
+        L.trust_r0 = (float)(dom.r0 * (1.0 - 1e-6));
+        near_reach = std::isfinite(reach) ? (float)(reach * (1.0 - 1e-5)) : 3.0e38f;
+        near_radius = std::isfinite(rho_near) ? (float)rho_near : 3.0e38f;
+        if (getenv("VK_RETREE_DEBUG"))
+            fprintf(stderr, "vecchio_amd: exact re-treeing, near form: %zu spheres (%zu small, own boxes grown by 1.25 eta(%g)), reach %g; trusted "
+                "ball centre (%g %g %g) radius %g\n", n, small_r.size(), rho_near, (double)near_reach, dom.c0[0], dom.c0[1], dom.c0[2], dom.r0);
+        return true;
+    }
+
     // dense object id of a dref for the tie table: [spheres][rects][boxes][lists]
     uint32_t tie_id(uint32_t dref) const {
         uint32_t k = VKD_KIND(dref), i = VKD_INDEX(dref);
@@ -784,6 +916,7 @@ struct Builder {
         std::vector<RtObj> objs;
         objs.reserve((size_t)simple_count[root]);
         bool ok = true;
+        own_gates = false;
         if (!rt_collect(root, flip, inst, objs, ok)) return false;
         std::vector<RtObj> all_units;           // (every unit has its tie ranks, the long ones too)
         if (ok && retree_units) {
@@ -792,6 +925,17 @@ struct Builder {
             // (the test switches gate_grow = false / another padding leave a tree the lemma does not cover: it is never reported as proven
             // and, like any unproven tree, takes VK_SCENE_EMPIRICAL_TREES)
             if (!gate_grow || gate_pad != RT_PAD) proven = false;
+            if (!proven && want_proof && allow_near && gate_grow && gate_pad == RT_PAD) {
+                // the unit form is not eligible (long units): the near form, sphere by sphere (a world of spheres converts nothing but
+                // sphere references: collecting again has no side effect to undo)
+                std::vector<RtObj> own;
+                own.reserve((size_t)simple_count[root]);
+                own_gates = true;
+                bool ok2 = true;
+                if (!rt_collect(root, flip, inst, own, ok2)) return false;
+                if (ok2 && rt_grow_near(own)) { objs.swap(own); all_units.clear(); proven = true; near_form = true; }
+                else own_gates = false;
+            }
             if (!proven && proof_only) ok = false;      // (no VK_SCENE_EMPIRICAL_TREES: the tree as handed over rather than an unproven one)
         }
         const std::vector<RtObj> &sized = all_units.empty() ? objs : all_units;
@@ -1057,6 +1201,7 @@ int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, con
     b.gate_grow = opt.gate_grow;
     b.want_proof = opt.want_proof;
     b.proof_only = !(desc && (desc->flags & VK_SCENE_EMPIRICAL_TREES) != 0u) && !opt.allow_empirical;
+    b.allow_near = opt.near_form;
     if (opt.t_pad > 0.0f && opt.t_pad < 1.0f) b.gate_pad = opt.t_pad;
     if (!b.run()) return b.status == VK_OK ? VK_ERR_BAD_ARG : b.status;
     out.world_items = b.world_items;
@@ -1086,7 +1231,8 @@ int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, con
         // Empirical form: the units' boxes as handed over and RT_PAD_EMPIRICAL (1/256 lost one sample in 1.9 G on the stress scene, 1/16
         // none in 12 G: DESIGN.md section 5), every origin "trusted".
         out.proven = b.proven;
-        out.t_pad = (float)(b.proven ? RT_PAD : RT_PAD_EMPIRICAL);
+        out.near_form = b.near_form; out.reach = b.near_form ? b.near_reach : 0.0f; out.near_radius = b.near_radius;
+        out.t_pad = (float)(b.near_form ? RT_PAD_NEAR : (b.proven ? RT_PAD : RT_PAD_EMPIRICAL));
         if (opt.t_pad > 0.0f && opt.t_pad < 1.0f) out.t_pad = opt.t_pad;
         if (!b.proven) { out.trust_c0[0] = out.trust_c0[1] = out.trust_c0[2] = 0.0f; out.trust_r0 = INFINITY; }
     }

@@ -38,7 +38,17 @@ struct LinearScene {
     uint32_t tie_base_rect = 0, tie_base_box = 0, tie_base_list = 0;
     std::vector<DItem> ref_items; float t_pad = 0.0f;      // see DScene
     float trust_c0[3] = {0.0f, 0.0f, 0.0f}; float trust_r0 = 0.0f;      // exact re-treeing: the trusted origin ball (DScene)
-    bool proven = false;        // exact re-treeing with grown gates: the gate lemma applies (vk_linearize.cpp rt_grow_units)
+    bool proven = false;        // exact re-treeing with grown gates: the gate lemma applies (vk_linearize.cpp rt_grow_units / rt_grow_near)
+    // The NEAR form of exact re-treeing (vk_linearize.cpp rt_grow_near): every sphere gated by its OWN box, sound for origins within
+    // near_radius of it; a segment's result stands only if its hit lies within `reach` of its origin (DScene::reach).  Needs both trees in
+    // items[] (a scene traversed from global memory): vk_api.hip keeps such a scene out of LDS.
+    bool near_form = false;
+    float reach = 0.0f, near_radius = 0.0f;
+    // for the per-frame "primary rays straight to the tree as handed over" decision (vk_api.hip): the box around the small spheres and
+    // the always-sound big ones (centre, radius), at most 8 (more: n_big = ~0 and the decision is "no")
+    float small_lo[3] = {0, 0, 0}, small_hi[3] = {0, 0, 0};     // (box around the small spheres' surfaces)
+    float small_clo[3] = {0, 0, 0}, small_chi[3] = {0, 0, 0}, clear_margin = 0.0f;      // DScene: the box of their CENTRES, the clearance
+    uint32_t n_big = 0; float big[8][4] = {};
     uint32_t features = 0;
     uint32_t n_prims = 0;
     uint32_t world_items = 0;   // items[0, world_items) is the world BVH; instance child ranges follow
@@ -65,6 +75,7 @@ struct LinearizeOptions {
     float t_pad = 0.0f;
     bool want_proof = true;     // VK_GATE_PROOF=0: the empirical form even where the proven one is cheap (comparisons; an unproven tree
                                 // still takes VK_SCENE_EMPIRICAL_TREES in the description)
+    bool near_form = true;      // VK_NEAR_FORM=0 (emulator / debug library): no near form where the unit form is not eligible
     bool allow_empirical = false;   // tests/emu and the debug library, VK_EMPIRICAL_TREES=1: as vk_scene_desc.flags & VK_SCENE_EMPIRICAL_TREES
 };
 
@@ -79,6 +90,13 @@ struct RtDomain { double c0[3]; double r0; };
 constexpr double RT_KAPPA = 1.0 / 524288.0;       // 2^-19 = 32 * 2^-24
 constexpr double RT_PAD = 1.0 / 4.0;              // LinearScene::t_pad of exact re-treeing with grown gates (the proven form)
 constexpr double RT_PAD_EMPIRICAL = 1.0 / 16.0;   // ... with the units' boxes as handed over (the empirical form)
+// the near form: a small sphere's own box grows by RT_NEAR_GROWTH of the median small radius (which fixes the radius within which its
+// gate is sound: eta(near_radius) = 0.8 RT_NEAR_GROWTH R, near_radius ~ 144 R); a sphere whose gate can be sound for EVERY origin of the
+// trusted ball at RT_NEAR_BIG_GROWTH of its radius is "big" and never restricts a segment; the ball reaches RT_NEAR_BALL extents
+constexpr double RT_PAD_NEAR = 1.0 / 64.0;
+constexpr double RT_NEAR_GROWTH = 0.05;
+constexpr double RT_NEAR_BIG_GROWTH = 0.01;
+constexpr double RT_NEAR_BALL = 4.0;
 constexpr double RT_MAX_AREA_GROWTH = 0.05;       // the grown gates are used when they cost at most this much leaf surface area
 constexpr double RT_LONG_GROWTH = 0.25;           // a unit whose gate would grow by more than this (in units of its smaller radius) is "long"
 inline double rt_eta(double rho, double R) { return RT_KAPPA * (rho + R) * (rho + R) / R; }

@@ -396,7 +396,9 @@ VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time, bool 
     L.wo = o; L.wd = d; L.time = time;
     // (both trees in items[]: a segment that starts outside the trusted ball is the handed-over tree's from the start — segment_unsafe
     // would send it there after a wasted walk)
-    if (TIGHT && S.walk_start != 0u) redo = redo || origin_untrusted(S, o);      // (TIGHT: the sphere-only variants)
+    // ... and so is, in the near form, a PRIMARY ray when the host found the camera farther than `reach` from everything
+    // (DScene::primary_ref: its rebuilt walk could never stand)
+    if (TIGHT && S.walk_start != 0u) redo = redo || origin_untrusted(S, o) || (S.primary_ref != 0u && L.depth == 1u);      // (TIGHT: the sphere-only variants)
     set_space<FUSED, TIGHT>(L, o, d, redo ? 1.0f : S.gate_scale);
     L.i = redo ? 0u : (S.walk_start << ISHIFT); L.end = S.n_world_items << ISHIFT; L.pend = 0; L.pend2 = 0; L.cur_inst = -1;
     L.T = INFINITY; L.best_prim = 0; L.best_inst = -1; L.best_aux = 0.0f;
@@ -605,6 +607,24 @@ VK_HD bool segment_unsafe(const Lane &L, const DScene &S, const Mem &M) {
     const bool outside = origin_untrusted(S, L.o);
     if (S.walk_start != 0u && outside) return false;       // (begin_segment: this one WAS walked on the tree as handed over)
     bool unsafe = outside || !(L.xnan == L.xnan);
+    // the near form (DScene::reach > 0): own-box gates are sound for the spheres within rho_near of the origin only, and only a hit
+    // within `reach` of the origin guarantees that no other sphere could hold a closer candidate (vk_linearize.cpp rt_grow_near: the
+    // reach lemma); a miss (T = +inf) never stands
+    if (S.reach > 0.0f) {
+        const float dn = sqrtf(L.a);
+        bool stands = L.T * dn <= S.reach;
+        if (!stands) {
+            // ... or the ray runs clear of every small sphere beyond `reach` (DScene::clear_margin): then no sphere outside rho_near holds a
+            // candidate at all, and what the walk found — a miss, a far hit on an always-sound sphere — is complete
+            const float k = S.reach / dn;
+            const V3 p = v3(L.o.x + L.d.x * k, L.o.y + L.d.y * k, L.o.z + L.d.z * k);
+            const float sl = 2.0e-3f * dn;
+            stands = (L.d.x >= sl && p.x - S.small_chi[0] >= S.clear_margin) || (L.d.x <= -sl && S.small_clo[0] - p.x >= S.clear_margin) ||
+                     (L.d.y >= sl && p.y - S.small_chi[1] >= S.clear_margin) || (L.d.y <= -sl && S.small_clo[1] - p.y >= S.clear_margin) ||
+                     (L.d.z >= sl && p.z - S.small_chi[2] >= S.clear_margin) || (L.d.z <= -sl && S.small_clo[2] - p.z >= S.clear_margin);
+        }
+        unsafe = unsafe || !stands;
+    }
     if (L.best_prim != 0u) {
         const DSphere sp = M.sphere(VKD_INDEX(L.best_prim));
         const float bx0 = sp.cx - sp.r, bx1 = sp.cx + sp.r, by0 = sp.cy - sp.r, by1 = sp.cy + sp.r, bz0 = sp.cz - sp.r, bz1 = sp.cz + sp.r;
