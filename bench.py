@@ -21,9 +21,10 @@ Also reported in the same JSON line:
                same workload (N = 1 only)
   handed_over_tree  one step of the same workload with VK_SCENE_REFERENCE_TREE (the tree of the description, nothing rebuilt), verified
                the same way: what the rebuilt tree of exact re-treeing is worth (N = 1 only)
-  config.also  one step each of the other BASELINE configs at full size (C4, C3, C5 — C5 as the default walks it, i.e. on the tree as
-               handed over, AND with VK_SCENE_EMPIRICAL_TREES), of C2 in the empirical form and with VK_SCENE_FAST_ACCEL, each verified
-               the same way (N = 1 only; --no-also skips them)
+  config.also  one step each of the other BASELINE configs at full size (C4, C3, C5 — C5 on the tree as handed over, as the default
+               walks it (the near form of exact re-treeing) AND with VK_SCENE_EMPIRICAL_TREES), of C2 in the empirical form and with
+               VK_SCENE_FAST_ACCEL, each verified the same way and, on a rebuilt tree, compared bit for bit with the same workload's frame
+               on the tree as handed over (N = 1 only; --no-also skips them)
 """
 import argparse
 import ctypes as C
@@ -304,7 +305,8 @@ def main():
     cores = usable_cpus()          # threads for the oracle: affinity mask capped by the cgroup quota
 
     TREE_NAMES = {0: "handed over", 1: "rebuilt, proven (exact re-treeing with grown gates)", 2: "rebuilt, empirical (VK_SCENE_EMPIRICAL_TREES)",
-                  3: "rebuilt object by object (VK_SCENE_FAST_ACCEL)"}
+                  3: "rebuilt object by object (VK_SCENE_FAST_ACCEL)",
+                  4: "rebuilt, proven (exact re-treeing, near form: own-box gates + reach / clearance, failed segments walked again as handed over)"}
 
     def run_workload(name, steps, warmup, spp_override=0, want_cpu=False, bvh="reference", fast_accel=False, live_traffic=False,
                      handed_over_tree=False, empirical=False):
@@ -338,8 +340,14 @@ def main():
         cam = hs.next_camera()
         params = hs.params(width, spp, depth, seed=2, tile_rank=rank, tile_world=world)   # render seed 2
         height = params.height
-        # scene upload: outside the timed region
-        ds = DeviceScene(hs.desc, devices=in_lib_devices) if args.in_library else DeviceScene(hs.desc, device=dev_index)
+        # scene upload: outside the timed region.  (The empirical leg: VK_GATE_PROOF=0 makes the library prefer the empirical unit form to
+        # the proven forms, which VK_SCENE_EMPIRICAL_TREES alone only allows where neither applies; read at scene creation.)
+        if empirical:
+            os.environ["VK_GATE_PROOF"] = "0"
+        try:
+            ds = DeviceScene(hs.desc, devices=in_lib_devices) if args.in_library else DeviceScene(hs.desc, device=dev_index)
+        finally:
+            os.environ.pop("VK_GATE_PROOF", None)
         info = ds.info()
         fb = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
         # the gathered frame on rank 0: f32 (y up), or with --rgb8 the reference's output stage fused into the exchange (bytes through
@@ -421,10 +429,16 @@ def main():
             if info.tree != 0 and sphere_only:
                 import emu_ffi
                 os.environ["EMU_GLOBAL_VARIANT"] = "0" if info.lds_bytes else "1"
+                # (the near form: C5's camera is 109 above the field, farther than `reach` from every sphere, so the library starts the
+                # primary rays on the tree as handed over — vk_api.hip, DScene::primary_ref — and so does the count of its walk)
+                os.environ["EMU_PRIMARY_REF"] = "1" if (info.tree == 4 and name == "C5") else "0"
+                if empirical:
+                    os.environ["VK_GATE_PROOF"] = "0"
                 emu_ffi.take_visit_counts()
                 pe = hs.params(cw, 1, depth, seed=2)
                 _, ps_e, _, _ = emu_ffi.render_samples(hs.desc, cam, pe, threads=cores)
                 nb, ns = emu_ffi.take_visit_counts()
+                os.environ.pop("VK_GATE_PROOF", None)
                 ne = float(ps_e.shape[0])
                 walked = {"box_tests": nb / ne, "sphere_tests": ns / ne, "oracle_box_tests": c["n_aabb"] / float(c["samples"]),
                           "oracle_sphere_tests": c["n_sphere"] / float(c["samples"])}
@@ -591,8 +605,10 @@ def main():
             exact_mismatch.append(f"{args.workload} default ({main_res['tree']}) differs from the tree as handed over in "
                                   f"{int((main_res['_frame'] != frames[args.workload]).any(axis=2).sum())} pixels")
     if n_gpus == 1 and not args.no_also and args.workload == "C2" and not args.spp:
-        for name, spp_o, fa, ho, emp in (("C4", 0, False, False, False), ("C3", 0, False, False, False), ("C5", 0, False, False, False),
-                                         ("C5", 0, False, False, True), ("C2", 0, False, False, True), ("C2", 0, True, False, False)):
+        # (C5: on the tree as handed over first — the frame its default, the near form of exact re-treeing, must equal)
+        for name, spp_o, fa, ho, emp in (("C4", 0, False, False, False), ("C3", 0, False, False, False), ("C5", 0, False, True, False),
+                                         ("C5", 0, False, False, False), ("C5", 0, False, False, True), ("C2", 0, False, False, True),
+                                         ("C2", 0, True, False, False)):
             r = run_workload(name, 1, 0, spp_o, fast_accel=fa, handed_over_tree=ho, empirical=emp)
             frame = r.pop("_frame")
             ident = None
@@ -600,7 +616,7 @@ def main():
                 frames.setdefault(name, frame)                # (walked as handed over: C5's default, C3, C4)
             elif name in frames:
                 ident = bool(np.array_equal(frame.view(np.uint32), frames[name].view(np.uint32)))
-                if not ident and r["tree_code"] == 1:
+                if not ident and r["tree_code"] in (1, 4):
                     exact_mismatch.append(f"{r['label']} ({r['tree']}) differs from the tree as handed over")
             del frame
             also.append({"workload": r["label"], "tree": r["tree"], "Msamples_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": 1,

@@ -186,11 +186,16 @@ typedef struct vk_scene_desc {
  * the region the bound was derived for — the tree as handed over decides (the segment is walked again, or its sample is rendered by
  * a second launch).  That this reproduces BVHNode::hit is a THEOREM given the bound (the "gate lemma"; forward error analysis, K < 30
  * against the 32 used; tests/test_gate_lemma.py attacks it with 10^7 adversarial rays).  The grown boxes are used only where they are
- * cheap (vk_scene_info.tree == VK_TREE_REBUILT_PROVEN: the InOneWeekend scene, +28 % throughput); a world whose reference tree has
- * very long leaf boxes (BVHNode::new's random axes on the 1 M-sphere stress scene) is walked as handed over.
+ * cheap (vk_scene_info.tree == VK_TREE_REBUILT_PROVEN: the InOneWeekend scene, +28 % throughput).  A world whose reference tree has
+ * very long leaf boxes (BVHNode::new's random axes on the 1 M-sphere stress scene) is walked in the NEAR form instead (ABI 6,
+ * VK_TREE_REBUILT_NEAR): every sphere behind its OWN box, which is sound for ray origins within ~144 radii of the sphere; a segment's
+ * result is taken only if its hit lies within that reach of its origin or the ray provably runs clear of every small sphere beyond it,
+ * and every other segment is walked again on the tree as handed over (both trees stay in device memory; docs/gate_lemma.md section 7;
+ * +80 % on that scene).  A world for which neither form applies is walked as handed over.
  * VK_SCENE_REFERENCE_TREE: walk the tree handed over and nothing else.
- * VK_SCENE_EMPIRICAL_TREES: allow the rebuilt tree also where the grown boxes would be too dear — with the units' boxes as handed
- * over and the closest hit so far padded by 1/16 instead.  NOT proven: a hit that precedes its unit's box entry by more than 1/16 and,
+ * VK_SCENE_EMPIRICAL_TREES: allow the rebuilt tree also where NEITHER proven form applies (since ABI 6: worlds with a sphere far
+ * smaller than the rest; the environment's VK_GATE_PROOF=0 prefers it to the proven forms, for comparisons) — with the units' boxes as
+ * handed over and the closest hit so far padded by 1/16 instead.  NOT proven: a hit that precedes its unit's box entry by more than 1/16 and,
  * in the reference's visiting order only, wins against a hit inside that gap is missed.  It takes a ray that grazes a sphere where the
  * sphere touches its box, within ~1e-5 of parallel to that face of a long box; tests/test_gate_lemma.py constructs one and shows the
  * wrong result.  Measured on natural frames: 0 differing pixels in 12.6 G samples (40 worlds, profiles/r03/exact_retree_seeds.log);
