@@ -33,6 +33,7 @@ static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string
     if (const char *e = getenv("VK_GATE_PROOF")) opt.want_proof = e[0] != '0';      // (as the library: prefers, does not allow)
     if (const char *e = getenv("VK_EMPIRICAL_TREES")) opt.allow_empirical = e[0] == '1';
     if (const char *e = getenv("VK_NEAR_FORM")) opt.near_form = e[0] != '0';
+    if (const char *e = getenv("VK_UNIT_FORM")) opt.unit_form = e[0] != '0';
     return linearize(desc, LS, err, opt);
 }
 // EMU_GLOBAL_VARIANT=1: scenes of spheres only as the device runs them from GLOBAL memory (unfused box test; exact re-treeing with both

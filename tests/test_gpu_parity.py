@@ -23,7 +23,7 @@ BUILDER_SCENES = ["random_spheres_iow", "cornell_box", "final_scene", "random_sp
 
 
 def device_samples(ds, cam, p):
-    lib = ffi.load_device_lib()
+    lib = ds._lib             # (a scene belongs to the library that created it: the product, or the debug build of the same sources)
     lib.vk_debug_render_samples.restype = C.c_int
     lib.vk_debug_render_samples.argtypes = [C.c_void_p, C.POINTER(ffi.Camera), C.POINTER(ffi.RenderParams), C.c_void_p, C.c_void_p]
     img = np.zeros((p.height, p.width, 3), np.float32)

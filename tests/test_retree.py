@@ -19,6 +19,8 @@ from test_emu_parity import compare
 from test_fuzz_scenes import Gen, _union
 from vecchio_amd import ffi
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 class Crowd(Gen):
     def crowd(self, n):
@@ -227,13 +229,20 @@ def test_exact_retree_on_sphere_crowds_is_the_handed_over_tree_per_sample(seed, 
     desc.contents.flags = ffi.VK_SCENE_REFERENCE_TREE
     img_r, ps_r, steps_r, info_r = emu.render_samples(desc, cam, p)
     compare(ps_o, ps_r, img_o, img_r)
-    # the default (grown gates where they are cheap, else the tree as handed over) and the opt-in empirical form
-    for flags in (0, ffi.VK_SCENE_EMPIRICAL_TREES):
+    # the default (the unit form with grown gates where it is cheap, else the near form, else the tree as handed over), the near form
+    # forced where the unit form would do (VK_UNIT_FORM=0: with and without primary rays starting on the tree as handed over), and the
+    # opt-in empirical form
+    for flags, env in ((0, {}), (0, {"VK_UNIT_FORM": "0"}), (0, {"VK_UNIT_FORM": "0", "EMU_PRIMARY_REF": "1"}),
+                       (ffi.VK_SCENE_EMPIRICAL_TREES, {"VK_GATE_PROOF": "0"})):
         desc.contents.flags = flags
+        for k in ("VK_UNIT_FORM", "EMU_PRIMARY_REF", "VK_GATE_PROOF"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         for variant in ("0", "1"):                           # the device's LDS form (whole samples again) and its global-memory form
             monkeypatch.setenv("EMU_GLOBAL_VARIANT", variant)
             img_x, ps_x, steps_x, info_x = emu.render_samples(desc, cam, p)
-            assert np.array_equal(ps_x.view(np.uint32), ps_r.view(np.uint32)), (flags, variant,
+            assert np.array_equal(ps_x.view(np.uint32), ps_r.view(np.uint32)), (flags, env, variant,
                 int((ps_x.view(np.uint32) != ps_r.view(np.uint32)).any(axis=1).sum()))
 
 
@@ -277,6 +286,35 @@ def test_exact_retree_on_sphere_crowds_on_the_gpu(seed, device, oracle):
         ds.close()
     assert np.array_equal(imgs[0].view(np.uint32), imgs[2].view(np.uint32))
     assert np.array_equal(imgs[1].view(np.uint32), imgs[2].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_near_form_forced_on_sphere_crowds_on_the_gpu(device, oracle):
+    """the near form (vk_linearize.cpp rt_grow_near) where the unit form would have done: VK_UNIT_FORM=0 is honoured by the DEBUG build
+    of the library only, and read at scene creation, so this runs in a child process: twelve crowds (four of them with coincident
+    spheres), every sample the oracle's and the handed-over tree's"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "import oracle_ffi as O\n"
+            "from test_retree import SphereCrowd\n"
+            "from test_gpu_parity import compare_samples, device_samples\n"
+            "from vecchio_amd import DeviceScene, ffi\n"
+            "dbg = ffi.load_debug_lib(); trees = []\n"
+            "for seed in list(range(8)) + [40, 41, 42, 43]:\n"
+            "    desc, cam, p = SphereCrowd(7200 + seed, nasty=seed >= 40).build()\n"
+            "    img_o, ps_o = O.render_samples(desc, cam, p)\n"
+            "    out = []\n"
+            "    for flags in (0, ffi.VK_SCENE_REFERENCE_TREE):\n"
+            "        desc.contents.flags = flags\n"
+            "        ds = DeviceScene(desc, lib=dbg); trees.append(ds.info().tree)\n"
+            "        img_d, ps_d = device_samples(ds, cam, p); compare_samples(ps_o, ps_d, img_o, img_d); out.append(ps_d); ds.close()\n"
+            "    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32)), seed\n"
+            "print('TREES', sorted(set(trees)))\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VK_UNIT_FORM="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "TREES" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert str(ffi.VK_TREE_REBUILT_NEAR) in r.stdout.split("TREES")[1], r.stdout
 
 
 @pytest.mark.gpu

@@ -302,6 +302,9 @@ void plan_residency(vk_scene *s, size_t hot) {
     const size_t pw = per_wave_lds_bytes(pick_variant(s));
     uint32_t best_waves = 0, best_wg = 0, best_n = 0;
     const bool spheres_only = pick_variant(s) == 0u;
+    // the near form of exact re-treeing walks a failed segment again in place: both trees in items[], i.e. global memory (staged in LDS,
+    // where a failed segment requeues its whole sample, it loses 11 % on the InOneWeekend scene against the unit form: round 5)
+    const bool near_needs_global = s->host->near_form;
     const uint32_t per_simd = spheres_only ? s->sphere_waves : (pick_variant(s) == (uint32_t)VKF_ALL_SCENE ? (uint32_t)VK_ALL_MINW
                                                                                                            : (uint32_t)VK_CORNELL_MINW);   // = MINW of launch_variant
     uint32_t cap = 4 * per_simd;                                             // waves per CU the variant's register budget admits
@@ -322,13 +325,13 @@ void plan_residency(vk_scene *s, size_t hot) {
     // workgroup (4 per SIMD) and a 768-thread one (3 per SIMD), from two concurrent launches.  Needs two LDS copies of the scene.
     s->dual_launch = false;
     // (the near form of exact re-treeing walks a failed segment again in place: both trees in items[], i.e. global memory)
-    if (spheres_only && !s->env.no_lds_scene && !s->host->near_form && s->env.max_waves_per_cu == 0 && !getenv("VK_NO_DUAL_LAUNCH") &&
+    if (spheres_only && !s->env.no_lds_scene && !near_needs_global && s->env.max_waves_per_cu == 0 && !getenv("VK_NO_DUAL_LAUNCH") &&
         2 * hot + 28 * pw <= LDS_PER_CU) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = 768; s->wgs_per_cu = 2;      // (the single-launch shape: probe, STATS, tiny frames)
         s->dual_launch = true;
         return;
     }
-    if (best_waves >= cap && !s->env.no_lds_scene && !s->host->near_form) {
+    if (best_waves >= cap && !s->env.no_lds_scene && !near_needs_global) {
         s->lds_bytes = (uint32_t)hot; s->wg_threads = best_wg * 64; s->wgs_per_cu = best_n;
     } else {
         // 28 (sphere-only: seven 4-wave workgroups, 7 waves/SIMD) or 24 waves per CU
@@ -1021,6 +1024,7 @@ int linearize_desc(const vk_scene_desc *desc, std::shared_ptr<const LinearScene>
     if (const char *e = getenv("VK_T_PAD")) opt.t_pad = (float)atof(e);
     if (const char *e = getenv("VK_EMPIRICAL_TREES")) opt.allow_empirical = e[0] == '1';
     if (const char *e = getenv("VK_NEAR_FORM")) opt.near_form = e[0] != '0';
+    if (const char *e = getenv("VK_UNIT_FORM")) opt.unit_form = e[0] != '0';
 #endif
     int rc = linearize(desc, *h, err, opt);
     if (rc != VK_OK) return fail(rc, err);

@@ -770,7 +770,7 @@ struct Builder {
     // "big": always sound, they do not enter `reach`.  The ball reaches RT_NEAR_BALL extents of the ordinary spheres; segments that
     // start outside it are the handed-over tree's from the start (begin_segment).
     float near_reach = 0.0f, near_radius = 0.0f;
-    bool near_form = false, allow_near = true;
+    bool near_form = false, allow_near = true, allow_unit = true;
     bool rt_grow_near(std::vector<RtObj> &objs) {
         if (objs.empty()) return false;
         const size_t n = objs.size();
@@ -821,16 +821,33 @@ struct Builder {
             // eta(rho_near) = 0.8 RT_NEAR_GROWTH R for the median small sphere
             const double rs = median(small_r);
             rho_near = std::sqrt(0.8 * RT_NEAR_GROWTH * rs * rs / RT_KAPPA) - rs;
-            double worst = 0.0;
+            double worst = 0.0, grow_sum = 0.0;
+            size_t n_small = 0;
             for (size_t i = 0; i < n; i++) {
                 if (big[i]) continue;
                 const double eta = rt_eta(rho_near, rr[i]);
                 grow[i] = 1.25 * eta;
-                if (grow[i] > 0.25 * (double)rr[i]) return false;          // (a sphere far smaller than the rest: its gate would be dear)
+                // (eta goes with 1 / R: a sphere far smaller than the median grows by more than its own radius — which is still little
+                // against its neighbours' boxes as long as it stays below the MEDIAN radius, and as long as such spheres are few: the mean
+                // growth is held to 15 % of the median radius; beyond that the world is not eligible)
+                grow_sum += grow[i]; n_small++;
+                if (grow[i] > rs) {
+                    if (getenv("VK_RETREE_DEBUG")) fprintf(stderr, "vecchio_amd: near form: a sphere of radius %g among spheres of median radius %g "
+                        "would grow by %g: not eligible\n", (double)rr[i], rs, grow[i]);
+                    return false;
+                }
                 worst = std::max(worst, (double)rr[i] + eta);
             }
             reach = rho_near - worst;
-            if (!(reach > 8.0 * rs)) return false;                          // (not even the neighbours are within reach)
+            if (grow_sum > 0.15 * rs * (double)n_small) {
+                if (getenv("VK_RETREE_DEBUG")) fprintf(stderr, "vecchio_amd: near form: mean growth %g of a median radius of %g: not eligible\n",
+                    grow_sum / (double)n_small, rs);
+                return false;
+            }
+            if (!(reach > 8.0 * rs)) {                                      // (not even the neighbours are within reach)
+                if (getenv("VK_RETREE_DEBUG")) fprintf(stderr, "vecchio_amd: near form: reach %g for a median radius of %g: not eligible\n", reach, rs);
+                return false;
+            }
         }
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -921,7 +938,7 @@ struct Builder {
         std::vector<RtObj> all_units;           // (every unit has its tie ranks, the long ones too)
         if (ok && retree_units) {
             all_units = objs;
-            proven = want_proof && rt_grow_units(objs);
+            proven = want_proof && allow_unit && rt_grow_units(objs);
             // (the test switches gate_grow = false / another padding leave a tree the lemma does not cover: it is never reported as proven
             // and, like any unproven tree, takes VK_SCENE_EMPIRICAL_TREES)
             if (!gate_grow || gate_pad != RT_PAD) proven = false;
@@ -1201,7 +1218,7 @@ int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, con
     b.gate_grow = opt.gate_grow;
     b.want_proof = opt.want_proof;
     b.proof_only = !(desc && (desc->flags & VK_SCENE_EMPIRICAL_TREES) != 0u) && !opt.allow_empirical;
-    b.allow_near = opt.near_form;
+    b.allow_near = opt.near_form; b.allow_unit = opt.unit_form;
     if (opt.t_pad > 0.0f && opt.t_pad < 1.0f) b.gate_pad = opt.t_pad;
     if (!b.run()) return b.status == VK_OK ? VK_ERR_BAD_ARG : b.status;
     out.world_items = b.world_items;

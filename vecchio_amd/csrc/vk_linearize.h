@@ -76,6 +76,7 @@ struct LinearizeOptions {
     bool want_proof = true;     // VK_GATE_PROOF=0: the empirical form even where the proven one is cheap (comparisons; an unproven tree
                                 // still takes VK_SCENE_EMPIRICAL_TREES in the description)
     bool near_form = true;      // VK_NEAR_FORM=0 (emulator / debug library): no near form where the unit form is not eligible
+    bool unit_form = true;      // VK_UNIT_FORM=0 (emulator / debug library): the near form even where the unit form is eligible (comparisons)
     bool allow_empirical = false;   // tests/emu and the debug library, VK_EMPIRICAL_TREES=1: as vk_scene_desc.flags & VK_SCENE_EMPIRICAL_TREES
 };
 
