@@ -93,6 +93,32 @@ def test_stress_scenes_are_walked_in_the_near_form_by_default(device):
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (name, int((img != ref).any(axis=2).sum()))
 
 
+@pytest.mark.parametrize("lookfrom,lookat,aperture", [
+    ((3.0, 0.6, 2.0), (10.0, 0.3, 9.0), 0.05),          # inside the field, a sphere's height above the ground: primary rays on the rebuilt tree
+    ((0.0, 40.0, 0.0), (1.0, 0.0, 1.0), 0.0),           # straight down from 40: just beyond reach, primary rays start as handed over
+    ((26.0, 4.0, 6.0), (0.0, 0.0, 0.0), 0.1),           # the InOneWeekend view, doubled
+    ((0.0, -300.0, 0.0), (30.0, 0.0, 30.0), 0.0),       # INSIDE the ground sphere, looking up at the field from below
+    ((900.0, 15.0, 0.0), (0.0, 0.0, 0.0), 0.0)])        # grazing, from far outside the field: long walks past thousands of spheres
+def test_near_form_from_other_viewpoints(lookfrom, lookat, aperture, device):
+    """the near form's conditions (reach, clearance, the per-frame choice of where primary rays start) depend on where rays start and
+    where they go: the stress world seen from inside the field, from just beyond reach, from inside its ground sphere and at a grazing
+    angle — default == VK_SCENE_REFERENCE_TREE, every pixel, bit for bit"""
+    from descs import camera
+    w, spp = 384, 24
+    imgs = {}
+    for flags in (0, ffi.VK_SCENE_REFERENCE_TREE):
+        hs = HostScene("stress_spheres:60", 1)
+        hs.desc.contents.flags = flags
+        cam = camera(lookfrom, lookat, vfov=35.0, aspect=16.0 / 9.0, aperture=aperture, focus=10.0)
+        ds = DeviceScene(hs.desc)
+        imgs[flags] = (ds.render(cam, hs.params(w, spp, 50, seed=6))[0], ds.info().tree)
+        ds.close(); hs.close()
+    assert imgs[0][1] == ffi.VK_TREE_REBUILT_NEAR and imgs[ffi.VK_SCENE_REFERENCE_TREE][1] == ffi.VK_TREE_HANDED_OVER
+    a, b = imgs[0][0], imgs[ffi.VK_SCENE_REFERENCE_TREE][0]
+    assert np.isfinite(a).all() and a.max() > 0.0
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), int((a != b).any(axis=2).sum())
+
+
 def test_a_full_redo_queue_never_yields_an_incomplete_frame(device):
     """VK_REDO_REGION_CAP=1 (a test switch) leaves one entry per queue between the two launches: samples that do not fit would be
     missing from the frame.  The fallback launch behind the second one then renders the partition again on the tree as handed over —
