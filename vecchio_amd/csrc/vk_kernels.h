@@ -662,8 +662,10 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
 #define VK_CORNELL_UNROLL 3
 #endif
 #ifndef VK_GLOBAL_SPHERE_UNROLL
-// (on the rebuilt trees of exact re-treeing, 1 M spheres, 1 / 2 / 3 / 4 steps per exit test: 1 046 / 1 080 / 1 066 / 1 038 Msamples/s)
-#define VK_GLOBAL_SPHERE_UNROLL 2
+// (on the rebuilt trees of exact re-treeing, 1 M spheres, 1 / 2 / 3 / 4 steps per exit test: 1 046 / 1 080 / 1 066 / 1 038 Msamples/s in the
+// empirical unit form, round 3; in the near form, round 5, whose walks alternate between the rebuilt and the handed-over tree:
+// 2 / 3 / 4 -> 1 263 / 1 276 / 1 254)
+#define VK_GLOBAL_SPHERE_UNROLL 3
 #endif
             constexpr int UNROLL = ((F & VKF_ALL_SCENE) == VKF_ALL_SCENE)
                 ? BOX_UNROLL + 1 : (SPHERES ? (LDS_SCENE ? BOX_UNROLL - 1 : VK_GLOBAL_SPHERE_UNROLL) : VK_CORNELL_UNROLL);
