@@ -34,6 +34,7 @@ static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string
     if (const char *e = getenv("VK_EMPIRICAL_TREES")) opt.allow_empirical = e[0] == '1';
     if (const char *e = getenv("VK_NEAR_FORM")) opt.near_form = e[0] != '0';
     if (const char *e = getenv("VK_UNIT_FORM")) opt.unit_form = e[0] != '0';
+    if (const char *e = getenv("VK_NEAR_FIRST")) opt.near_first = e[0] != '0';
     return linearize(desc, LS, err, opt);
 }
 // EMU_GLOBAL_VARIANT=1: scenes of spheres only as the device runs them from GLOBAL memory (unfused box test; exact re-treeing with both
@@ -41,7 +42,8 @@ static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string
 static bool global_variant() { const char *e = getenv("EMU_GLOBAL_VARIANT"); return e && e[0] == '1'; }
 static DScene scene_view(const LinearScene &LS, std::vector<DItem> &both) {
     DScene S = LS.host_view();
-    if ((global_variant() || LS.near_form) && !LS.ref_items.empty()) {      // (the near form: both trees in items[], as the device keeps it)
+    // (the near form whose reach does not span its small spheres: both trees in items[], as the device keeps it)
+    if ((global_variant() || (LS.near_form && !LS.near_spans)) && !LS.ref_items.empty()) {
         uint32_t ws = 0;
         both = LS.combined_items(ws);
         S.items = both.data(); S.n_items = (uint32_t)both.size(); S.n_world_items = (uint32_t)both.size(); S.walk_start = ws;
@@ -81,6 +83,12 @@ static void trace_one(const DScene &S, const GlobalMem &M0, const RenderConsts &
         }
         g_box_tests += nb; g_sphere_tests += ns;
         const bool early = !on_ref && segment_unsafe<F, Mem>(L, S, M);
+        if (early && getenv("EMU_REDO_REASONS")) {      // (diagnostics: why the segment does not stand)
+            const float dn = sqrtf(L.a);
+            const bool outside = origin_untrusted(S, L.o), odd = !(L.xnan == L.xnan), far = S.reach > 0.0f && !(L.T * dn <= S.reach);
+            fprintf(stderr, "REDO depth %u outside %d odd %d beyond_reach %d miss %d T|d| %.4g prim %08x o (%.4g %.4g %.4g) u (%.3g %.3g %.3g)\n", L.depth, (int)outside,
+                (int)odd, (int)far, (int)(L.best_prim == 0u), (double)(L.T * dn), L.best_prim, L.o.x, L.o.y, L.o.z, L.d.x / dn, L.d.y / dn, L.d.z / dn);
+        }
         if (getenv("EMU_TRACE")) fprintf(stderr, "  seg depth %u o (%.9g %.9g %.9g) d (%.9g %.9g %.9g) T %.9g prim %08x early %d on_ref %d t_pad %g\n", L.depth,
             L.o.x, L.o.y, L.o.z, L.d.x, L.d.y, L.d.z, L.T, L.best_prim, (int)early, (int)on_ref, S.t_pad);
         on_ref = false;
@@ -587,9 +595,9 @@ uint64_t emu_div_by_a_model(uint64_t cases, uint64_t seed, float worst[4]) {
 //   tmax = next(t) (1 + RT_PAD_NEAR).          counts = {candidates, gates closed}
 // mode 1 — REACH: rays from rho_near .. 1e5 away that pass the sphere at up to 1 + 64 u (rho / R)^2 radii (where false roots live): a
 //   candidate's distance t |d| must exceed reach = rho_near - (R + eta(rho_near)).          counts = {candidates, t |d| <= reach}
-// mode 2 — CLEARANCE: centres anywhere in a box, a ray that satisfies segment_unsafe's clear test for that box (outward slope >= 2e-3 on
-//   an axis, its point at distance `reach` clear_margin outside): no sphere with rho > rho_near may hold a candidate.  Spheres are placed
-//   where they hurt: on the box's face the ray leaves through, under the ray.          counts = {rays x spheres tried, candidates}
+// mode 2 — CLEARANCE: a ray that the device's clear_of_small_spheres lets through (outside the box around the spheres' surfaces grown by
+//   M for every s >= reach): no sphere with rho > rho_near may hold a candidate.  Rays at the test's boundary; spheres placed where they
+//   hurt, at the box's point nearest the ray.          counts = {rays x spheres tried, candidates}
 int emu_near_form_claims(int mode, uint64_t n, uint64_t seed, uint64_t counts[2], float viol[12]) {
     Lcg g(seed);
     counts[0] = counts[1] = 0;
@@ -600,7 +608,6 @@ int emu_near_form_claims(int mode, uint64_t n, uint64_t seed, uint64_t counts[2]
         const double eta_near = rt_eta(rho_near, R);
         const double reach = (rho_near - (R + eta_near)) * (1.0 - 1e-5);
         float c[3] = {(float)((g.uni() - .5) * 2e3), (float)((g.uni() - .5) * 2e3), (float)((g.uni() - .5) * 2e3)};
-        if (mode == 2) { c[0] = (float)((g.uni() - .5) * 1e3); c[1] = 0.2f; c[2] = (float)((g.uni() - .5) * 1e3); }
         double maxabs = 0.0;
         for (int a = 0; a < 3; a++) maxabs = std::max(maxabs, std::fabs((double)c[a]) + R);
         const float gg = std::nextafter((float)(1.25 * eta_near + 8.0 * U24 * maxabs), INFINITY);
@@ -649,29 +656,81 @@ int emu_near_form_claims(int mode, uint64_t n, uint64_t seed, uint64_t counts[2]
             }
             continue;
         }
-        // ---- mode 2: a slab of centres y = 0.2, |x|, |z| <= 500; the ray leaves upwards (or sideways) as segment_unsafe's test demands
-        const float clo[3] = {-500.0f, 0.2f, -500.0f}, chi[3] = {500.0f, 0.2f, 500.0f};
-        const double b = std::sqrt(RT_KAPPA);
-        // (mode 3: the control — a quarter of the margin: candidates DO appear, the test has teeth)
-        const float margin = (float)((((double)R * (1.0 + b) + b * reach) / (1.0 - b) * 1.02 + 64.0 * U24 * (500.0 + reach)) * (mode == 3 ? 0.25 : 1.0));
-        const double slope = g.log_uni(2.0e-3, 1.0);
-        double dir[3] = {g.uni() - .5, 0.0, g.uni() - .5};
-        const double hn = std::sqrt(dir[0] * dir[0] + dir[2] * dir[2]) + 1e-30;
-        dir[0] /= hn; dir[2] /= hn; dir[1] = slope / std::sqrt(1.0 - std::min(slope * slope, 0.999999));      // dy / |d| = slope
-        const double dn = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]), dl = g.log_uni(1e-2, 1e2);
-        // origin such that the point at distance reach is just clear: y(reach) = chi_y + margin (1 + tiny)
-        const double y0 = 0.2 + (double)margin * (1.0 + g.log_uni(1e-6, 1.0)) - reach * dir[1] / dn;
-        o = v3((float)((g.uni() - .5) * 800.0), (float)y0, (float)((g.uni() - .5) * 800.0));
-        d = v3((float)(dir[0] / dn * dl), (float)(dir[1] / dn * dl), (float)(dir[2] / dn * dl));
-        {   // segment_unsafe's own test, on the +y axis
-            const float dnf = sqrtf(length2(d)), k = (float)reach / dnf, py = o.y + d.y * k;
-            if (!(d.y >= 2.0e-3f * dnf && py - chi[1] >= margin)) continue;
+        // ---- mode 2: a box of centres (flat fields, rows, cubes: each extent 0 .. 1e3), the spheres' surfaces R around it; the DEVICE's own
+        // test (vk_trace.h clear_of_small_spheres) with the lineariser's constants.  The ray is pushed to the test's boundary: its origin is
+        // bisected along an axis between a position where the test refuses and one where it accepts.
+        // (mode 3, the control: M replaced by MINUS a quarter of a radius, i.e. rays that dip into the box are let through: candidates DO
+        // appear, the test has teeth)
+        DScene S; memset(&S, 0, sizeof(S));
+        double ext[3], blo[3], bhi[3];
+        for (int a = 0; a < 3; a++) {
+            ext[a] = g.uni() < 0.3 ? 0.0 : g.log_uni(1e-1, 1e3);
+            const double mid = (g.uni() - .5) * 1e3;
+            blo[a] = (float)(mid - 0.5 * ext[a]); bhi[a] = (float)(mid + 0.5 * ext[a]);
+            S.small_clo[a] = std::nextafter((float)blo[a] - R, -INFINITY); S.small_chi[a] = std::nextafter((float)bhi[a] + R, INFINITY);
         }
-        // spheres under the ray, beyond rho_near: where the ray passes closest to the slab of centres
-        for (int k = 0; k < 4; k++) {
-            const double s = g.log_uni(std::max(reach, 1e-3), 2e3);                       // distance along the ray
-            float cc[3] = {(float)(o.x + dir[0] / dn * s + (g.uni() - .5) * 2.0 * R), 0.2f, (float)(o.z + dir[2] / dn * s + (g.uni() - .5) * 2.0 * R)};
-            if (!(cc[0] >= clo[0] && cc[0] <= chi[0] && cc[2] >= clo[2] && cc[2] <= chi[2])) continue;
+        double mab = 0.0;
+        for (int a = 0; a < 3; a++) mab = std::max(mab, std::max(std::fabs((double)S.small_clo[a]), std::fabs((double)S.small_chi[a])));
+        const double bb = std::sqrt(RT_KAPPA);
+        S.reach = (float)reach;
+        S.clear_k = (float)(1.02 * bb / (1.0 - 2.0 * bb)); S.clear_r2 = (float)(2.0 * (double)R * (1.0 + 1e-6)); S.clear_slack = (float)(64.0 * U24 * mab);
+        S.t_pad = (float)RT_PAD_NEAR; S.gate_scale = 1.0f / (1.0f + S.t_pad);
+        if (mode == 3) { S.clear_k = 0.0f; S.clear_slack = -0.25f * R; }
+        if (mode == 4) { S.clear_k = 0.0f; S.clear_slack = 0.0f; }              // (no margin at all: how much of it is needed?)
+        // a ray through the box region, shallow against one of its faces more often than not
+        const int ax = (int)(g.uni() * 3) % 3;
+        double dir[3] = {g.uni() - .5, g.uni() - .5, g.uni() - .5};
+        {
+            const double hn = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2] - dir[ax] * dir[ax]) + 1e-30;
+            if (g.uni() < 0.7) dir[ax] = (g.uni() < 0.5 ? 1.0 : -1.0) * hn * g.log_uni(1e-5, 1.0);
+        }
+        const double dn0 = std::sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]) + 1e-30, dl = g.log_uni(1e-2, 1e2);
+        d = v3((float)(dir[0] / dn0 * dl), (float)(dir[1] / dn0 * dl), (float)(dir[2] / dn0 * dl));
+        {
+            const float fx = fabsf(d.x), fy = fabsf(d.y), fz = fabsf(d.z);
+            if (!(fx > 1e-6f && fx < 1e6f && fy > 1e-6f && fy < 1e6f && fz > 1e-6f && fz < 1e6f)) continue;
+        }
+        const float dnf = sqrtf(length2(d));
+        // (the lane's reciprocals: 1 / d off by up to an ulp, as v_rcp_f32's are, times gate_scale)
+        auto rcp = [&](float x) { float r = 1.0f / x; const double u = g.uni(); r = u < 0.25 ? std::nextafter(r, -INFINITY) : u < 0.5 ? std::nextafter(r, INFINITY) : r; return r * S.gate_scale; };
+        const V3 inv = v3(rcp(d.x), rcp(d.y), rcp(d.z));
+        // the ray passes through a point of the box at distance s0 from its origin (s0 around reach, or far beyond it) ...
+        double q[3];
+        for (int a = 0; a < 3; a++) q[a] = blo[a] + g.uni() * (bhi[a] - blo[a]);
+        const double s0 = g.uni() < 0.5 ? reach * g.log_uni(0.5, 4.0) : g.log_uni(std::max(reach, 1e-3), 3e3);
+        double o0[3], o1[3];
+        for (int a = 0; a < 3; a++) o0[a] = q[a] - (double)d.x * (a == 0) / dnf * s0 - (double)d.y * (a == 1) / dnf * s0 - (double)d.z * (a == 2) / dnf * s0;
+        // ... and is shifted along an axis until the test accepts
+        const int sa = g.uni() < 0.7 ? ax : (int)(g.uni() * 3) % 3;
+        const double sgn = g.uni() < 0.5 ? 1.0 : -1.0;
+        for (int a = 0; a < 3; a++) o1[a] = o0[a] + (a == sa ? sgn * (ext[a] + 4.0 * R + 0.1 * (s0 + 3e3)) : 0.0);
+        auto at = [&](double l) { return v3((float)(o0[0] + l * (o1[0] - o0[0])), (float)(o0[1] + l * (o1[1] - o0[1])), (float)(o0[2] + l * (o1[2] - o0[2]))); };
+        double l0 = 0.0, l1 = 1.0;
+        if (clear_of_small_spheres(S, at(0.0), inv, dnf)) l1 = 0.0;              // (already clear: leaves the box before reach)
+        else if (!clear_of_small_spheres(S, at(1.0), inv, dnf)) continue;
+        else for (int k = 0; k < 48; k++) { const double lm = 0.5 * (l0 + l1); if (clear_of_small_spheres(S, at(lm), inv, dnf)) l1 = lm; else l0 = lm; }
+        o = at(l1);
+        if (!clear_of_small_spheres(S, o, inv, dnf)) continue;
+        // spheres where they hurt: centres at the box's point nearest the ray, for the ray's closest approach beyond reach and a few more
+        double best_s = reach, best_d = INFINITY;
+        for (int k = 0; k < 96; k++) {
+            const double s = reach * std::pow(3e3 / std::max(reach, 1e-3) + 2.0, k / 95.0);
+            double dist2 = 0.0;
+            for (int a = 0; a < 3; a++) {
+                const double pa = (a == 0 ? o.x + (double)d.x / dnf * s : a == 1 ? o.y + (double)d.y / dnf * s : o.z + (double)d.z / dnf * s);
+                const double e = pa < blo[a] ? blo[a] - pa : pa > bhi[a] ? pa - bhi[a] : 0.0;
+                dist2 += e * e;
+            }
+            if (dist2 < best_d) { best_d = dist2; best_s = s; }
+        }
+        for (int k = 0; k < 6; k++) {
+            const double s = k < 3 ? best_s * (1.0 + (g.uni() - .5) * 0.05) : g.log_uni(std::max(reach, 1e-3), 3e3);
+            if (s < reach) continue;
+            float cc[3];
+            for (int a = 0; a < 3; a++) {
+                const double pa = (a == 0 ? o.x + (double)d.x / dnf * s : a == 1 ? o.y + (double)d.y / dnf * s : o.z + (double)d.z / dnf * s);
+                cc[a] = (float)std::min(std::max(pa + (k % 3 == 0 ? 0.0 : (g.uni() - .5) * 0.5 * R), blo[a]), bhi[a]);
+            }
             const double ox = (double)o.x - cc[0], oy = (double)o.y - cc[1], oz = (double)o.z - cc[2];
             if (std::sqrt(ox * ox + oy * oy + oz * oz) <= rho_near) continue;             // (a near sphere: behind a sound gate)
             counts[0]++;

@@ -228,8 +228,12 @@ def test_near_form_claims(mode, what, lem):
 
 
 def test_the_clearance_margin_is_not_idle(lem):
-    """control of mode 2: with a quarter of the clearance margin, rays that "test clear" do pass spheres close enough for candidates"""
+    """control of mode 2: rays that dip a quarter of a radius INTO the box around the spheres' surfaces do find candidates"""
     cnt = (C.c_uint64 * 2)(); v = (C.c_float * 12)()
     lem.emu_near_form_claims(3, 1_500_000, 1, cnt, v)
-    print(f"a quarter of the margin: {cnt[1]} candidates in {cnt[0]} pairs")
+    print(f"a quarter of a radius inside the box: {cnt[1]} candidates in {cnt[0]} pairs")
+    assert cnt[1] > 100
+    # ... and so do rays that merely stay outside the box itself (M = 0): the margin is needed, and the rays above sit on its boundary
+    lem.emu_near_form_claims(4, 500_000, 1, cnt, v)
+    print(f"no margin at all: {cnt[1]} candidates in {cnt[0]} pairs")
     assert cnt[1] > 100

@@ -31,11 +31,13 @@ def render(name, w, spp, flags, tile=None):
     return img, st, rq.value, info
 
 
-# (the stress scenes' reference trees have leaf boxes too long for grown UNIT gates: their default is the NEAR form, round 5 — own-box gates,
-# both trees in global memory; the unit form with bare gates is the opt-in empirical one, preferred with VK_GATE_PROOF=0)
+# (round 5: the default is the NEAR form — own-box gates.  The InOneWeekend scene: its reach spans the field, staged in LDS, the rare
+# failed segment requeues its sample.  The stress scenes: reach does not span them and their reference trees have leaf boxes too long
+# for grown UNIT gates: both trees in global memory; the unit form with bare gates is the opt-in empirical one, preferred with
+# VK_GATE_PROOF=0.  The unit form with grown gates: test_unit_form_forced_on_the_gpu.)
 @pytest.mark.parametrize("name,w,spp,in_lds,flags,tree", [
-    ("random_spheres_iow", 640, 96, True, 0, ffi.VK_TREE_REBUILT_PROVEN),
-    ("random_spheres_iow", 640, 96, True, ffi.VK_SCENE_EMPIRICAL_TREES, ffi.VK_TREE_REBUILT_PROVEN),
+    ("random_spheres_iow", 640, 96, True, 0, ffi.VK_TREE_REBUILT_NEAR),
+    ("random_spheres_iow", 640, 96, True, ffi.VK_SCENE_EMPIRICAL_TREES, ffi.VK_TREE_REBUILT_NEAR),
     ("stress_spheres:150", 512, 12, False, 0, ffi.VK_TREE_REBUILT_NEAR),
     ("stress_spheres:30", 384, 24, False, 0, ffi.VK_TREE_REBUILT_NEAR),
     ("stress_spheres:150", 512, 12, False, ffi.VK_SCENE_EMPIRICAL_TREES, ffi.VK_TREE_REBUILT_EMPIRICAL),
@@ -63,9 +65,32 @@ def test_exact_retree_image_is_the_handed_over_trees(name, w, spp, in_lds, flags
     assert rq_p <= rq
 
 
+def test_unit_form_forced_on_the_gpu(device):
+    """the UNIT form (the reference's leaf units as gates, grown: rounds 3-4's default) where the near form is taken first now:
+    VK_NEAR_FIRST=0, honoured by the DEBUG build only and read at scene creation — a child process.  InOneWeekend scene, staged in LDS,
+    every pixel the handed-over tree's, a few samples through the second launch."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from vecchio_amd import DeviceScene, HostScene, ffi\n"
+            "dbg = ffi.load_debug_lib(); out = []\n"
+            "for flags in (0, ffi.VK_SCENE_REFERENCE_TREE):\n"
+            "    hs = HostScene('random_spheres_iow', 1); hs.desc.contents.flags = flags; cam = hs.next_camera()\n"
+            "    ds = DeviceScene(hs.desc, lib=dbg)\n"
+            "    img, st = ds.render(cam, hs.params(640, 96, 50, seed=3))\n"
+            "    out.append((img, ds.info().tree, ds.last_requeued_samples(), st.scene_in_lds, st.samples)); ds.close()\n"
+            "assert out[0][1] == ffi.VK_TREE_REBUILT_PROVEN and out[1][1] == ffi.VK_TREE_HANDED_OVER, (out[0][1], out[1][1])\n"
+            "assert out[0][3] and 0 < out[0][2] < 0.01 * out[0][4], out[0][2:]\n"
+            "assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))\n"
+            "print('UNIT FORM OK', out[0][2])\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VK_NEAR_FIRST="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "UNIT FORM OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_the_headline_frame_at_full_size_is_the_handed_over_trees(device):
     """BASELINE C2 exactly as bench.py renders it — 1920 x 1080 x 1024 spp, depth 50, scene seed 1, render seed 2: the default (exact
-    re-treeing, proven form) against VK_SCENE_REFERENCE_TREE, all 2.1 G samples, bit for bit (main.rs:181-198; 0.6 s of GPU)."""
+    re-treeing, near form staged in LDS) against VK_SCENE_REFERENCE_TREE, all 2.1 G samples, bit for bit (main.rs:181-198; 0.6 s of GPU)."""
     def frame(flags):
         hs = HostScene("random_spheres_iow", 1)
         hs.desc.contents.flags = flags
@@ -78,7 +103,7 @@ def test_the_headline_frame_at_full_size_is_the_handed_over_trees(device):
     ref, st_r, info_r = frame(ffi.VK_SCENE_REFERENCE_TREE)
     img, st, info = frame(0)
     assert img.shape == (1080, 1920, 3) and st.samples == 1920 * 1080 * 1024 == st_r.samples
-    assert info_r.tree == ffi.VK_TREE_HANDED_OVER and info.tree == ffi.VK_TREE_REBUILT_PROVEN
+    assert info_r.tree == ffi.VK_TREE_HANDED_OVER and info.tree == ffi.VK_TREE_REBUILT_NEAR
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), int((img != ref).any(axis=2).sum())
     assert st.clamped_samples == 0 and np.isfinite(img).all()
 
@@ -93,30 +118,44 @@ def test_stress_scenes_are_walked_in_the_near_form_by_default(device):
         assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (name, int((img != ref).any(axis=2).sum()))
 
 
-@pytest.mark.parametrize("lookfrom,lookat,aperture", [
-    ((3.0, 0.6, 2.0), (10.0, 0.3, 9.0), 0.05),          # inside the field, a sphere's height above the ground: primary rays on the rebuilt tree
-    ((0.0, 40.0, 0.0), (1.0, 0.0, 1.0), 0.0),           # straight down from 40: just beyond reach, primary rays start as handed over
-    ((26.0, 4.0, 6.0), (0.0, 0.0, 0.0), 0.1),           # the InOneWeekend view, doubled
-    ((0.0, -300.0, 0.0), (30.0, 0.0, 30.0), 0.0),       # INSIDE the ground sphere, looking up at the field from below
-    ((900.0, 15.0, 0.0), (0.0, 0.0, 0.0), 0.0)])        # grazing, from far outside the field: long walks past thousands of spheres
-def test_near_form_from_other_viewpoints(lookfrom, lookat, aperture, device):
+@pytest.mark.parametrize("scene,lookfrom,lookat,aperture", [
+    ("stress_spheres:60", (3.0, 0.6, 2.0), (10.0, 0.3, 9.0), 0.05),    # inside the field, a sphere's height above the ground: primary rays on the rebuilt tree
+    ("stress_spheres:60", (0.0, 40.0, 0.0), (1.0, 0.0, 1.0), 0.0),     # straight down from 40: just beyond reach, primary rays start as handed over
+    ("stress_spheres:60", (26.0, 4.0, 6.0), (0.0, 0.0, 0.0), 0.1),     # the InOneWeekend view, doubled
+    ("stress_spheres:60", (0.0, -300.0, 0.0), (30.0, 0.0, 30.0), 0.0), # INSIDE the ground sphere, looking up at the field from below
+    ("stress_spheres:60", (900.0, 15.0, 0.0), (0.0, 0.0, 0.0), 0.0),   # grazing, from far outside the field: long walks past thousands of spheres
+    # the InOneWeekend world (staged in LDS: one tree per launch):
+    ("random_spheres_iow", (3.0, 0.6, 2.0), (-6.0, 0.3, -7.0), 0.05),  # among the spheres
+    ("random_spheres_iow", (0.0, 60.0, 0.0), (1.0, 0.0, 1.0), 0.0),    # farther than reach from everything: the frame on the tree as handed over
+    ("random_spheres_iow", (0.0, 33.0, 0.0), (1.0, 0.0, 1.0), 0.0),    # just within reach of the ground: primary hits beyond it requeue
+    ("random_spheres_iow", (0.0, -300.0, 0.0), (8.0, 0.0, 8.0), 0.0),  # inside the ground sphere, looking up at the field
+    ("random_spheres_iow", (200.0, 3.0, 0.0), (0.0, 0.5, 0.0), 0.0)])  # grazing, from outside the field
+def test_near_form_from_other_viewpoints(scene, lookfrom, lookat, aperture, device):
     """the near form's conditions (reach, clearance, the per-frame choice of where primary rays start) depend on where rays start and
-    where they go: the stress world seen from inside the field, from just beyond reach, from inside its ground sphere and at a grazing
+    where they go: the worlds seen from inside the field, from just beyond reach, from inside the ground sphere and at a grazing
     angle — default == VK_SCENE_REFERENCE_TREE, every pixel, bit for bit"""
     from descs import camera
     w, spp = 384, 24
     imgs = {}
     for flags in (0, ffi.VK_SCENE_REFERENCE_TREE):
-        hs = HostScene("stress_spheres:60", 1)
+        hs = HostScene(scene, 1)
         hs.desc.contents.flags = flags
         cam = camera(lookfrom, lookat, vfov=35.0, aspect=16.0 / 9.0, aperture=aperture, focus=10.0)
         ds = DeviceScene(hs.desc)
-        imgs[flags] = (ds.render(cam, hs.params(w, spp, 50, seed=6))[0], ds.info().tree)
+        imgs[flags] = (ds.render(cam, hs.params(w, spp, 50, seed=6))[0], ds.info().tree, ds.last_requeued_samples())
         ds.close(); hs.close()
     assert imgs[0][1] == ffi.VK_TREE_REBUILT_NEAR and imgs[ffi.VK_SCENE_REFERENCE_TREE][1] == ffi.VK_TREE_HANDED_OVER
     a, b = imgs[0][0], imgs[ffi.VK_SCENE_REFERENCE_TREE][0]
     assert np.isfinite(a).all() and a.max() > 0.0
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), int((a != b).any(axis=2).sum())
+    # Staged in LDS (one tree per launch) a frame whose camera is farther than reach from everything is rendered on the tree as handed
+    # over: nothing requeued.  From 33 above the ground only the rays straight down hit within reach: a fifth of the samples requeue,
+    # the queues overflow, the frame is rendered again as handed over and the rebuilt tree suspended (vk_api.hip judge_frame) — the
+    # image is the same either way.
+    if lookfrom == (0.0, 60.0, 0.0):
+        assert imgs[0][2] == 0
+    elif lookfrom != (0.0, 33.0, 0.0):
+        assert imgs[0][2] < 0.03 * w * (w * 9 // 16) * spp, imgs[0][2]
 
 
 def test_a_full_redo_queue_never_yields_an_incomplete_frame(device):

@@ -229,13 +229,13 @@ def test_exact_retree_on_sphere_crowds_is_the_handed_over_tree_per_sample(seed, 
     desc.contents.flags = ffi.VK_SCENE_REFERENCE_TREE
     img_r, ps_r, steps_r, info_r = emu.render_samples(desc, cam, p)
     compare(ps_o, ps_r, img_o, img_r)
-    # the default (the unit form with grown gates where it is cheap, else the near form, else the tree as handed over), the near form
-    # forced where the unit form would do (VK_UNIT_FORM=0: with and without primary rays starting on the tree as handed over), and the
-    # opt-in empirical form
-    for flags, env in ((0, {}), (0, {"VK_UNIT_FORM": "0"}), (0, {"VK_UNIT_FORM": "0", "EMU_PRIMARY_REF": "1"}),
+    # the default (the near form where its reach spans the world, else the unit form with grown gates where it is cheap, else the near
+    # form whatever its reach, else the tree as handed over), the unit form wherever it is eligible (VK_NEAR_FIRST=0), the near form
+    # wherever it is (VK_UNIT_FORM=0: with and without primary rays starting on the tree as handed over), and the opt-in empirical form
+    for flags, env in ((0, {}), (0, {"VK_NEAR_FIRST": "0"}), (0, {"VK_UNIT_FORM": "0"}), (0, {"VK_UNIT_FORM": "0", "EMU_PRIMARY_REF": "1"}),
                        (ffi.VK_SCENE_EMPIRICAL_TREES, {"VK_GATE_PROOF": "0"})):
         desc.contents.flags = flags
-        for k in ("VK_UNIT_FORM", "EMU_PRIMARY_REF", "VK_GATE_PROOF"):
+        for k in ("VK_UNIT_FORM", "VK_NEAR_FIRST", "EMU_PRIMARY_REF", "VK_GATE_PROOF"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -289,10 +289,13 @@ def test_exact_retree_on_sphere_crowds_on_the_gpu(seed, device, oracle):
 
 
 @pytest.mark.gpu
-def test_near_form_forced_on_sphere_crowds_on_the_gpu(device, oracle):
-    """the near form (vk_linearize.cpp rt_grow_near) where the unit form would have done: VK_UNIT_FORM=0 is honoured by the DEBUG build
-    of the library only, and read at scene creation, so this runs in a child process: twelve crowds (four of them with coincident
-    spheres), every sample the oracle's and the handed-over tree's"""
+@pytest.mark.parametrize("switch,tree", [("VK_UNIT_FORM", ffi.VK_TREE_REBUILT_NEAR)])
+def test_a_form_forced_on_sphere_crowds_on_the_gpu(switch, tree, device, oracle):
+    """the near form (vk_linearize.cpp rt_grow_near) wherever it is eligible (VK_UNIT_FORM=0) — the default takes it first only where
+    its reach spans the world.  (The unit form is never cheap on these crowds — their leaf units are long — so forcing IT has its own
+    test on the InOneWeekend scene: test_gpu_exact_retree.py test_unit_form_forced_on_the_gpu.)  The switches are honoured by the
+    DEBUG build of the library only, and read at scene creation, so this runs in a child process: twelve crowds (four of them with
+    coincident spheres), every sample the oracle's and the handed-over tree's"""
     import subprocess
     import sys
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
@@ -312,9 +315,9 @@ def test_near_form_forced_on_sphere_crowds_on_the_gpu(device, oracle):
             "        img_d, ps_d = device_samples(ds, cam, p); compare_samples(ps_o, ps_d, img_o, img_d); out.append(ps_d); ds.close()\n"
             "    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32)), seed\n"
             "print('TREES', sorted(set(trees)))\n") % (ROOT, os.path.join(ROOT, "tests"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VK_UNIT_FORM="0"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{switch: "0"}), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "TREES" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    assert str(ffi.VK_TREE_REBUILT_NEAR) in r.stdout.split("TREES")[1], r.stdout
+    assert str(tree) in r.stdout.split("TREES")[1], r.stdout
 
 
 @pytest.mark.gpu

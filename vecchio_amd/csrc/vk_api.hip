@@ -137,6 +137,7 @@ struct EnvSwitches {
     // VK_RETREE=0/1/2: nothing rebuilt / every draw-free subtree / exact re-treeing (default: vk_scene_desc.flags)
     int retree = -1;
     int redo_region_cap = 0;           // VK_REDO_REGION_CAP=n (tests): entries per queue between the two launches of exact re-treeing
+    int near_lds = -1;                 // VK_NEAR_LDS=0/1 (comparisons): the near form of exact re-treeing from global memory / staged in LDS
     static int int_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
     static EnvSwitches read() {
         EnvSwitches v;
@@ -154,6 +155,7 @@ struct EnvSwitches {
         v.probe_depth = int_env("VK_PROBE_DEPTH");
         v.prim_weight = int_env("VK_PRIM_WEIGHT");
         v.redo_region_cap = int_env("VK_REDO_REGION_CAP");
+        if (const char *e = getenv("VK_NEAR_LDS")) v.near_lds = e[0] != '0';
         return v;
     }
 };
@@ -302,9 +304,10 @@ void plan_residency(vk_scene *s, size_t hot) {
     const size_t pw = per_wave_lds_bytes(pick_variant(s));
     uint32_t best_waves = 0, best_wg = 0, best_n = 0;
     const bool spheres_only = pick_variant(s) == 0u;
-    // the near form of exact re-treeing walks a failed segment again in place: both trees in items[], i.e. global memory (staged in LDS,
-    // where a failed segment requeues its whole sample, it loses 11 % on the InOneWeekend scene against the unit form: round 5)
-    const bool near_needs_global = s->host->near_form;
+    // The near form of exact re-treeing walks a failed segment again in place: both trees in items[], i.e. global memory — unless its
+    // reach spans the small spheres' whole box: then hardly a segment fails (the InOneWeekend scene: 3 in 10^5), a failed one may as well
+    // requeue its whole sample, and the scene is staged in LDS like any other (7 520 against the unit form's 7 285 Msamples/s at 256 spp)
+    const bool near_needs_global = s->host->near_form && (s->env.near_lds >= 0 ? s->env.near_lds == 0 : !s->host->near_spans);
     const uint32_t per_simd = spheres_only ? s->sphere_waves : (pick_variant(s) == (uint32_t)VKF_ALL_SCENE ? (uint32_t)VK_ALL_MINW
                                                                                                            : (uint32_t)VK_CORNELL_MINW);   // = MINW of launch_variant
     uint32_t cap = 4 * per_simd;                                             // waves per CU the variant's register budget admits
@@ -519,7 +522,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     // The near form: primary rays start on the tree as handed over when the camera (its lens included) is farther than `reach` from every
     // sphere — their walk on the rebuilt tree could not stand (vk_trace.h begin_segment).  Decided from the box around the small spheres
     // and the surfaces of the few big ones; when in doubt: no.
-    if (s->host->near_form && A.S.walk_start != 0u && s->host->n_big != 0xFFFFFFFFu) {
+    if (s->host->near_form && (A.S.walk_start != 0u || s->exact) && s->host->n_big != 0xFFFFFFFFu) {
         const LinearScene &H = *s->host;
         const double reach = (double)H.reach + (double)fabsf(cam->lens_radius) * 1.5 + 1e-3 * (double)H.reach;
         double d2 = 0.0;
@@ -533,7 +536,8 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
             for (int k = 0; k < 3; k++) q += ((double)cam->origin[k] - H.big[b][k]) * ((double)cam->origin[k] - H.big[b][k]);
             far_from_all = fabs(sqrt(q) - (double)H.big[b][3]) > reach;
         }
-        A.S.primary_ref = far_from_all ? 1u : 0u;
+        if (A.S.walk_start != 0u) A.S.primary_ref = far_from_all ? 1u : 0u;
+        else if (far_from_all) exact = false;      // (staged in LDS there is one tree per launch: such a frame on the tree as handed over)
     }
     A.C.cam = *cam;
     A.C.width = p->width; A.C.height = p->height; A.C.spp = p->samples_per_pixel; A.C.max_depth = p->max_depth;
@@ -951,7 +955,7 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
         D.t_pad = hv.t_pad; D.gate_scale = hv.gate_scale; D.tmin_gate = hv.tmin_gate;
         for (int k = 0; k < 3; k++) { D.trust_c0[k] = hv.trust_c0[k]; D.small_clo[k] = hv.small_clo[k]; D.small_chi[k] = hv.small_chi[k]; }
         D.trust_r0sq = hv.trust_r0sq;
-        D.reach = hv.reach; D.clear_margin = hv.clear_margin;
+        D.reach = hv.reach; D.clear_k = hv.clear_k; D.clear_r2 = hv.clear_r2; D.clear_slack = hv.clear_slack;
         if (s->lds_bytes != 0) {
             UP(items, items); UP(ref_items, ref_items);
             D.n_ref_items = hv.n_ref_items; D.n_items = (uint32_t)H.items.size(); D.n_world_items = H.world_items;
@@ -1025,6 +1029,7 @@ int linearize_desc(const vk_scene_desc *desc, std::shared_ptr<const LinearScene>
     if (const char *e = getenv("VK_EMPIRICAL_TREES")) opt.allow_empirical = e[0] == '1';
     if (const char *e = getenv("VK_NEAR_FORM")) opt.near_form = e[0] != '0';
     if (const char *e = getenv("VK_UNIT_FORM")) opt.unit_form = e[0] != '0';
+    if (const char *e = getenv("VK_NEAR_FIRST")) opt.near_first = e[0] != '0';
 #endif
     int rc = linearize(desc, *h, err, opt);
     if (rc != VK_OK) return fail(rc, err);

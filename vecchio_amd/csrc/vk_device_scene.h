@@ -135,11 +135,12 @@ struct DScene {
     // within `reach` of its origin (T |d| <= reach; a miss never does): then every sphere that could hold a closer candidate is within
     // the radius its own-box gate is sound for.  0 = no such condition (the unit form, whose gates are sound for the whole ball).
     float reach;
-    // ... or if, beyond `reach`, the ray runs CLEAR of every small sphere: on some axis it moves outward (|d_a| / |d| >= 2e-3) and its
-    // point at distance `reach` is already clear_margin outside the box [small_clo, small_chi] of the small spheres' centres.  A sphere
-    // farther than rho_near then has no candidate at all (its hit points lie within sqrt(R^2 + 32 u (rho + R)^2) of its centre: a
-    // margin that grows by 1.4e-3 per unit travelled), so a MISS, or a far hit on a big sphere, stands too.
-    float small_clo[3], small_chi[3], clear_margin;
+    // ... or if, beyond `reach`, the ray runs CLEAR of every small sphere.  A far sphere's candidate point lies within
+    // delta = sqrt(32 u) (rho + R) of the sphere, hence of the box [small_clo, small_chi] around the small spheres' SURFACES, and no
+    // farther from the origin than that box's far corner: delta <= M := clear_k (D_far(o) + clear_r2) + clear_slack.  If the ray is
+    // outside that box grown by M for every s >= reach (a slab test), no sphere beyond rho_near holds a candidate at all, and a MISS,
+    // or a far hit on a big sphere, stands too (vk_trace.h clear_of_small_spheres; docs/gate_lemma.md section 7).
+    float small_clo[3], small_chi[3], clear_k, clear_r2, clear_slack;
     // ... and, decided per frame by the host: primary rays (depth 1) start on the tree as handed over (the camera is farther than
     // `reach` from everything, so their rebuilt walk could never stand)
     uint32_t primary_ref;

@@ -38,8 +38,8 @@ DScene LinearScene::host_view() const {
     for (int k = 0; k < 3; k++) s.trust_c0[k] = trust_c0[k];
     s.trust_r0sq = trust_r0 * trust_r0;
     s.reach = ref_items.empty() ? 0.0f : reach; s.primary_ref = 0u;
-    for (int k = 0; k < 3; k++) { s.small_clo[k] = small_clo[k]; s.small_chi[k] = small_chi[k]; }
-    s.clear_margin = clear_margin;
+    for (int k = 0; k < 3; k++) { s.small_clo[k] = small_lo[k]; s.small_chi[k] = small_hi[k]; }
+    s.clear_k = clear_k; s.clear_r2 = clear_r2; s.clear_slack = clear_slack;
     s.fast_div = 1u;
     for (const DSphere &sp : spheres)
         if (!(fabsf(sp.cx) < 1073741824.0f && fabsf(sp.cy) < 1073741824.0f && fabsf(sp.cz) < 1073741824.0f && fabsf(sp.r) < 1073741824.0f)) s.fast_div = 0u;
@@ -770,8 +770,10 @@ struct Builder {
     // "big": always sound, they do not enter `reach`.  The ball reaches RT_NEAR_BALL extents of the ordinary spheres; segments that
     // start outside it are the handed-over tree's from the start (begin_segment).
     float near_reach = 0.0f, near_radius = 0.0f;
-    bool near_form = false, allow_near = true, allow_unit = true;
+    bool near_form = false, allow_near = true, allow_unit = true, near_first = true;
+    bool near_spans = false;       // reach spans the small spheres' whole box (or there are none): hardly a segment is walked twice
     bool rt_grow_near(std::vector<RtObj> &objs) {
+        near_spans = false;
         if (objs.empty()) return false;
         const size_t n = objs.size();
         const double U24 = 1.0 / 16777216.0;
@@ -796,31 +798,41 @@ struct Builder {
         }
         if (!(ext > 0.0) || !std::isfinite(far_side)) return false;
         // The ball only bounds what the BIG spheres' gates must cover (a small sphere's soundness is a matter of rho_near): as far as the far
-        // side of every sphere — paths inside a ground sphere start there — when the big spheres stay big at that size, else
-        // RT_NEAR_BALL extents
-        dom.r0 = std::max(RT_NEAR_BALL * ext, 1.05 * far_side);
-        {
-            bool ok_wide = true;
-            for (size_t i = 0; i < n && ok_wide; i++) {
-                const bool big_narrow = 1.25 * rt_eta(dist[i] + RT_NEAR_BALL * ext, rr[i]) <= RT_NEAR_BIG_GROWTH * (double)rr[i];
-                const bool big_wide = 1.25 * rt_eta(dist[i] + dom.r0, rr[i]) <= RT_NEAR_BIG_GROWTH * (double)rr[i];
-                ok_wide = big_wide || !big_narrow;
-            }
-            if (!ok_wide) dom.r0 = RT_NEAR_BALL * ext;
-        }
-        // big spheres: sound for every origin of the ball (the near rule at the ball's far end) at a small relative growth
+        // side of every sphere — paths inside a ground sphere start there — if the world is eligible with the spheres that are big at THAT
+        // size (a sphere that is big only for a smaller ball is a small one then), else RT_NEAR_BALL extents
         std::vector<char> big(n, 0);
         std::vector<double> grow(n, 0.0);
         std::vector<float> small_r;
-        for (size_t i = 0; i < n; i++) {
-            const double g_all = 1.25 * rt_eta(dist[i] + dom.r0, rr[i]);
-            if (g_all <= RT_NEAR_BIG_GROWTH * (double)rr[i]) { big[i] = 1; grow[i] = g_all; } else small_r.push_back(rr[i]);
-        }
         double rho_near = INFINITY, reach = INFINITY;
-        if (!small_r.empty()) {
+        auto attempt = [&](double r0, bool say) -> bool {
+            dom.r0 = r0;
+            // big spheres: sound for every origin of the ball (the near rule at the ball's far end) at a small relative growth
+            small_r.clear();
+            for (size_t i = 0; i < n; i++) {
+                const double g_all = 1.25 * rt_eta(dist[i] + dom.r0, rr[i]);
+                big[i] = g_all <= RT_NEAR_BIG_GROWTH * (double)rr[i];
+                grow[i] = big[i] ? g_all : 0.0;
+                if (!big[i]) small_r.push_back(rr[i]);
+            }
+            rho_near = INFINITY; reach = INFINITY;
+            near_spans = small_r.empty();
+            if (small_r.empty()) return true;
             // eta(rho_near) = 0.8 RT_NEAR_GROWTH R for the median small sphere
             const double rs = median(small_r);
             rho_near = std::sqrt(0.8 * RT_NEAR_GROWTH * rs * rs / RT_KAPPA) - rs;
+            {   // ... a little farther if that lets `reach` span the small spheres' whole box: a ray that starts among them and travels
+                // beyond reach has then left the box, which the clearance test sees — at up to twice the growth
+                double lo2[3] = {INFINITY, INFINITY, INFINITY}, hi2[3] = {-INFINITY, -INFINITY, -INFINITY}, rmx = 0.0;
+                for (size_t i = 0; i < n; i++) {
+                    if (big[i]) continue;
+                    for (int a = 0; a < 3; a++) { lo2[a] = std::min(lo2[a], (double)objs[i].mn[a]); hi2[a] = std::max(hi2[a], (double)objs[i].mx[a]); }
+                    rmx = std::max(rmx, (double)rr[i]);
+                }
+                const double diag = std::sqrt((hi2[0] - lo2[0]) * (hi2[0] - lo2[0]) + (hi2[1] - lo2[1]) * (hi2[1] - lo2[1]) + (hi2[2] - lo2[2]) * (hi2[2] - lo2[2]));
+                const double want = (diag + 2.0 * rmx) * 1.05, cap = std::sqrt(0.8 * 2.0 * RT_NEAR_GROWTH * rs * rs / RT_KAPPA) - rs;
+                if (want > rho_near && want <= cap) rho_near = want;
+                near_spans = rho_near >= want;
+            }
             double worst = 0.0, grow_sum = 0.0;
             size_t n_small = 0;
             for (size_t i = 0; i < n; i++) {
@@ -832,7 +844,7 @@ struct Builder {
                 // growth is held to 15 % of the median radius; beyond that the world is not eligible)
                 grow_sum += grow[i]; n_small++;
                 if (grow[i] > rs) {
-                    if (getenv("VK_RETREE_DEBUG")) fprintf(stderr, "vecchio_amd: near form: a sphere of radius %g among spheres of median radius %g "
+                    if (say) fprintf(stderr, "vecchio_amd: near form: a sphere of radius %g among spheres of median radius %g "
                         "would grow by %g: not eligible\n", (double)rr[i], rs, grow[i]);
                     return false;
                 }
@@ -840,12 +852,21 @@ struct Builder {
             }
             reach = rho_near - worst;
             if (grow_sum > 0.15 * rs * (double)n_small) {
-                if (getenv("VK_RETREE_DEBUG")) fprintf(stderr, "vecchio_amd: near form: mean growth %g of a median radius of %g: not eligible\n",
+                if (say) fprintf(stderr, "vecchio_amd: near form: mean growth %g of a median radius of %g: not eligible\n",
                     grow_sum / (double)n_small, rs);
                 return false;
             }
             if (!(reach > 8.0 * rs)) {                                      // (not even the neighbours are within reach)
-                if (getenv("VK_RETREE_DEBUG")) fprintf(stderr, "vecchio_amd: near form: reach %g for a median radius of %g: not eligible\n", reach, rs);
+                if (say) fprintf(stderr, "vecchio_amd: near form: reach %g for a median radius of %g: not eligible\n", reach, rs);
+                return false;
+            }
+            return true;
+        };
+        {
+            const bool say = getenv("VK_RETREE_DEBUG") != nullptr;
+            const double wide = std::max(RT_NEAR_BALL * ext, 1.05 * far_side), narrow = RT_NEAR_BALL * ext;
+            if (!attempt(wide, false) && !(narrow < wide && attempt(narrow, say))) {
+                if (say && !(narrow < wide)) (void)attempt(wide, true);
                 return false;
             }
         }
@@ -875,16 +896,19 @@ struct Builder {
                 }
             for (int a = 0; a < 3; a++) objs[i].c[a] = 0.5f * objs[i].mn[a] + 0.5f * objs[i].mx[a];
         }
-        for (int a = 0; a < 3; a++) { L.small_lo[a] = lo[a]; L.small_hi[a] = hi[a]; L.trust_c0[a] = (float)dom.c0[a];
-            L.small_clo[a] = clo[a]; L.small_chi[a] = chi[a]; }
-        {   // CLEARANCE (DScene::clear_margin).  A far sphere's hit point P(s) satisfies |P(s) - c| <= D <= (R (1 + b) + b s) / (1 - b),
-            // b = sqrt(32 u) = 1.381e-3 (from D <= R + b (rho + R) and rho <= s + D), and s >= reach: the margin at s = reach, with 2 % and
-            // the boxes' rounding on top; beyond, an outward slope of 2e-3 outruns the margin's 1.383e-3
+        for (int a = 0; a < 3; a++) { L.small_lo[a] = lo[a]; L.small_hi[a] = hi[a]; L.trust_c0[a] = (float)dom.c0[a]; }
+        {   // CLEARANCE (DScene::clear_k ..., vk_trace.h clear_of_small_spheres; the box [small_lo, small_hi] is the one around the small
+            // spheres' SURFACES).  A far sphere's hit point H = P(s) lies within D <= R + b (rho + R) of its centre, b = sqrt(32 u) =
+            // 1.381e-3, i.e. within delta = b (rho + R) of the sphere, hence of that box; so s <= D_far + delta (D_far: the origin's distance
+            // from the box's far corner) and rho <= s + R + delta give delta <= b (D_far + 2 R) / (1 - 2 b).  2 % and the boxes' rounding on
+            // top (the slab test's own rounding, 3 u D_far, is a hundredth of the 2 %).
             const double b = std::sqrt(RT_KAPPA);
             double maxabs = 0.0;
-            for (int a = 0; a < 3; a++) maxabs = std::max(maxabs, std::max(std::fabs((double)clo[a]), std::fabs((double)chi[a])));
-            const double m = (r_max_small * (1.0 + b) + b * (std::isfinite(reach) ? reach : 0.0)) / (1.0 - b);
-            L.clear_margin = small_r.empty() ? 0.0f : (float)(m * 1.02 + 64.0 * U24 * (maxabs + (std::isfinite(reach) ? reach : 0.0)));
+            for (int a = 0; a < 3; a++) maxabs = std::max(maxabs, std::max(std::fabs((double)lo[a]), std::fabs((double)hi[a])));
+            L.clear_k = (float)(1.02 * b / (1.0 - 2.0 * b));
+            L.clear_r2 = (float)(2.0 * r_max_small * (1.0 + 1e-6));
+            L.clear_slack = (float)(64.0 * U24 * maxabs);
+            (void)clo; (void)chi;
         }
         L.trust_r0 = (float)(dom.r0 * (1.0 - 1e-6));
         near_reach = std::isfinite(reach) ? (float)(reach * (1.0 - 1e-5)) : 3.0e38f;
@@ -938,20 +962,29 @@ struct Builder {
         std::vector<RtObj> all_units;           // (every unit has its tie ranks, the long ones too)
         if (ok && retree_units) {
             all_units = objs;
-            proven = want_proof && allow_unit && rt_grow_units(objs);
+            // Two proven forms.  The NEAR form first where its reach spans the small spheres' whole box (hardly a segment is walked twice
+            // then, and own boxes are tighter gates than the reference's units: the InOneWeekend scene +3 %), else the UNIT form where
+            // it is cheap, else the near form whatever its reach (long units: the 10^6-sphere stress scene).  (A world of spheres
+            // converts nothing but sphere references: collecting twice has no side effect to undo.)
             // (the test switches gate_grow = false / another padding leave a tree the lemma does not cover: it is never reported as proven
             // and, like any unproven tree, takes VK_SCENE_EMPIRICAL_TREES)
-            if (!gate_grow || gate_pad != RT_PAD) proven = false;
-            if (!proven && want_proof && allow_near && gate_grow && gate_pad == RT_PAD) {
-                // the unit form is not eligible (long units): the near form, sphere by sphere (a world of spheres converts nothing but
-                // sphere references: collecting again has no side effect to undo)
-                std::vector<RtObj> own;
+            const bool provable = want_proof && gate_grow && gate_pad == RT_PAD;
+            std::vector<RtObj> own;
+            bool near_ok = false;
+            if (provable && allow_near) {
                 own.reserve((size_t)simple_count[root]);
                 own_gates = true;
                 bool ok2 = true;
                 if (!rt_collect(root, flip, inst, own, ok2)) return false;
-                if (ok2 && rt_grow_near(own)) { objs.swap(own); all_units.clear(); proven = true; near_form = true; }
-                else own_gates = false;
+                near_ok = ok2 && rt_grow_near(own);
+                own_gates = false;
+            }
+            const bool spans = near_spans;
+            proven = false;
+            if (!(near_ok && spans && near_first)) proven = provable && allow_unit && rt_grow_units(objs);
+            if (!proven && near_ok) {
+                // (rt_grow_units writes the trusted ball only where it succeeds: the near form's is still in place)
+                objs.swap(own); all_units.clear(); proven = true; near_form = true; own_gates = true;
             }
             if (!proven && proof_only) ok = false;      // (no VK_SCENE_EMPIRICAL_TREES: the tree as handed over rather than an unproven one)
         }
@@ -1218,7 +1251,7 @@ int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, con
     b.gate_grow = opt.gate_grow;
     b.want_proof = opt.want_proof;
     b.proof_only = !(desc && (desc->flags & VK_SCENE_EMPIRICAL_TREES) != 0u) && !opt.allow_empirical;
-    b.allow_near = opt.near_form; b.allow_unit = opt.unit_form;
+    b.allow_near = opt.near_form; b.allow_unit = opt.unit_form; b.near_first = opt.near_first;
     if (opt.t_pad > 0.0f && opt.t_pad < 1.0f) b.gate_pad = opt.t_pad;
     if (!b.run()) return b.status == VK_OK ? VK_ERR_BAD_ARG : b.status;
     out.world_items = b.world_items;
@@ -1249,6 +1282,7 @@ int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, con
         // none in 12 G: DESIGN.md section 5), every origin "trusted".
         out.proven = b.proven;
         out.near_form = b.near_form; out.reach = b.near_form ? b.near_reach : 0.0f; out.near_radius = b.near_radius;
+        out.near_spans = b.near_form && b.near_spans;
         out.t_pad = (float)(b.near_form ? RT_PAD_NEAR : (b.proven ? RT_PAD : RT_PAD_EMPIRICAL));
         if (opt.t_pad > 0.0f && opt.t_pad < 1.0f) out.t_pad = opt.t_pad;
         if (!b.proven) { out.trust_c0[0] = out.trust_c0[1] = out.trust_c0[2] = 0.0f; out.trust_r0 = INFINITY; }

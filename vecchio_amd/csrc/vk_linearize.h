@@ -43,11 +43,12 @@ struct LinearScene {
     // near_radius of it; a segment's result stands only if its hit lies within `reach` of its origin (DScene::reach).  Needs both trees in
     // items[] (a scene traversed from global memory): vk_api.hip keeps such a scene out of LDS.
     bool near_form = false;
+    bool near_spans = false;      // ... whose reach spans the small spheres' whole box: staged in LDS where it fits (vk_api.hip plan_residency)
     float reach = 0.0f, near_radius = 0.0f;
     // for the per-frame "primary rays straight to the tree as handed over" decision (vk_api.hip): the box around the small spheres and
     // the always-sound big ones (centre, radius), at most 8 (more: n_big = ~0 and the decision is "no")
     float small_lo[3] = {0, 0, 0}, small_hi[3] = {0, 0, 0};     // (box around the small spheres' surfaces)
-    float small_clo[3] = {0, 0, 0}, small_chi[3] = {0, 0, 0}, clear_margin = 0.0f;      // DScene: the box of their CENTRES, the clearance
+    float clear_k = 0.0f, clear_r2 = 0.0f, clear_slack = 0.0f;      // DScene: the clearance test's constants
     uint32_t n_big = 0; float big[8][4] = {};
     uint32_t features = 0;
     uint32_t n_prims = 0;
@@ -77,6 +78,7 @@ struct LinearizeOptions {
                                 // still takes VK_SCENE_EMPIRICAL_TREES in the description)
     bool near_form = true;      // VK_NEAR_FORM=0 (emulator / debug library): no near form where the unit form is not eligible
     bool unit_form = true;      // VK_UNIT_FORM=0 (emulator / debug library): the near form even where the unit form is eligible (comparisons)
+    bool near_first = true;     // VK_NEAR_FIRST=0 (emulator / debug library): the unit form where both are eligible (comparisons)
     bool allow_empirical = false;   // tests/emu and the debug library, VK_EMPIRICAL_TREES=1: as vk_scene_desc.flags & VK_SCENE_EMPIRICAL_TREES
 };
 

@@ -597,6 +597,27 @@ template <uint32_t F>
 VK_HD float gate_of(const Lane &L, const DScene &S) {
     return ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && S.t_pad > 0.0f && L.i >= S.walk_start) ? L.T * (1.0f + S.t_pad) : L.T;
 }
+// The near form's clearance test (DScene::clear_k): beyond `reach` the ray stays outside the box around the small spheres' surfaces grown by
+// M = clear_k (D_far + clear_r2) + clear_slack, D_far = the origin's distance from the box's far corner — then no sphere farther than
+// rho_near from the origin holds a candidate (docs/gate_lemma.md section 7).  A slab test in the ray's parameter: inside the grown box
+// for t in [tin, tout]; clear iff that interval is empty or ends before reach.  `inv` are the lane's reciprocals (v_rcp_f32: 1 ulp, times
+// gate_scale: another), so the parameters carry gate_scale and an error of 4 u |b - o| in position — a thousandth of the 2 % in clear_k.
+// (Ordinary rays only: no zero component.)
+VK_HD bool clear_of_small_spheres(const DScene &S, V3 o, V3 inv, float dn) {
+    const float fx = fmaxf(fabsf(o.x - S.small_clo[0]), fabsf(o.x - S.small_chi[0]));
+    const float fy = fmaxf(fabsf(o.y - S.small_clo[1]), fabsf(o.y - S.small_chi[1]));
+    const float fz = fmaxf(fabsf(o.z - S.small_clo[2]), fabsf(o.z - S.small_chi[2]));
+    const float dfar = sqrtf(fx * fx + fy * fy + fz * fz);
+    const float m = __builtin_fmaf(S.clear_k, dfar + S.clear_r2, S.clear_slack);
+    const float x0 = ((S.small_clo[0] - m) - o.x) * inv.x, x1 = ((S.small_chi[0] + m) - o.x) * inv.x;
+    const float y0 = ((S.small_clo[1] - m) - o.y) * inv.y, y1 = ((S.small_chi[1] + m) - o.y) * inv.y;
+    const float z0 = ((S.small_clo[2] - m) - o.z) * inv.z, z1 = ((S.small_chi[2] + m) - o.z) * inv.z;
+    const float tin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    const float tout = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    // (a NaN anywhere: not clear)
+    return (tin > tout) || (tout * dn < S.reach * S.gate_scale);
+}
+
 // Must the segment just walked (on the rebuilt tree: the lane's reciprocals are the scaled ones) be decided by the tree as handed over?
 // Decided on the scaled fast-path quantities with the box test's own margin on the side of "unsafe": a false positive costs one walk
 // (or one sample) done twice.
@@ -613,16 +634,7 @@ VK_HD bool segment_unsafe(const Lane &L, const DScene &S, const Mem &M) {
     if (S.reach > 0.0f) {
         const float dn = sqrtf(L.a);
         bool stands = L.T * dn <= S.reach;
-        if (!stands) {
-            // ... or the ray runs clear of every small sphere beyond `reach` (DScene::clear_margin): then no sphere outside rho_near holds a
-            // candidate at all, and what the walk found — a miss, a far hit on an always-sound sphere — is complete
-            const float k = S.reach / dn;
-            const V3 p = v3(L.o.x + L.d.x * k, L.o.y + L.d.y * k, L.o.z + L.d.z * k);
-            const float sl = 2.0e-3f * dn;
-            stands = (L.d.x >= sl && p.x - S.small_chi[0] >= S.clear_margin) || (L.d.x <= -sl && S.small_clo[0] - p.x >= S.clear_margin) ||
-                     (L.d.y >= sl && p.y - S.small_chi[1] >= S.clear_margin) || (L.d.y <= -sl && S.small_clo[1] - p.y >= S.clear_margin) ||
-                     (L.d.z >= sl && p.z - S.small_chi[2] >= S.clear_margin) || (L.d.z <= -sl && S.small_clo[2] - p.z >= S.clear_margin);
-        }
+        if (!stands) stands = clear_of_small_spheres(S, L.o, L.inv, dn);
         unsafe = unsafe || !stands;
     }
     if (L.best_prim != 0u) {
