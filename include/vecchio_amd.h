@@ -185,13 +185,14 @@ typedef struct vk_scene_desc {
  * and whenever its winner is not certain to be the reference's too — a hit not safely behind its own box's entry, a ray from outside
  * the region the bound was derived for — the tree as handed over decides (the segment is walked again, or its sample is rendered by
  * a second launch).  That this reproduces BVHNode::hit is a THEOREM given the bound (the "gate lemma"; forward error analysis, K < 30
- * against the 32 used; tests/test_gate_lemma.py attacks it with 10^7 adversarial rays).  The grown boxes are used only where they are
- * cheap (vk_scene_info.tree == VK_TREE_REBUILT_PROVEN: the InOneWeekend scene, +28 % throughput).  A world whose reference tree has
- * very long leaf boxes (BVHNode::new's random axes on the 1 M-sphere stress scene) is walked in the NEAR form instead (ABI 6,
- * VK_TREE_REBUILT_NEAR): every sphere behind its OWN box, which is sound for ray origins within ~144 radii of the sphere; a segment's
- * result is taken only if its hit lies within that reach of its origin or the ray provably runs clear of every small sphere beyond it,
- * and every other segment is walked again on the tree as handed over (both trees stay in device memory; docs/gate_lemma.md section 7;
- * +80 % on that scene).  A world for which neither form applies is walked as handed over.
+ * against the 32 used; tests/test_gate_lemma.py attacks it with 10^7 adversarial rays).  Two proven forms (vk_scene_info.tree).  The
+ * NEAR form (ABI 6, VK_TREE_REBUILT_NEAR): every sphere behind its OWN box, which is sound for ray origins within a trusted radius of
+ * the sphere (~144 radii); a segment's result is taken only if its hit lies within that reach of its origin or the ray provably runs
+ * clear of every small sphere beyond it, and every other segment is decided by the tree as handed over (both trees stay in device
+ * memory; docs/gate_lemma.md section 7).  It is the default where its reach spans the world's small spheres (the InOneWeekend scene:
+ * +20 % throughput over the tree handed over) and where the other form is too dear (BVHNode::new's long leaf boxes on the 1 M-sphere
+ * stress scene: +85 %).  The UNIT form (VK_TREE_REBUILT_PROVEN): the reference's leaf units as gates, grown by the bound — where that is
+ * cheap and the near form's reach does not span the world.  A world for which neither form applies is walked as handed over.
  * VK_SCENE_REFERENCE_TREE: walk the tree handed over and nothing else.
  * VK_SCENE_EMPIRICAL_TREES: allow the rebuilt tree also where NEITHER proven form applies (since ABI 6: worlds with a sphere far
  * smaller than the rest; the environment's VK_GATE_PROOF=0 prefers it to the proven forms, for comparisons) — with the units' boxes as
@@ -363,7 +364,8 @@ enum {
     VK_TREE_REBUILT_FAST = 3,       /* VK_SCENE_FAST_ACCEL */
     VK_TREE_REBUILT_NEAR = 4        /* exact re-treeing, near form (ABI 6): every sphere behind its own box, a segment's result taken only
                                        where no sphere beyond that box's trusted radius can matter, else walked again on the tree handed
-                                       over: proven like VK_TREE_REBUILT_PROVEN; worlds whose leaf units are too long for that form */
+                                       over: proven like VK_TREE_REBUILT_PROVEN; taken first where its reach spans the world's small
+                                       spheres, and for worlds whose leaf units are too long for the unit form */
 };
 int vk_scene_get_info(const vk_scene *scene, vk_scene_info *out);
 
