@@ -105,3 +105,17 @@ def test_sample_stream_statistics(oracle):
     c, dof = _chi2(np.histogram2d(first[:-1, 0], first[1:, 0], bins=24, range=((0, 1), (0, 1)))[0])
     assert abs(c - dof) < 5.0 * np.sqrt(2.0 * dof), (c, dof)
     assert abs(np.corrcoef(first[:-1, 0], first[1:, 0])[0, 1]) < 0.02
+
+
+def test_the_ranges_whose_redraw_test_never_fires():
+    """vk_math.h gen_pm1 / gen_0_to restate gen_range(-1, 1) and gen_range(0, 2 pi) without rand 0.7.3's `if res < high` loop
+    (UniformFloat::sample_single): every one of the 2^23 possible draws gives res < high, in f32 arithmetic as the code performs it
+    (one multiply, one add, each rounded)."""
+    k = np.arange(1 << 23, dtype=np.uint32)
+    v01 = ((k | np.uint32(0x3F800000)).view(np.float32) - np.float32(1.0)).astype(np.float32)
+    pm1 = (v01 * np.float32(2.0)).astype(np.float32) + np.float32(-1.0)
+    assert pm1.dtype == np.float32 and pm1.max() < np.float32(1.0) and pm1.min() == np.float32(-1.0)
+    assert pm1.max() == np.float32(1.0 - 2.0 ** -22)
+    two_pi = np.float32(2.0) * np.float32(3.14159265358979323846)
+    a = (v01 * two_pi).astype(np.float32) + np.float32(0.0)
+    assert a.max() < two_pi and a.min() == 0.0

@@ -310,6 +310,48 @@ __device__ __forceinline__ PreTurb cooperative_turb(const Lane &L, const DScene 
     return pt;
 }
 
+// ---- random_in_unit_sphere for the lanes about to scatter off a Metal (or an Isotropic), drawn by the WHOLE wave.  The rejection loop
+// (util.rs:31-40) accepts 52 % of its candidates: run lane by lane, a wave with ten such lanes iterates four times on average, and
+// removing the loop altogether would make the InOneWeekend scene 7.7 % faster (profiles/r05/experiments).  The generator is
+// counter-based — candidate m of a lane's loop is draws ctr + 3m + 1 .. 3 of its stream, whoever computes them — so the 64 lanes are
+// dealt evenly to the K lanes that need a point: lane h draws candidate h mod G of the lane of rank h / G, G = 64 / K, and the
+// owner takes the first one inside the sphere (the loop's own choice).  One round nearly always does (0.476^6 = 1 %); the rest go round
+// again with the wave regrouped.
+__device__ __forceinline__ PreBall cooperative_ball(bool want, const Rng &rng, uint32_t lane) {
+    PreBall out = no_pre_ball();
+    uint32_t m0 = 0u;                                    // candidates of this lane's loop already refused
+    unsigned long long need = __builtin_amdgcn_ballot_w64(want);
+    while (need != 0ull) {                               // (wave-uniform)
+        const uint32_t K = (uint32_t)__popcll(need), G = 64u / K;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+        // table rank -> lane (a push: lanes that need nothing write entry 63, which is an owner's only when all 64 are)
+        const int tbl = __builtin_amdgcn_ds_permute((int)((want ? rank : 63u) << 2), (int)lane);
+        const uint32_t j = (lane * ((65536u + G - 1u) / G)) >> 16;      // lane / G (exact below 64)
+        const uint32_t c = lane - j * G;
+        const int owner = __builtin_amdgcn_ds_bpermute((int)((j < 63u ? j : 63u) << 2), tbl) << 2;
+        const uint32_t klo = (uint32_t)__builtin_amdgcn_ds_bpermute(owner, (int)(uint32_t)rng.key);
+        const uint32_t khi = (uint32_t)__builtin_amdgcn_ds_bpermute(owner, (int)(uint32_t)(rng.key >> 32));
+        const uint32_t cb = (uint32_t)__builtin_amdgcn_ds_bpermute(owner, (int)(rng.ctr + 3u * m0));
+        bool inside;
+        const V3 p = ball_candidate((uint64_t)klo | ((uint64_t)khi << 32), cb + 3u * c, inside);
+        const unsigned long long fl = __builtin_amdgcn_ballot_w64(inside && j < K);
+        // the owner's helpers are lanes rank * G .. rank * G + G - 1
+        const uint32_t lo = rank * G;
+        const unsigned long long grp = want ? ((fl >> (lo & 63u)) & (G == 64u ? ~0ull : ((1ull << G) - 1ull))) : 0ull;
+        const uint32_t first = grp ? (uint32_t)__builtin_ctzll(grp) : 0u;
+        const int src = (int)(((lo + first) & 63u) << 2);
+        const float x = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(p.x)));
+        const float y = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(p.y)));
+        const float z = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(p.z)));
+        if (want) {
+            if (grp) { want = false; out.have = 1u; out.p = v3(x, y, z); out.skip = 3u * (m0 + first + 1u); }
+            else m0 += G;
+        }
+        need = __builtin_amdgcn_ballot_w64(want);
+    }
+    return out;
+}
+
 // ---- the SHADE + REFILL phase body: shade the lanes whose segment is fully traversed, deposit finished samples, hand new
 // samples to the lanes without a path.  Leaves `fresh` lanes with a new ray parked in L.wo / L.wd / L.time, which the caller
 // installs with ONE begin_segment (its three exact reciprocals are ~60 instructions per call site). Used inline by the lean variants and
@@ -365,13 +407,32 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool e
         }
     }
     touched = is_shade;
+    PreBall pre_ball = no_pre_ball();
+    if constexpr (F == 0u && LDS_SCENE) {
+        // (the sphere-only scatter variant staged in LDS — the headline's: the material is one gather away, shade_core reads the same
+        // record; before the path's other cold state is loaded: the traversal state of the lanes that are not shading stays live
+        // through this phase, registers are short.  Its PDF twin and the global-memory variants would spill more than they gain.)
+        bool want = false;
+        Rng g; g.key = 0ull; g.ctr = 0u;
+        if (is_shade && L.best_prim != 0u) {
+            const uint32_t kind = S.sphere_material[VKD_INDEX(L.best_prim)].kind;
+            want = kind == VK_MAT_METAL || kind == VK_MAT_ISOTROPIC;
+        }
+        if (want) {
+            g.key = (uint64_t)__float_as_uint(cold[CF_KEY * 64 + lane]) | ((uint64_t)__float_as_uint(cold[(CF_KEY + 1) * 64 + lane]) << 32);
+            g.ctr = __float_as_uint(cold[CF_CTR * 64 + lane]);
+        }
+        pre_ball = cooperative_ball(want, g, lane);
+    }
     if (is_shade) {
         if (STATS) st_t1 = clock64();
         cold_load_path<F>(cold, lane, L);
         if (STATS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); clk.cold += clock64() - st_t1; }
+    }
+    if (is_shade) {
         if (STATS) st_t1 = clock64();
         V3 no, nd; float nt;
-        bool cont = shade_core<F, Mem>(L, S, M, C, no, nd, nt, pre_turb);
+        bool cont = shade_core<F, Mem>(L, S, M, C, no, nd, nt, pre_turb, pre_ball);
         if (cont) { L.wo = no; L.wd = nd; L.time = nt; fresh = true; }
         if (STATS) st_t_mat += clock64() - st_t1;
         if (!cont) {

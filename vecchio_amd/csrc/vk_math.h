@@ -117,6 +117,24 @@ template <class R> VK_HD float gen_range(R &r, float lo, float hi) {
     }
 }
 
+// gen_range(r, -1.0f, 1.0f) without its loop: the redraw test can never fire for this range.  v01 = k 2^-23 with k < 2^23; v01 * 2 is
+// exact; 2 v01 - 1 is a multiple of 2^-22 of magnitude <= 1, hence exact too, and at most 1 - 2^-22 < hi.  (tests/test_math_rng.py
+// walks all 2^23 values.)  The rejection samplers built on it (util.rs:31-52) then have ONE loop, not one per coordinate inside it.
+template <class R> VK_HD float gen_pm1(R &r) {
+    float v12 = bits_f32((next_u32(r) >> 9) | 0x3F800000u);
+    float v01 = v12 - 1.0f;
+    return v01 * 2.0f + -1.0f;
+}
+
+// gen_range(r, 0.0f, hi) for a CONSTANT hi for which the redraw test can never fire either: fl(v01 * hi) < hi for every v01 <= 1 - 2^-23
+// when (1 - 2^-23) hi lies more than half an ulp below hi — true unless hi is a power of two (its lower neighbour is half as far);
+// used for hi = 2 pi (6.2831855: 1.57 ulps below).  tests/test_math_rng.py walks all 2^23 values.
+template <class R> VK_HD float gen_0_to(R &r, float hi) {
+    float v12 = bits_f32((next_u32(r) >> 9) | 0x3F800000u);
+    float v01 = v12 - 1.0f;
+    return v01 * hi + 0.0f;
+}
+
 // rand 0.7.3 UniformInt<u32>::sample_single(0, n) as used by SliceRandom::choose/gen_index
 template <class R> VK_HD uint32_t gen_index(R &r, uint32_t n) {
     uint32_t range = n;

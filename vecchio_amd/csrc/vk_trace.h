@@ -1007,15 +1007,33 @@ VK_HD V3 material_color(const DScene &S, const DMaterial &m, const Rec &R, const
 // ------------------------------------------------------------------ samplers (util.rs:31-63, material.rs:51-58)
 VK_HD V3 random_in_unit_sphere(Rng &g) {
     for (;;) {
-        float x = vk::gen_range(g, -1.0f, 1.0f), y = vk::gen_range(g, -1.0f, 1.0f), z = vk::gen_range(g, -1.0f, 1.0f);
+        float x = vk::gen_pm1(g), y = vk::gen_pm1(g), z = vk::gen_pm1(g);      // gen_range(-1, 1)
         V3 p = v3(x, y, z);
         if (length2(p) >= 1.0f) continue;
         return p;
     }
 }
+// A point of random_in_unit_sphere computed ahead by the wave (vk_kernels.h cooperative_ball: the generator is counter-based, so the
+// candidates of one lane's rejection loop can be drawn by other lanes).  `skip` draws of the lane's stream are accounted for; `have`:
+// they end with the accepted point `p` (nothing computed ahead: skip = 0, have = 0, and the loop runs here).
+struct PreBall { uint32_t skip, have; V3 p; };
+VK_HD PreBall no_pre_ball() { PreBall b; b.skip = 0u; b.have = 0u; b.p = v3s(0.0f); return b; }
+VK_HD V3 ball_sample(Rng &g, const PreBall &pb) {
+    g.ctr += pb.skip;
+    if (pb.have) return pb.p;
+    return random_in_unit_sphere(g);
+}
+// one candidate of that loop, from draws ctr+1 .. ctr+3 of the stream `key`
+VK_HD V3 ball_candidate(uint64_t key, uint32_t ctr, bool &inside) {
+    Rng g; g.key = key; g.ctr = ctr;
+    float x = vk::gen_pm1(g), y = vk::gen_pm1(g), z = vk::gen_pm1(g);
+    V3 p = v3(x, y, z);
+    inside = !(length2(p) >= 1.0f);
+    return p;
+}
 VK_HD V3 random_in_unit_disk(Rng &g) {
     for (;;) {
-        float x = vk::gen_range(g, -1.0f, 1.0f), y = vk::gen_range(g, -1.0f, 1.0f);
+        float x = vk::gen_pm1(g), y = vk::gen_pm1(g);
         V3 p = v3(x, y, 0.0f);
         if (length2(p) >= 1.0f) continue;
         return p;
@@ -1031,8 +1049,8 @@ VK_HD V3 random_cosine_direction(Rng &g) {
     return v3(x, y, z);
 }
 VK_HD V3 lambertian_random(Rng &g) {
-    float a = vk::gen_range(g, 0.0f, 2.0f * PI_F);
-    float z = vk::gen_range(g, -1.0f, 1.0f);
+    float a = vk::gen_0_to(g, 2.0f * PI_F);                   // gen_range(0, 2 pi)
+    float z = vk::gen_pm1(g);                                 // gen_range(-1, 1)
     float r = sqrtf(1.0f - z * z);
     vk::SinCos sc = vk::sincosf_(a);
     return v3(r * sc.c, r * sc.s, z);
@@ -1184,7 +1202,7 @@ VK_HD V3 background_of(const RenderConsts &C, V3 ud) {       // ud = unit(ray di
 // its radiance).
 template <uint32_t F, class Mem>
 VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts &C, V3 &no, V3 &ndir, float &ntime,
-    const PreTurb &pt = no_pre_turb()) {
+    const PreTurb &pt = no_pre_turb(), const PreBall &pb = no_pre_ball()) {
     const bool miss = L.best_prim == 0;
     Rec R;
     const DMaterial *m = S.materials;
@@ -1222,7 +1240,7 @@ VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts
             atten = material_color<F>(S, *m, R, pt);
         } else if (kind == VK_MAT_METAL) {                    // material.rs:118-132
             V3 reflected = reflect(ud, R.n);
-            ndir = reflected + random_in_unit_sphere(L.rng) * m->param;
+            ndir = reflected + ball_sample(L.rng, pb) * m->param;      // (no draw before it: see cooperative_ball)
             atten = material_color<F>(S, *m, R, pt);
             scattered = dot(ndir, R.n) > 0.0f;
         } else if (kind == VK_MAT_DIELECTRIC) {               // material.rs:150-175
@@ -1237,7 +1255,7 @@ VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts
                 else ndir = refract(ud, R.n, eta);
             }
         } else if (kind == VK_MAT_ISOTROPIC) {                // material.rs:442-446
-            ndir = random_in_unit_sphere(L.rng);
+            ndir = ball_sample(L.rng, pb);
             atten = material_color<F>(S, *m, R, pt);
         } else {                                              // DiffuseLight: material.rs:215-225
             scattered = false;
@@ -1265,7 +1283,8 @@ VK_HD bool shade_core(Lane &L, const DScene &S, const Mem &M, const RenderConsts
         uint32_t kind = m->kind;
         if (kind == VK_MAT_METAL) {                           // material.rs:134-141 (Ray::new: time 0, never absorbs)
             V3 reflected = reflect(ud, R.n);
-            ndir = reflected + random_in_unit_sphere(L.rng) * m->param;
+            // (computed ahead only where the hit's own material is the Metal: no SpecDiffuse draw before it)
+            ndir = reflected + ball_sample(L.rng, pb) * m->param;
             ntime = 0.0f;
             L.thr = L.thr * material_color<F>(S, *m, R, pt);         // specular: emitted is NOT added (main.rs:134-137)
         } else if (kind == VK_MAT_DIELECTRIC) {               // material.rs:177-206
