@@ -118,6 +118,37 @@ def scatter_sky():
     return d, desc, cam, params(48, 32, 8, integrator=ffi.VK_INTEGRATOR_SCATTER, background=ffi.VK_BACKGROUND_SKY)
 
 
+def metal_only():
+    """spheres of fuzzy Metal only, filling the frame: every shading lane of a wave wants a random_in_unit_sphere point at once — the
+    device deals ONE candidate per lane and round (vk_kernels.h cooperative_ball, K = 64, G = 1) and regroups until the slowest
+    lane has accepted; paths bounce between the mirrors to the depth limit"""
+    d = Desc()
+    refs = [d.sphere((0, -1000.0, 0), 1000.0, d.mat(ffi.VK_MAT_METAL, d.solid(0.9, 0.9, 0.9), 0.6))]
+    for i in range(-3, 4):
+        for j in range(-3, 4):
+            refs.append(d.sphere((1.1 * i, 0.5, 1.1 * j), 0.5, d.mat(ffi.VK_MAT_METAL, d.solid(0.6 + 0.05 * i, 0.7, 0.6 + 0.05 * j),
+                                                                     0.05 * ((i + j) % 7 + 3))))
+    world = _bvh_chain(d, refs)
+    desc = d.finish(world, [])
+    cam = camera((4, 6, 5), (0, 0, 0), vfov=35.0, aspect=1.0, aperture=0.0, focus=8.0)
+    return d, desc, cam, params(64, 64, 8, integrator=ffi.VK_INTEGRATOR_SCATTER, background=ffi.VK_BACKGROUND_SKY)
+
+
+def one_metal_among_many():
+    """one small fuzzy Metal sphere among Lambertian ones: a wave seldom has more than a lane or two that want a sphere point — the
+    cooperative sampler's other extreme (K = 1: all 64 lanes draw candidates for one owner), and most phases have none at all"""
+    d = Desc()
+    refs = [d.sphere((0, -1000.0, 0), 1000.0, d.lambertian(0.5, 0.5, 0.5))]
+    for i in range(-3, 4):
+        for j in range(-3, 4):
+            m = d.mat(ffi.VK_MAT_METAL, d.solid(0.9, 0.8, 0.7), 1.0) if (i, j) == (0, 0) else d.lambertian(0.3 + 0.1 * (i % 3), 0.5, 0.4)
+            refs.append(d.sphere((1.1 * i, 0.5, 1.1 * j), 0.5, m))
+    world = _bvh_chain(d, refs)
+    desc = d.finish(world, [])
+    cam = camera((4, 6, 5), (0, 0, 0), vfov=35.0, aspect=1.0, aperture=0.1, focus=8.0)
+    return d, desc, cam, params(64, 64, 8, integrator=ffi.VK_INTEGRATOR_SCATTER, background=ffi.VK_BACKGROUND_SKY)
+
+
 def noise_everywhere():
     """Perlin noise textures wherever one can sit: on more spheres than the lineariser's noise-sphere list holds (the device then
     looks the material up), on a rect, on a Boxy, on a sphere under a transform, behind a checker, inside a SpecDiffuse and on a
@@ -143,4 +174,5 @@ def noise_everywhere():
 
 
 ALL = {"nested_transforms": nested_transforms, "noise_everywhere": noise_everywhere, "lights_and_specdiffuse": lights_and_specdiffuse,
-       "media_and_textures": media_and_textures, "scatter_sky": scatter_sky}
+       "media_and_textures": media_and_textures, "scatter_sky": scatter_sky, "metal_only": metal_only,
+       "one_metal_among_many": one_metal_among_many}
