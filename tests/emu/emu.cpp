@@ -35,6 +35,7 @@ static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string
     if (const char *e = getenv("VK_NEAR_FORM")) opt.near_form = e[0] != '0';
     if (const char *e = getenv("VK_UNIT_FORM")) opt.unit_form = e[0] != '0';
     if (const char *e = getenv("VK_NEAR_FIRST")) opt.near_first = e[0] != '0';
+    if (const char *e = getenv("VK_GRID_FORM")) opt.grid_form = e[0] != '0';
     return linearize(desc, LS, err, opt);
 }
 // EMU_GLOBAL_VARIANT=1: scenes of spheres only as the device runs them from GLOBAL memory (unfused box test; exact re-treeing with both
@@ -42,11 +43,23 @@ static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string
 static bool global_variant() { const char *e = getenv("EMU_GLOBAL_VARIANT"); return e && e[0] == '1'; }
 static DScene scene_view(const LinearScene &LS, std::vector<DItem> &both) {
     DScene S = LS.host_view();
+    if (const char *e = getenv("EMU_GRID")) { if (e[0] == '0') { S.grid.nu = 0u; S.trust_r0sq = LS.trust_r0 * LS.trust_r0; S.reach = LS.reach; } }
+    if (S.grid.nu != 0u && !LS.ref_items.empty()) {
+        // the grid form.  From LDS (default): a failed segment requeues its sample (trace_one: the whole sample again on reference_view).
+        // From global memory (EMU_GLOBAL_VARIANT=1): items[] is the tree as handed over, walk_start = its length (nothing rebuilt
+        // follows): a failed segment is walked again in place, as the device does it
+        if (global_variant()) {
+            S.items = LS.ref_items.data(); S.n_items = (uint32_t)LS.ref_items.size(); S.n_world_items = S.n_items; S.walk_start = S.n_items;
+            S.ref_items = nullptr; S.n_ref_items = 0; S.unit_tree = LS.ref_items.data();
+        }
+        return S;
+    }
     // (the near form whose reach does not span its small spheres: both trees in items[], as the device keeps it)
     if ((global_variant() || (LS.near_form && !LS.near_spans)) && !LS.ref_items.empty()) {
         uint32_t ws = 0;
         both = LS.combined_items(ws);
         S.items = both.data(); S.n_items = (uint32_t)both.size(); S.n_world_items = (uint32_t)both.size(); S.walk_start = ws;
+        S.unit_tree = both.data();      // (the tree as handed over comes first, item for item)
         S.ref_items = nullptr; S.n_ref_items = 0;
         if (const char *e = getenv("EMU_PRIMARY_REF")) S.primary_ref = e[0] == '1';       // (what vk_api.hip decides per frame)
     }
@@ -62,6 +75,7 @@ static DScene reference_view(const DScene &S) {
     DScene r = S;
     r.items = S.ref_items; r.n_items = S.n_ref_items; r.n_world_items = S.n_ref_items;
     r.ref_items = nullptr; r.n_ref_items = 0; r.t_pad = 0.0f; r.gate_scale = 1.0f; r.tmin_gate = T_MIN; r.tie_rank = nullptr;
+    r.grid.nu = 0u;
     return r;
 }
 

@@ -90,6 +90,20 @@ enum : uint32_t {  // feature bits -> kernel variant selection
                           // vk_kernels.h cooperative_turb)
 };
 
+// The GRID form of exact re-treeing (vk_linearize.cpp rt_build_grid, vk_trace.h grid_step; docs/gate_lemma.md section 8): a world of
+// spheres whose small spheres lie in a layer (the reference's random_spheres worlds) is walked on a uniform 2-D grid over the layer's
+// plane (x, z; the layer's normal is y) instead of a tree.  Every small sphere is registered in the cells its box overlaps; the few
+// others (a ground sphere, large spheres: at most 8) are tested for every segment.  A segment visits the cells within
+// dl = k (s_exit + r2) + slack of its path through the layer's box — as far as an f32 Sphere::hit can report a hit off its sphere
+// (the residual bound of the gate lemma) — so EVERY sphere that holds a candidate is tested, wherever the ray starts.
+struct DGrid {
+    uint32_t nu, nv;              // cells along x and z (0: no grid); cell c = ix * nv + iz
+    float ou, ov, cell, inv_cell; // the grid's corner and cell size
+    float lo[3], hi[3];           // the box around the registered spheres' surfaces
+    float k, r2, slack;           // the dilation: dl = k (s + r2) + slack
+    uint32_t n_always;            // refs[0, n_always): the spheres tested for every segment; cells' lists follow
+};
+
 // What the kernel sees.  All pointers are device (or, in the CPU emulator, host) addresses.
 struct DScene {
     const DItem *items; uint32_t n_items; uint32_t n_world_items;   // world range = items[0, n_world_items); instance ranges follow
@@ -144,6 +158,11 @@ struct DScene {
     // ... and, decided per frame by the host: primary rays (depth 1) start on the tree as handed over (the camera is farther than
     // `reach` from everything, so their rebuilt walk could never stand)
     uint32_t primary_ref;
+    // The grid form (DGrid above): cells[c] .. cells[c + 1] is cell c's range in refs[] (sphere references)
+    DGrid grid; const uint32_t *grid_cells; const uint32_t *grid_refs;
+    // exact re-treeing: unit_item[sphere] = the item of the tree as handed over whose box gates the sphere there (its leaf); null: none.
+    // unit_tree = that tree's items (ref_items, or items[] when both trees share it: DScene::walk_start)
+    const uint32_t *unit_item; const DItem *unit_tree;
 };
 
 }  // namespace vkd

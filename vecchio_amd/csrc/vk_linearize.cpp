@@ -40,6 +40,14 @@ DScene LinearScene::host_view() const {
     s.reach = ref_items.empty() ? 0.0f : reach; s.primary_ref = 0u;
     for (int k = 0; k < 3; k++) { s.small_clo[k] = small_lo[k]; s.small_chi[k] = small_hi[k]; }
     s.clear_k = clear_k; s.clear_r2 = clear_r2; s.clear_slack = clear_slack;
+    // (only where Lemma 1 is PROVEN: in the empirical form the stricter own-box test is part of what keeps it right in practice)
+    s.unit_item = (ref_items.empty() || unit_item.empty() || !proven) ? nullptr : unit_item.data(); s.unit_tree = ref_items.data();
+    if (!ref_items.empty() && grid.nu != 0u) {
+        // the grid form: sound for every ordinary ray wherever it starts — no ball, no reach (vk_trace.h segment_unsafe keeps the
+        // safe-winner test)
+        s.grid = grid; s.grid_cells = grid_cells.data(); s.grid_refs = grid_refs.data();
+        s.trust_r0sq = INFINITY; s.reach = 0.0f;
+    }
     s.fast_div = 1u;
     for (const DSphere &sp : spheres)
         if (!(fabsf(sp.cx) < 1073741824.0f && fabsf(sp.cy) < 1073741824.0f && fabsf(sp.cz) < 1073741824.0f && fabsf(sp.r) < 1073741824.0f)) s.fast_div = 0u;
@@ -919,6 +927,94 @@ struct Builder {
         return true;
     }
 
+    // ---- The GRID form of exact re-treeing (round 5; DGrid in vk_device_scene.h, vk_trace.h grid_step, docs/gate_lemma.md section 8).
+    // `units`: every sphere of the world (dref, dref2).  Eligible: spheres of positive radius only (the caller saw to that), all but at
+    // most 8 of them "small" (radius <= 2.5 median radii) and lying in a LAYER across y — the box around their surfaces at least four
+    // times as wide in x and in z as in y — and at least 64 of them.  Cell size: one small sphere per cell on average, never below 2.5
+    // median radii (a sphere's box then overlaps four cells at most), never so small that a side needs more than 1000 cells.
+    bool allow_grid = true;
+    bool rt_build_grid(const std::vector<RtObj> &units) {
+        L.grid = DGrid{}; L.grid_cells.clear(); L.grid_refs.clear();
+        std::vector<uint32_t> all;
+        for (const RtObj &u : units) { all.push_back(u.dref); if (u.dref2) all.push_back(u.dref2); }
+        for (uint32_t r : all) if (VKD_KIND(r) != DK_SPHERE) return false;
+        if (all.size() < 72u) return false;
+        std::vector<float> rr;
+        for (uint32_t r : all) {
+            const DSphere &sp = L.spheres[VKD_INDEX(r)];
+            if (!(sp.r > 9.0949470177292824e-13f && sp.r < 1073741824.0f && std::fabs(sp.cx) < 1073741824.0f && std::fabs(sp.cy) < 1073741824.0f &&
+                  std::fabs(sp.cz) < 1073741824.0f)) return false;
+            rr.push_back(sp.r);
+        }
+        std::vector<float> tmp = rr;
+        std::nth_element(tmp.begin(), tmp.begin() + tmp.size() / 2, tmp.end());
+        const double r_med = tmp[tmp.size() / 2];
+        std::vector<uint32_t> always, field;
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, r_max = 0.0;
+        for (size_t i = 0; i < all.size(); i++) {
+            const DSphere &sp = L.spheres[VKD_INDEX(all[i])];
+            if ((double)sp.r > 2.5 * r_med) { always.push_back(all[i]); continue; }
+            field.push_back(all[i]);
+            const double c[3] = {sp.cx, sp.cy, sp.cz};
+            for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], c[a] - (double)sp.r); hi[a] = std::max(hi[a], c[a] + (double)sp.r); }
+            r_max = std::max(r_max, (double)sp.r);
+        }
+        if (always.size() > 8u || field.size() < 64u) return false;
+        const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        if (!(ex >= 4.0 * ey && ez >= 4.0 * ey && ex > 0.0 && ez > 0.0)) return false;
+        double h = std::sqrt(ex * ez / (double)field.size());
+        h = std::max(h, 2.5 * r_med);
+        h = std::max(h, std::max(ex, ez) / 990.0);
+        double maxabs = 0.0;
+        for (int a = 0; a < 3; a++) maxabs = std::max(maxabs, std::max(std::fabs(lo[a]), std::fabs(hi[a])));
+        // the cells' own margin: a sphere is registered wherever its box comes within m_reg of a cell, the walk visits every cell within
+        // dl + m_walk of the ray: together they cover the f32 rounding of both (2^-20 of the coordinates, 2^-10 of a cell)
+        const double m_reg = h / 1024.0 + maxabs / 1048576.0;
+        const double g0x = lo[0] - 2.0 * m_reg, g0z = lo[2] - 2.0 * m_reg;
+        const uint32_t nu = (uint32_t)std::ceil((ex + 4.0 * m_reg) / h), nv = (uint32_t)std::ceil((ez + 4.0 * m_reg) / h);
+        if (nu < 1u || nv < 1u || nu > 1000u || nv > 1000u) return false;
+        const float hf = (float)h, g0xf = (float)g0x, g0zf = (float)g0z;
+        std::vector<uint32_t> count((size_t)nu * nv + 1u, 0u);
+        auto range = [&](double a, double b, float g0, uint32_t n, uint32_t &i0, uint32_t &i1) {
+            const double f0 = std::floor((a - m_reg - (double)g0) / (double)hf), f1 = std::floor((b + m_reg - (double)g0) / (double)hf);
+            i0 = (uint32_t)std::min<double>(std::max(f0, 0.0), (double)(n - 1u)); i1 = (uint32_t)std::min<double>(std::max(f1, 0.0), (double)(n - 1u));
+        };
+        for (int pass = 0; pass < 2; pass++) {
+            for (uint32_t r : field) {
+                const DSphere &sp = L.spheres[VKD_INDEX(r)];
+                uint32_t x0, x1, z0, z1;
+                range((double)sp.cx - sp.r, (double)sp.cx + sp.r, g0xf, nu, x0, x1);
+                range((double)sp.cz - sp.r, (double)sp.cz + sp.r, g0zf, nv, z0, z1);
+                for (uint32_t ix = x0; ix <= x1; ix++)
+                    for (uint32_t iz = z0; iz <= z1; iz++) {
+                        const size_t c = (size_t)ix * nv + iz;
+                        if (pass == 0) count[c + 1]++;
+                        else L.grid_refs[count[c]++] = r;
+                    }
+            }
+            if (pass == 0) {
+                count[0] = (uint32_t)always.size();
+                for (size_t c = 1; c < count.size(); c++) count[c] += count[c - 1];
+                if (count.back() > (1u << 27)) return false;
+                L.grid_cells = count;
+                L.grid_refs.assign(count.back() + 1u, 0u);       // (+1: the walk reads refs in pairs)
+                for (size_t i = 0; i < always.size(); i++) L.grid_refs[i] = always[i];
+            }
+        }
+        DGrid &G = L.grid;
+        G.nu = nu; G.nv = nv; G.ou = g0xf; G.ov = g0zf; G.cell = hf; G.inv_cell = 1.0f / hf;
+        for (int a = 0; a < 3; a++) { G.lo[a] = std::nextafter((float)lo[a], -INFINITY); G.hi[a] = std::nextafter((float)hi[a], INFINITY); }
+        const double b = std::sqrt(RT_KAPPA);
+        G.k = (float)(1.05 * b / (1.0 - 2.0 * b));
+        G.r2 = (float)(2.0 * r_max * (1.0 + 1e-6));
+        G.slack = (float)(2.0 * m_reg);
+        G.n_always = (uint32_t)always.size();
+        if (getenv("VK_RETREE_DEBUG"))
+            fprintf(stderr, "vecchio_amd: exact re-treeing, grid form: %zu spheres in %u x %u cells of %g (%zu references), %zu tested always\n",
+                field.size(), nu, nv, h, L.grid_refs.size() - 1u - always.size(), always.size());
+        return true;
+    }
+
     // dense object id of a dref for the tie table: [spheres][rects][boxes][lists]
     uint32_t tie_id(uint32_t dref) const {
         uint32_t k = VKD_KIND(dref), i = VKD_INDEX(dref);
@@ -1015,6 +1111,7 @@ struct Builder {
                 if (first || VKD_KIND(dr) == DK_RECT) L.tie_rank[id] = (n_blocks << 20) | (k ? ranked[i].rank2 : ranked[i].rank);
             }
         }
+        if (retree_units && proven && allow_grid && inst < 0 && items0 == 0) (void)rt_build_grid(ranked);
         rt_emit(objs, 0, objs.size(), 0);
         done = true;
         if (inst < 0 && VK_REF_KIND(d->world) == VK_KIND_BVH && root == VK_REF_INDEX(d->world)) world_rebuilt = true;
@@ -1251,7 +1348,7 @@ int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, con
     b.gate_grow = opt.gate_grow;
     b.want_proof = opt.want_proof;
     b.proof_only = !(desc && (desc->flags & VK_SCENE_EMPIRICAL_TREES) != 0u) && !opt.allow_empirical;
-    b.allow_near = opt.near_form; b.allow_unit = opt.unit_form; b.near_first = opt.near_first;
+    b.allow_near = opt.near_form; b.allow_unit = opt.unit_form; b.near_first = opt.near_first; b.allow_grid = opt.grid_form;
     if (opt.t_pad > 0.0f && opt.t_pad < 1.0f) b.gate_pad = opt.t_pad;
     if (!b.run()) return b.status == VK_OK ? VK_ERR_BAD_ARG : b.status;
     out.world_items = b.world_items;
@@ -1276,6 +1373,15 @@ int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, con
             memcmp(ref.spheres.data(), out.spheres.data(), ref.spheres.size() * sizeof(DSphere)) == 0;
         if (!same) { err = "exact re-tree: the two linearisations number the spheres differently"; return VK_ERR_UNSUPPORTED; }
         out.ref_items = ref.items;
+        // every sphere's leaf in the tree as handed over (the node whose box gates it there): the safe-winner test's second chance
+        // (vk_trace.h segment_unsafe).  A shared sphere: the first leaf that holds it.
+        out.unit_item.assign(out.spheres.size(), 0xFFFFFFFFu);
+        for (size_t i = 0; i < out.ref_items.size(); i++) {
+            const DItem &it = out.ref_items[i];
+            if ((it.w0 >> 28) == 0u) continue;
+            for (uint32_t w : {it.w0, it.w1})
+                if (w && VKD_KIND(w) == DK_SPHERE && out.unit_item[VKD_INDEX(w)] == 0xFFFFFFFFu) out.unit_item[VKD_INDEX(w)] = (uint32_t)i;
+        }
         // The gate's relative padding.  Proven form (rt_grow_units succeeded): RT_PAD, which covers the hit points of FAR origins — they
         // may precede the ray's entry into the unit's grown box by up to the box's size; near origins are covered by the growth.
         // Empirical form: the units' boxes as handed over and RT_PAD_EMPIRICAL (1/256 lost one sample in 1.9 G on the stress scene, 1/16

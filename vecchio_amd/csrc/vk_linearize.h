@@ -37,6 +37,7 @@ struct LinearScene {
     std::vector<uint32_t> tie_rank;
     uint32_t tie_base_rect = 0, tie_base_box = 0, tie_base_list = 0;
     std::vector<DItem> ref_items; float t_pad = 0.0f;      // see DScene
+    std::vector<uint32_t> unit_item;                      // see DScene (one entry per sphere when ref_items is there)
     float trust_c0[3] = {0.0f, 0.0f, 0.0f}; float trust_r0 = 0.0f;      // exact re-treeing: the trusted origin ball (DScene)
     bool proven = false;        // exact re-treeing with grown gates: the gate lemma applies (vk_linearize.cpp rt_grow_units / rt_grow_near)
     // The NEAR form of exact re-treeing (vk_linearize.cpp rt_grow_near): every sphere gated by its OWN box, sound for origins within
@@ -50,6 +51,9 @@ struct LinearScene {
     float small_lo[3] = {0, 0, 0}, small_hi[3] = {0, 0, 0};     // (box around the small spheres' surfaces)
     float clear_k = 0.0f, clear_r2 = 0.0f, clear_slack = 0.0f;      // DScene: the clearance test's constants
     uint32_t n_big = 0; float big[8][4] = {};
+    // the GRID form (DGrid): grid.nu != 0 when the world is eligible (vk_linearize.cpp rt_build_grid)
+    DGrid grid = {};
+    std::vector<uint32_t> grid_cells, grid_refs;
     uint32_t features = 0;
     uint32_t n_prims = 0;
     uint32_t world_items = 0;   // items[0, world_items) is the world BVH; instance child ranges follow
@@ -78,6 +82,7 @@ struct LinearizeOptions {
                                 // still takes VK_SCENE_EMPIRICAL_TREES in the description)
     bool near_form = true;      // VK_NEAR_FORM=0 (emulator / debug library): no near form where the unit form is not eligible
     bool unit_form = true;      // VK_UNIT_FORM=0 (emulator / debug library): the near form even where the unit form is eligible (comparisons)
+    bool grid_form = true;      // VK_GRID_FORM=0 (emulator / debug library): no grid form (comparisons)
     bool near_first = true;     // VK_NEAR_FIRST=0 (emulator / debug library): the unit form where both are eligible (comparisons)
     bool allow_empirical = false;   // tests/emu and the debug library, VK_EMPIRICAL_TREES=1: as vk_scene_desc.flags & VK_SCENE_EMPIRICAL_TREES
 };

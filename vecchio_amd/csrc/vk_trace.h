@@ -67,6 +67,9 @@ struct GlobalMem {
     VK_HD DItem item(uint32_t i) const { return items[i]; }
     VK_HD DSphere sphere(uint32_t i) const { return spheres[i]; }
     VK_HD uint32_t smat(uint32_t i) const { return sphere_mat[i]; }
+    // the grid form's cell table and reference lists (DGrid)
+    VK_HD uint32_t grid_cell(const DScene &S, uint32_t c) const { return S.grid_cells[c]; }
+    VK_HD uint32_t grid_ref(const DScene &S, uint32_t k) const { return S.grid_refs[k]; }
 };
 
 // ------------------------------------------------------------------ per-lane state
@@ -79,6 +82,10 @@ struct Lane {
     V3 wo, wd;                 // world-space ray of this segment
     // traversal cursor
     uint32_t i, end, pend, pend2; int32_t cur_inst;
+    // ... of the grid form (DGrid; grid_step below): i, end = the current cell's range in refs[]; cell = major index | minor index << 10
+    // | last minor index of this column << 20, or GRID_START / GRID_DONE; the segment's parameter range inside the layer's dilated box
+    // and the dilation itself
+    uint32_t cell; float ta, tb, dl;
     // closest hit so far (deferred record)
     float T; uint32_t best_prim; int32_t best_inst; float best_aux;
     // path
@@ -384,6 +391,7 @@ VK_HD bool slab_exact(const DItem &n, V3 o, V3 d, float tmin, float tmax) {
     return true;
 }
 // ------------------------------------------------------------------ traversal
+constexpr uint32_t GRID_START = 0xFFFFFFFEu, GRID_DONE = 0xFFFFFFFFu;
 // exact re-treeing: outside the ball in which the gate lemma's bounds hold (DScene::trust_c0; never for r0 = +inf)
 VK_HD bool origin_untrusted(const DScene &S, V3 o) {
     const V3 oc = o - v3(S.trust_c0[0], S.trust_c0[1], S.trust_c0[2]);
@@ -401,6 +409,10 @@ VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time, bool 
     if (TIGHT && S.walk_start != 0u) redo = redo || origin_untrusted(S, o) || (S.primary_ref != 0u && L.depth == 1u);      // (TIGHT: the sphere-only variants)
     set_space<FUSED, TIGHT>(L, o, d, redo ? 1.0f : S.gate_scale);
     L.i = redo ? 0u : (S.walk_start << ISHIFT); L.end = S.n_world_items << ISHIFT; L.pend = 0; L.pend2 = 0; L.cur_inst = -1;
+    L.cell = GRID_DONE;
+    // the grid form: refs[0, n_always) first (a segment walked again — scenes in global memory keep the tree as handed over in items[],
+    // walk_start = its length — walks that tree instead)
+    if (TIGHT && S.grid.nu != 0u && !redo) { L.i = 0u; L.end = S.grid.n_always; L.cell = GRID_START; }
     L.T = INFINITY; L.best_prim = 0; L.best_inst = -1; L.best_aux = 0.0f;
     // A ray with a NaN (or infinite) direction or origin hits EVERY box — f32::min/max drop the NaN quotients, accel.rs:21-31 —
     // and no sphere: Sphere::hit's discriminant is NaN (hittable.rs:66-70).  The reference walks its whole tree for such a ray
@@ -410,7 +422,7 @@ VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time, bool 
     // EVERY frame, whatever its length.
     if (S.features == 0u) {
         bool dead = !(L.a < INFINITY) || !(fabsf(o.x) + fabsf(o.y) + fabsf(o.z) < INFINITY);
-        if (dead) L.i = L.end;
+        if (dead) { L.i = L.end; L.cell = GRID_DONE; }
     }
 }
 
@@ -564,7 +576,7 @@ VK_HD void process_ref(Lane &L, const DScene &S, const Mem &M, uint32_t ref) {
 //              (accel.rs:64-70)
 // A lane has box work when pend == 0 and prim work when pend != 0; objects are always
 // finished before the next item is fetched, which is the reference's order.
-VK_HD bool traversing(const Lane &L) { return L.i < L.end || L.pend != 0 || L.cur_inst >= 0; }
+VK_HD bool traversing(const Lane &L) { return L.i < L.end || L.pend != 0 || L.cur_inst >= 0 || L.cell != GRID_DONE; }
 VK_HD bool has_prim_work(const Lane &L) { return L.pend != 0; }
 // Sphere / MovingSphere / Rect tests are ~50 instructions; Boxy, lists, media and instance entry cost several times that
 // In the everything-variants a Boxy (kind 7: six rect tests, no draw, no change of space) counts as light and is served inside the
@@ -667,6 +679,16 @@ VK_HD bool segment_unsafe(const Lane &L, const DScene &S, const Mem &M) {
             DItem own;
             own.mnx = bx0; own.mxx = bx1; own.mny = by0; own.mxy = by1; own.mnz = bz0; own.mxz = bz1; own.w0 = 0u; own.w1 = 0u;
             ok = slab_exact(own, L.o, L.d, T_MIN, L.T);
+        }
+        if (!ok && L.xnan == L.xnan && S.unit_item != nullptr) {
+            // Second chance: the box that gates the sphere in the tree as handed over — its leaf's.  The reference reaches the sphere
+            // through that leaf and its ancestors, which contain it: if the leaf's box passes AxisBB::hit with tmax = the winner's t,
+            // they all do (same monotonicity), whatever the sphere's own box says.  (The hit point of a FAR origin lies up to
+            // eta(rho) off its sphere, sometimes outside the sphere's own box and still inside the leaf's: of the 1 M-sphere scene's
+            // segments 0.66 % fail the first test, 0.47 % both — hits reported BEFORE the ray enters the leaf's box, which the reference
+            // accepts or not depending on what it found earlier: the tree as handed over has to say.)
+            const uint32_t ui = S.unit_item[VKD_INDEX(L.best_prim)];
+            if (ui != 0xFFFFFFFFu) ok = slab_exact(S.unit_tree[ui], L.o, L.d, T_MIN, L.T);
         }
         unsafe = unsafe || !ok || !(sp.r > 0.0f);
     }
@@ -806,10 +828,97 @@ VK_HD void prim_step(Lane &L, const DScene &S, const Mem &M) {
     }
 }
 
+// ---- The grid form's walk (DGrid, docs/gate_lemma.md section 8).  One step: queue the next two references of the current cell, or
+// move on — to the next cell of this column of cells, to the next column along the ray's major axis (x or z, whichever component is
+// larger), or out.  A column is the strip U0 <= u <= U1 of the grid; the ray is inside the strip dilated by e = dl for t in
+// [t_lo, t_hi] (clipped to the segment's range [ta, min(tb, T)]), and over that range its minor coordinate covers [v_lo, v_hi]: the
+// cells of the column within e of that are visited.  Every cell within e of the ray's path is: a point of the path lies in some
+// column's dilated strip at a parameter inside that column's range.  The reciprocals are the lane's (1 ulp, times gate_scale: undone
+// here), floor() of a quotient may land a cell off: dl carries 2 m_reg for that (vk_linearize.cpp rt_build_grid).
+template <class Mem>
+VK_HD void grid_advance(Lane &L, const DScene &S, const Mem &M) {
+    const DGrid &G = S.grid;
+    const bool mz = fabsf(L.d.z) > fabsf(L.d.x);
+    const float unscale = 1.0f + S.t_pad;
+    const float ou = mz ? L.o.z : L.o.x, ov = mz ? L.o.x : L.o.z, du = mz ? L.d.z : L.d.x, dv = mz ? L.d.x : L.d.z;
+    const float ru = (mz ? L.inv.z : L.inv.x) * unscale;
+    const float gu = mz ? G.ov : G.ou, gv = mz ? G.ou : G.ov;
+    const int nmaj = (int)(mz ? G.nv : G.nu), nmin = (int)(mz ? G.nu : G.nv);
+    const int dir = du > 0.0f ? 1 : -1;
+    int i, j, jhi;
+    bool enter;                       // a column is to be entered (else: the next cell of the current one)
+    if (L.cell == GRID_START) {
+        // the dilation this origin can need at most (the far corner of the layer's box), the segment's range inside the box dilated by
+        // that, the dilation its far end needs, the range again across the layer
+        const float fx = fmaxf(fabsf(L.o.x - G.lo[0]), fabsf(L.o.x - G.hi[0])), fy = fmaxf(fabsf(L.o.y - G.lo[1]), fabsf(L.o.y - G.hi[1]));
+        const float fz = fmaxf(fabsf(L.o.z - G.lo[2]), fabsf(L.o.z - G.hi[2]));
+        const float dlc = __builtin_fmaf(G.k, sqrtf(fx * fx + fy * fy + fz * fz) + G.r2, G.slack);
+        const float ix_ = L.inv.x * unscale, iy_ = L.inv.y * unscale, iz_ = L.inv.z * unscale;
+        const float x0 = ((G.lo[0] - dlc) - L.o.x) * ix_, x1 = ((G.hi[0] + dlc) - L.o.x) * ix_;
+        const float y0 = ((G.lo[1] - dlc) - L.o.y) * iy_, y1 = ((G.hi[1] + dlc) - L.o.y) * iy_;
+        const float z0 = ((G.lo[2] - dlc) - L.o.z) * iz_, z1 = ((G.hi[2] + dlc) - L.o.z) * iz_;
+        float ta = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+        float tb = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), L.T));
+        if (!(ta <= tb)) { L.cell = GRID_DONE; return; }
+        const float dn = sqrtf(L.a);
+        float dl = fminf(__builtin_fmaf(G.k, __builtin_fmaf(tb, dn, G.r2), G.slack), dlc);
+        if (!(dl >= 0.0f)) dl = dlc;
+        const float w0 = ((G.lo[1] - dl) - L.o.y) * iy_, w1 = ((G.hi[1] + dl) - L.o.y) * iy_;
+        ta = fmaxf(ta, fminf(w0, w1)); tb = fminf(tb, fmaxf(w0, w1));
+        if (!(ta <= tb)) { L.cell = GRID_DONE; return; }
+        L.ta = ta; L.tb = tb; L.dl = dl;
+        const float ua = __builtin_fmaf(du, ta, ou) - (float)dir * dl;
+        i = (int)fminf(fmaxf(floorf((ua - gu) * G.inv_cell), 0.0f), (float)(nmaj - 1));
+        j = 0; jhi = 0;
+        enter = true;
+    } else {
+        i = (int)(L.cell & 1023u); j = (int)((L.cell >> 10) & 1023u) + 1; jhi = (int)((L.cell >> 20) & 1023u);
+        enter = j > jhi;
+        if (enter) i += dir;
+    }
+    const float e = L.dl;
+    for (int guard = 0; guard < 4 && enter; guard++) {
+        if (i < 0 || i >= nmaj) { L.cell = GRID_DONE; return; }
+        const float tend = fminf(L.tb, L.T);
+        const float U0 = __builtin_fmaf((float)i, G.cell, gu), U1 = U0 + G.cell;
+        const float tA = ((U0 - e) - ou) * ru, tB = ((U1 + e) - ou) * ru;
+        const float t_lo = fmaxf(L.ta, fminf(tA, tB)), t_hi = fminf(tend, fmaxf(tA, tB));
+        if (!(t_lo <= t_hi)) {
+            if (!(fminf(tA, tB) <= tend)) { L.cell = GRID_DONE; return; }       // the path ends before this column
+            i += dir;                                                           // (the column lies before the range's start)
+            continue;
+        }
+        const float v0 = __builtin_fmaf(dv, t_lo, ov), v1 = __builtin_fmaf(dv, t_hi, ov);
+        j = (int)fminf(fmaxf(floorf(((fminf(v0, v1) - e) - gv) * G.inv_cell), 0.0f), (float)(nmin - 1));
+        jhi = (int)fminf(fmaxf(floorf(((fmaxf(v0, v1) + e) - gv) * G.inv_cell), 0.0f), (float)(nmin - 1));
+        enter = false;
+    }
+    if (enter) {       // (four columns in a row outside the range: go on in the next step)
+        L.cell = (uint32_t)(i - dir) | (1u << 10);          // j = 1 > jhi = 0: the next step enters column i
+        L.i = 0u; L.end = 0u;
+        return;
+    }
+    const uint32_t c = mz ? (uint32_t)j * G.nv + (uint32_t)i : (uint32_t)i * G.nv + (uint32_t)j;
+    L.i = M.grid_cell(S, c); L.end = M.grid_cell(S, c + 1u);
+    L.cell = (uint32_t)i | ((uint32_t)j << 10) | ((uint32_t)jhi << 20);
+}
+template <class Mem>
+VK_HD bool grid_step(Lane &L, const DScene &S, const Mem &M) {       // returns: references were queued
+    if (!(L.i < L.end)) grid_advance(L, S, M);
+    if (L.i < L.end) {
+        L.pend = M.grid_ref(S, L.i);
+        L.pend2 = L.i + 1u < L.end ? M.grid_ref(S, L.i + 1u) : 0u;
+        L.i = L.i + 2u < L.end ? L.i + 2u : L.end;
+        return true;
+    }
+    return false;
+}
+
 // sequential form (CPU emulator): one step of whichever kind is due
 template <uint32_t F, class Mem>
 VK_HD void traverse_step(Lane &L, const DScene &S, const Mem &M) {
     if (has_prim_work(L)) prim_step<F, Mem>(L, S, M);
+    else if (spheres_only<F>() && L.cell != GRID_DONE) (void)grid_step(L, S, M);
     else box_step<F, Mem>(L, S, M, true);
 }
 
