@@ -306,7 +306,9 @@ def main():
 
     TREE_NAMES = {0: "handed over", 1: "rebuilt, proven (exact re-treeing with grown gates)", 2: "rebuilt, empirical (VK_SCENE_EMPIRICAL_TREES)",
                   3: "rebuilt object by object (VK_SCENE_FAST_ACCEL)",
-                  4: "rebuilt, proven (exact re-treeing, near form: own-box gates + reach / clearance, failed segments walked again as handed over)"}
+                  4: "rebuilt, proven (exact re-treeing, near form: own-box gates + reach / clearance, failed segments walked again as handed over)",
+                  5: "no tree: a grid over the layer of small spheres, proven (exact re-treeing, grid form: every sphere that can hold a "
+                     "candidate is tested, failed segments' samples rendered again as handed over)"}
 
     def run_workload(name, steps, warmup, spp_override=0, want_cpu=False, bvh="reference", fast_accel=False, live_traffic=False,
                      handed_over_tree=False, empirical=False):
@@ -432,13 +434,14 @@ def main():
                 # (the near form: C5's camera is 109 above the field, farther than `reach` from every sphere, so the library starts the
                 # primary rays on the tree as handed over — vk_api.hip, DScene::primary_ref — and so does the count of its walk)
                 os.environ["EMU_PRIMARY_REF"] = "1" if (info.tree == 4 and name == "C5") else "0"
+                os.environ["VK_GRID_FORM"] = "1" if info.tree == 5 else "0"     # (the grid form only where the device walks it: scenes in LDS)
                 if empirical:
                     os.environ["VK_GATE_PROOF"] = "0"
                 emu_ffi.take_visit_counts()
                 pe = hs.params(cw, 1, depth, seed=2)
                 _, ps_e, _, _ = emu_ffi.render_samples(hs.desc, cam, pe, threads=cores)
                 nb, ns = emu_ffi.take_visit_counts()
-                os.environ.pop("VK_GATE_PROOF", None)
+                os.environ.pop("VK_GATE_PROOF", None); os.environ.pop("VK_GRID_FORM", None)
                 ne = float(ps_e.shape[0])
                 walked = {"box_tests": nb / ne, "sphere_tests": ns / ne, "oracle_box_tests": c["n_aabb"] / float(c["samples"]),
                           "oracle_sphere_tests": c["n_sphere"] / float(c["samples"])}
@@ -616,7 +619,7 @@ def main():
                 frames.setdefault(name, frame)                # (walked as handed over: C5's default, C3, C4)
             elif name in frames:
                 ident = bool(np.array_equal(frame.view(np.uint32), frames[name].view(np.uint32)))
-                if not ident and r["tree_code"] in (1, 4):
+                if not ident and r["tree_code"] in (1, 4, 5):
                     exact_mismatch.append(f"{r['label']} ({r['tree']}) differs from the tree as handed over")
             del frame
             also.append({"workload": r["label"], "tree": r["tree"], "Msamples_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": 1,

@@ -362,10 +362,14 @@ enum {
     VK_TREE_REBUILT_PROVEN = 1,     /* exact re-treeing with grown gates: results proven to be the handed-over tree's */
     VK_TREE_REBUILT_EMPIRICAL = 2,  /* exact re-treeing without them (VK_SCENE_EMPIRICAL_TREES): measured, not proven */
     VK_TREE_REBUILT_FAST = 3,       /* VK_SCENE_FAST_ACCEL */
-    VK_TREE_REBUILT_NEAR = 4        /* exact re-treeing, near form (ABI 6): every sphere behind its own box, a segment's result taken only
+    VK_TREE_REBUILT_NEAR = 4,       /* exact re-treeing, near form (ABI 6): every sphere behind its own box, a segment's result taken only
                                        where no sphere beyond that box's trusted radius can matter, else walked again on the tree handed
                                        over: proven like VK_TREE_REBUILT_PROVEN; taken first where its reach spans the world's small
                                        spheres, and for worlds whose leaf units are too long for the unit form */
+    VK_TREE_REBUILT_GRID = 5        /* exact re-treeing, grid form (ABI 6, round 5): no tree at all — a world of spheres whose small spheres
+                                       lie in a layer across y is walked on a uniform grid over the layer; every sphere that can hold a
+                                       candidate for the ray is tested, the winner is checked like the other forms' and the tree handed
+                                       over decides where that fails: proven like them (docs/gate_lemma.md section 8) */
 };
 int vk_scene_get_info(const vk_scene *scene, vk_scene_info *out);
 

@@ -43,15 +43,12 @@ static int linearize_env(const vk_scene_desc *desc, LinearScene &LS, std::string
 static bool global_variant() { const char *e = getenv("EMU_GLOBAL_VARIANT"); return e && e[0] == '1'; }
 static DScene scene_view(const LinearScene &LS, std::vector<DItem> &both) {
     DScene S = LS.host_view();
-    if (const char *e = getenv("EMU_GRID")) { if (e[0] == '0') { S.grid.nu = 0u; S.trust_r0sq = LS.trust_r0 * LS.trust_r0; S.reach = LS.reach; } }
+    // EMU_GRID=0: the rebuilt TREE of a world that has a grid too (what the device does with such a world when it is too large for LDS)
+    if (const char *e = getenv("EMU_GRID")) { if (e[0] == '0') drop_grid(S); }
     if (S.grid.nu != 0u && !LS.ref_items.empty()) {
-        // the grid form.  From LDS (default): a failed segment requeues its sample (trace_one: the whole sample again on reference_view).
-        // From global memory (EMU_GLOBAL_VARIANT=1): items[] is the tree as handed over, walk_start = its length (nothing rebuilt
-        // follows): a failed segment is walked again in place, as the device does it
-        if (global_variant()) {
-            S.items = LS.ref_items.data(); S.n_items = (uint32_t)LS.ref_items.size(); S.n_world_items = S.n_items; S.walk_start = S.n_items;
-            S.ref_items = nullptr; S.n_ref_items = 0; S.unit_tree = LS.ref_items.data();
-        }
+        use_grid(S);
+        // the grid form: a failed segment requeues its sample (trace_one: the whole sample again on reference_view), whether the device
+        // walks the grid from LDS or from global memory
         return S;
     }
     // (the near form whose reach does not span its small spheres: both trees in items[], as the device keeps it)

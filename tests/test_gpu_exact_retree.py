@@ -36,8 +36,8 @@ def render(name, w, spp, flags, tile=None):
 # for grown UNIT gates: both trees in global memory; the unit form with bare gates is the opt-in empirical one, preferred with
 # VK_GATE_PROOF=0.  The unit form with grown gates: test_unit_form_forced_on_the_gpu.)
 @pytest.mark.parametrize("name,w,spp,in_lds,flags,tree", [
-    ("random_spheres_iow", 640, 96, True, 0, ffi.VK_TREE_REBUILT_NEAR),
-    ("random_spheres_iow", 640, 96, True, ffi.VK_SCENE_EMPIRICAL_TREES, ffi.VK_TREE_REBUILT_NEAR),
+    ("random_spheres_iow", 640, 96, True, 0, ffi.VK_TREE_REBUILT_GRID),
+    ("random_spheres_iow", 640, 96, True, ffi.VK_SCENE_EMPIRICAL_TREES, ffi.VK_TREE_REBUILT_GRID),
     ("stress_spheres:150", 512, 12, False, 0, ffi.VK_TREE_REBUILT_NEAR),
     ("stress_spheres:30", 384, 24, False, 0, ffi.VK_TREE_REBUILT_NEAR),
     ("stress_spheres:150", 512, 12, False, ffi.VK_SCENE_EMPIRICAL_TREES, ffi.VK_TREE_REBUILT_EMPIRICAL),
@@ -84,7 +84,8 @@ def test_unit_form_forced_on_the_gpu(device):
             "assert out[0][3] and 0 < out[0][2] < 0.01 * out[0][4], out[0][2:]\n"
             "assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))\n"
             "print('UNIT FORM OK', out[0][2])\n") % ROOT
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VK_NEAR_FIRST="0"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VK_NEAR_FIRST="0", VK_NO_GRID="1"), capture_output=True, text=True,
+                       timeout=600)
     assert r.returncode == 0 and "UNIT FORM OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -103,7 +104,7 @@ def test_the_headline_frame_at_full_size_is_the_handed_over_trees(device):
     ref, st_r, info_r = frame(ffi.VK_SCENE_REFERENCE_TREE)
     img, st, info = frame(0)
     assert img.shape == (1080, 1920, 3) and st.samples == 1920 * 1080 * 1024 == st_r.samples
-    assert info_r.tree == ffi.VK_TREE_HANDED_OVER and info.tree == ffi.VK_TREE_REBUILT_NEAR
+    assert info_r.tree == ffi.VK_TREE_HANDED_OVER and info.tree == ffi.VK_TREE_REBUILT_GRID
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), int((img != ref).any(axis=2).sum())
     assert st.clamped_samples == 0 and np.isfinite(img).all()
 
@@ -144,7 +145,8 @@ def test_near_form_from_other_viewpoints(scene, lookfrom, lookat, aperture, devi
         ds = DeviceScene(hs.desc)
         imgs[flags] = (ds.render(cam, hs.params(w, spp, 50, seed=6))[0], ds.info().tree, ds.last_requeued_samples())
         ds.close(); hs.close()
-    assert imgs[0][1] == ffi.VK_TREE_REBUILT_NEAR and imgs[ffi.VK_SCENE_REFERENCE_TREE][1] == ffi.VK_TREE_HANDED_OVER
+    assert imgs[0][1] == (ffi.VK_TREE_REBUILT_GRID if scene == "random_spheres_iow" else ffi.VK_TREE_REBUILT_NEAR)
+    assert imgs[ffi.VK_SCENE_REFERENCE_TREE][1] == ffi.VK_TREE_HANDED_OVER
     a, b = imgs[0][0], imgs[ffi.VK_SCENE_REFERENCE_TREE][0]
     assert np.isfinite(a).all() and a.max() > 0.0
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), int((a != b).any(axis=2).sum())
@@ -152,10 +154,9 @@ def test_near_form_from_other_viewpoints(scene, lookfrom, lookat, aperture, devi
     # over: nothing requeued.  From 33 above the ground only the rays straight down hit within reach: a fifth of the samples requeue,
     # the queues overflow, the frame is rendered again as handed over and the rebuilt tree suspended (vk_api.hip judge_frame) — the
     # image is the same either way.
-    if lookfrom == (0.0, 60.0, 0.0):
-        assert imgs[0][2] == 0
-    elif lookfrom != (0.0, 33.0, 0.0):
-        assert imgs[0][2] < 0.03 * w * (w * 9 // 16) * spp, imgs[0][2]
+    # (The InOneWeekend world is walked on the GRID form since late in round 5, which has no such conditions — these viewpoints stay as
+    # they are hard for any form: the near form is their test with VK_NO_GRID=1, tests/test_retree.py / the emulator.)
+    assert imgs[0][2] < 0.03 * w * (w * 9 // 16) * spp, imgs[0][2]
 
 
 def test_a_full_redo_queue_never_yields_an_incomplete_frame(device):

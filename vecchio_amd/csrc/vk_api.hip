@@ -137,6 +137,8 @@ struct EnvSwitches {
     // VK_RETREE=0/1/2: nothing rebuilt / every draw-free subtree / exact re-treeing (default: vk_scene_desc.flags)
     int retree = -1;
     int redo_region_cap = 0;           // VK_REDO_REGION_CAP=n (tests): entries per queue between the two launches of exact re-treeing
+    bool grid_global = false;          // VK_GRID_GLOBAL=1 (comparisons): the grid form also for scenes traversed from global memory
+    bool no_grid = false;              // VK_NO_GRID=1 (comparisons): the tree forms of exact re-treeing where the grid form would do
     int near_lds = -1;                 // VK_NEAR_LDS=0/1 (comparisons): the near form of exact re-treeing from global memory / staged in LDS
     static int int_env(const char *name) { const char *e = getenv(name); return e ? atoi(e) : 0; }
     static EnvSwitches read() {
@@ -156,6 +158,8 @@ struct EnvSwitches {
         v.prim_weight = int_env("VK_PRIM_WEIGHT");
         v.redo_region_cap = int_env("VK_REDO_REGION_CAP");
         if (const char *e = getenv("VK_NEAR_LDS")) v.near_lds = e[0] != '0';
+        if (const char *e = getenv("VK_NO_GRID")) v.no_grid = e[0] == '1';
+        if (const char *e = getenv("VK_GRID_GLOBAL")) v.grid_global = e[0] == '1';
         return v;
     }
 };
@@ -180,6 +184,8 @@ struct vk_scene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int num_cus = 256;
     uint32_t lds_bytes = 0;    // hot-record bytes staged per workgroup (0 = not LDS resident)
+    bool grid_on = false;      // the grid form of exact re-treeing is this scene's walk (DGrid)
+    uint32_t grid_slots = 0;   // the grid form: size of the table [cells | refs] in 32-byte units (KArgs::lds_items of its launches)
     size_t hot_bytes = 0;      // items + spheres + boxes: what traversal gathers from
     uint32_t wg_threads = 512; // workgroup size chosen by plan_residency()
     uint32_t sphere_waves = 6; // waves per SIMD of the sphere-only variant (8 was measured 3 % slower: it spills)
@@ -307,7 +313,7 @@ void plan_residency(vk_scene *s, size_t hot) {
     // The near form of exact re-treeing walks a failed segment again in place: both trees in items[], i.e. global memory — unless its
     // reach spans the small spheres' whole box: then hardly a segment fails (the InOneWeekend scene: 3 in 10^5), a failed one may as well
     // requeue its whole sample, and the scene is staged in LDS like any other (7 520 against the unit form's 7 285 Msamples/s at 256 spp)
-    const bool near_needs_global = s->host->near_form && (s->env.near_lds >= 0 ? s->env.near_lds == 0 : !s->host->near_spans);
+    const bool near_needs_global = s->host->near_form && !s->grid_on && (s->env.near_lds >= 0 ? s->env.near_lds == 0 : !s->host->near_spans);
     const uint32_t per_simd = spheres_only ? s->sphere_waves : (pick_variant(s) == (uint32_t)VKF_ALL_SCENE ? (uint32_t)VK_ALL_MINW
                                                                                                            : (uint32_t)VK_CORNELL_MINW);   // = MINW of launch_variant
     uint32_t cap = 4 * per_simd;                                             // waves per CU the variant's register budget admits
@@ -365,6 +371,15 @@ int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shme
         return VK_OK;
     };
     int rc;
+    if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) {
+        if (A.S.grid.nu != 0u) {      // the grid form of exact re-treeing (DGrid)
+            if (cost) rc = lds ? go(&render_kernel<F, true, MINW, false, true, true>) : go(&render_kernel<F, false, MINW_G, false, true, true>);
+            else rc = lds ? go(&render_kernel<F, true, MINW, false, false, true>) : go(&render_kernel<F, false, MINW_G, false, false, true>);
+            if (rc != VK_OK) return rc;
+            HIP_TRY(hipGetLastError());
+            return VK_OK;
+        }
+    }
     if (cost) rc = lds ? go(&render_kernel<F, true, MINW, false, true>) : go(&render_kernel<F, false, MINW_G, false, true>);
     else rc = lds ? go(&render_kernel<F, true, MINW, false, false>) : go(&render_kernel<F, false, MINW_G, false, false>);
     if (rc != VK_OK) return rc;
@@ -374,9 +389,9 @@ int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shme
 
 // The dual launch of plan_residency: the same 7-waves-per-SIMD build of a sphere-only LDS variant, once with 1024-thread workgroups on
 // `st` and once with 768-thread workgroups on the scene's second stream, one workgroup of each per CU; both pull units from A.counter.
-template <uint32_t F>
+template <uint32_t F, bool GRID = false>
 int launch_dual(vk_scene *s, const KArgs &A, size_t per_wave, hipStream_t st) {
-    auto kernel = &render_kernel<F, true, 7, false, false>;
+    auto kernel = &render_kernel<F, true, 7, false, false, GRID>;
     const size_t shm_a = s->lds_bytes + 16 * per_wave, shm_b = s->lds_bytes + 12 * per_wave;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_a));
     // (VK_DUAL_SAME_STREAM=1, tests: both launches on ONE stream, i.e. serialised — what the self-check must notice)
@@ -522,7 +537,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     // The near form: primary rays start on the tree as handed over when the camera (its lens included) is farther than `reach` from every
     // sphere — their walk on the rebuilt tree could not stand (vk_trace.h begin_segment).  Decided from the box around the small spheres
     // and the surfaces of the few big ones; when in doubt: no.
-    if (s->host->near_form && (A.S.walk_start != 0u || s->exact) && s->host->n_big != 0xFFFFFFFFu) {
+    if (s->host->near_form && !s->grid_on && (A.S.walk_start != 0u || s->exact) && s->host->n_big != 0xFFFFFFFFu) {
         const LinearScene &H = *s->host;
         const double reach = (double)H.reach + (double)fabsf(cam->lens_radius) * 1.5 + 1e-3 * (double)H.reach;
         double d2 = 0.0;
@@ -612,6 +627,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         A.accum = s->accum;
     }
     s->redo_last = false;
+    const bool lds_scene = s->lds_bytes != 0;
     uint64_t per_region = 0;
     if (exact) {
         // queues for the samples the first launch drops: room for 1/32 of the partition's samples (C2 drops 0.05 %; 8 bytes each: 0.5 GB
@@ -620,6 +636,9 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         // (at most 256 MB: a frame that needs more overflows, and the fallback launch renders it on the tree as handed over)
         s->redo_last_samples = partition_samples(p, g);
         per_region = std::min<uint64_t>(s->redo_last_samples / 32u / REDO_REGIONS + 4096u, (256ull << 20) / sizeof(uint2) / REDO_REGIONS);
+        // (the grid form seen from far away — the 1 M-sphere scene's camera — requeues 4 % of its samples: hits reported before the ray
+        // enters their leaf's box, see segment_unsafe; room for an eighth, up to 4 GB of the 288)
+        if (s->grid_on && !lds_scene) per_region = std::min<uint64_t>(s->redo_last_samples / 8u / REDO_REGIONS + 4096u, (4096ull << 20) / sizeof(uint2) / REDO_REGIONS);
         if (s->env.redo_region_cap >= 1) per_region = (uint64_t)s->env.redo_region_cap;      // tests
     }
     if (exact) {
@@ -633,11 +652,16 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
     } else if (s->exact) {
         A.S = s->ref_view;      // no second launch (diagnostic builds, a scene switched off, an oversized frame): the tree as handed over
     }
+    if (s->grid_on && s->want_phase_stats && A.S.grid.nu != 0u) {
+        // (the diagnostic builds have no grid walk: the tree as handed over, which is what items[] holds for a grid scene in global memory)
+        A.S.grid.nu = 0u; A.S.walk_start = 0u; A.S.t_pad = 0.0f; A.S.gate_scale = 1.0f; A.S.tmin_gate = T_MIN; A.S.tie_rank = nullptr;
+    }
     // LDS residency of the hot records
     bool lds = s->lds_bytes != 0;
     const uint32_t waves_per_wg = s->wg_threads / 64;
     size_t shmem = (size_t)waves_per_wg * per_wave_lds_bytes(pick_variant(s));
-    if (lds) { A.lds_items = A.S.n_items; A.lds_spheres = s->dev.n_spheres; A.lds_boxes = s->dev.n_boxes; shmem += s->lds_bytes; }
+    if (lds) { A.lds_items = A.S.grid.nu != 0u ? s->grid_slots : A.S.n_items; A.lds_spheres = s->dev.n_spheres; A.lds_boxes = s->dev.n_boxes;
+        shmem += s->lds_bytes; }
     // persistent grid: enough workgroups to fill the chip, never more than there are units
     s->dual_last = false;
     const uint64_t n_units = (uint64_t)A.n_local_tiles * A.n_chunks;
@@ -734,8 +758,10 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
             if (!(s->env.shade_defer >= 1 && s->env.shade_defer <= 64)) A.shade_defer = 6u;
             if (!(s->env.prim_weight >= 1 && s->env.prim_weight <= 64)) A.prim_weight = 2u;
         }
-        if (dual && F == 0u) rc = launch_dual<0u>(s, A, per_wave_lds_bytes(0u), st);
-        else if (dual && F == (uint32_t)VKF_INTEG_PDF) rc = launch_dual<VKF_INTEG_PDF>(s, A, per_wave_lds_bytes(0u), st);
+        const bool gridw = A.S.grid.nu != 0u;
+        if (dual && F == 0u) rc = gridw ? launch_dual<0u, true>(s, A, per_wave_lds_bytes(0u), st) : launch_dual<0u>(s, A, per_wave_lds_bytes(0u), st);
+        else if (dual && F == (uint32_t)VKF_INTEG_PDF) rc = gridw ? launch_dual<VKF_INTEG_PDF, true>(s, A, per_wave_lds_bytes(0u), st)
+                                                                   : launch_dual<VKF_INTEG_PDF>(s, A, per_wave_lds_bytes(0u), st);
         else rc = launch_by_features(s, F, A, lds, dim3(grid), shmem, st, false);
     }
     if (rc != VK_OK) return rc;
@@ -945,8 +971,23 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
     // (exact re-treeing: the second launch stages the tree as handed over instead of the rebuilt one, whichever is larger counts)
     size_t hot = std::max(H.items.size(), H.ref_items.size()) * sizeof(DItem) + H.spheres.size() * sizeof(DSphere) +
                  H.boxes.size() * sizeof(DBox);
+    // the grid form (DGrid): the first launch stages the table [cells | refs] instead of a tree, the second one the tree as handed over
+    bool grid = H.grid.nu != 0u && !H.ref_items.empty() && !s->env.no_grid;
+    const size_t grid_table_bytes = grid ? ((H.grid_cells.size() + H.grid_refs.size()) * sizeof(uint32_t) + 31u) / 32u * 32u : 0u;
+    // (the probe and the diagnostic builds walk the rebuilt TREE, which therefore counts too where the scene is staged in LDS)
+    if (grid) hot = std::max(grid_table_bytes, std::max(H.ref_items.size(), H.items.size()) * sizeof(DItem)) + H.spheres.size() * sizeof(DSphere);
+    s->grid_on = grid;
     s->hot_bytes = hot;
     plan_residency(s.get(), hot);
+    if (grid && s->lds_bytes == 0 && !s->env.grid_global) {
+        // The grid form is for scenes staged in LDS.  A large layer seen from far away — the 1 M-sphere scene — needs wide bands of cells
+        // around its primary rays (the dilation grows with the distance from the origin: 1.4 per 1 000), and a wave waits for its
+        // longest walk: measured 500 against the near form's 1 290 Msamples/s there, 1 880 against 3 270 on 3 600 spheres.
+        grid = false;
+        hot = std::max(H.items.size(), H.ref_items.size()) * sizeof(DItem) + H.spheres.size() * sizeof(DSphere) + H.boxes.size() * sizeof(DBox);
+        s->grid_on = false; s->hot_bytes = hot;
+        plan_residency(s.get(), hot);
+    }
     D.gate_scale = 1.0f; D.tmin_gate = T_MIN;
     if (!H.ref_items.empty()) {
         // Exact re-treeing (vk_trace.h).  Staged in LDS: the rebuilt tree is the scene's, the tree as handed over serves the second launch
@@ -956,9 +997,31 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
         for (int k = 0; k < 3; k++) { D.trust_c0[k] = hv.trust_c0[k]; D.small_clo[k] = hv.small_clo[k]; D.small_chi[k] = hv.small_chi[k]; }
         D.trust_r0sq = hv.trust_r0sq;
         D.reach = hv.reach; D.clear_k = hv.clear_k; D.clear_r2 = hv.clear_r2; D.clear_slack = hv.clear_slack;
+        if (grid) {
+            // no ball, no reach: the grid's walk tests every sphere that can hold a candidate, wherever the ray starts
+            use_grid(D);
+            std::vector<uint32_t> table(grid_table_bytes / sizeof(uint32_t), 0u);
+            std::copy(H.grid_cells.begin(), H.grid_cells.end(), table.begin());
+            std::copy(H.grid_refs.begin(), H.grid_refs.end(), table.begin() + H.grid_cells.size());
+            rc = upload(s.get(), table, D.grid_cells);
+            if (rc != VK_OK) return rc;
+            D.grid_refs = D.grid_cells + H.grid_cells.size();
+            D.grid = H.grid;
+            s->grid_slots = (uint32_t)(grid_table_bytes / 32u);
+        }
+        if (!H.unit_item.empty() && H.proven) { rc = upload(s.get(), H.unit_item, D.unit_item); if (rc != VK_OK) return rc; }
+        if (grid && s->lds_bytes == 0) {
+            // from global memory: the first launch reads the table and the spheres only; the tree as handed over serves the second one
+            // (and the diagnostic builds)
+            UP(ref_items, ref_items);
+            D.items = D.ref_items; D.n_ref_items = hv.n_ref_items; D.n_items = D.n_ref_items; D.n_world_items = D.n_ref_items;
+            D.unit_tree = D.ref_items;
+            s->exact = true;
+        } else
         if (s->lds_bytes != 0) {
             UP(items, items); UP(ref_items, ref_items);
             D.n_ref_items = hv.n_ref_items; D.n_items = (uint32_t)H.items.size(); D.n_world_items = H.world_items;
+            D.unit_tree = D.ref_items;
             s->exact = true;
         } else {
             uint32_t walk_start = 0;
@@ -966,6 +1029,7 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
             rc = upload(s.get(), both, D.items);
             if (rc != VK_OK) return rc;
             D.n_items = (uint32_t)both.size(); D.n_world_items = (uint32_t)both.size(); D.walk_start = walk_start;
+            D.unit_tree = D.items;       // (the tree as handed over comes first, item for item)
         }
     } else {
         UP(items, items);
@@ -997,7 +1061,7 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
         s->ref_view = D;
         s->ref_view.items = D.ref_items; s->ref_view.n_items = D.n_ref_items; s->ref_view.n_world_items = D.n_ref_items;
         s->ref_view.ref_items = nullptr; s->ref_view.n_ref_items = 0; s->ref_view.t_pad = 0.0f; s->ref_view.gate_scale = 1.0f;
-        s->ref_view.tmin_gate = T_MIN; s->ref_view.tie_rank = nullptr;
+        s->ref_view.tmin_gate = T_MIN; s->ref_view.tie_rank = nullptr; s->ref_view.grid.nu = 0u;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->redo_count), (REDO_REGIONS * REDO_COUNT_STRIDE + 16) * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->plan_host), 8 * sizeof(uint32_t), hipHostMallocDefault));
         memset(s->plan_host, 0, 8 * sizeof(uint32_t));
@@ -1164,7 +1228,7 @@ int vk_scene_get_info(const vk_scene *s, vk_scene_info *out) {
     out->device_bytes = b;
     out->lds_bytes = one->lds_bytes;
     out->features = pick_variant(one);
-    out->tree = !H.ref_items.empty() ? (H.near_form ? VK_TREE_REBUILT_NEAR : (H.proven ? VK_TREE_REBUILT_PROVEN : VK_TREE_REBUILT_EMPIRICAL))
+    out->tree = !H.ref_items.empty() ? (one->grid_on ? VK_TREE_REBUILT_GRID : H.near_form ? VK_TREE_REBUILT_NEAR : (H.proven ? VK_TREE_REBUILT_PROVEN : VK_TREE_REBUILT_EMPIRICAL))
                                      : (!H.tie_rank.empty() ? VK_TREE_REBUILT_FAST : VK_TREE_HANDED_OVER);
     out->gather = s->parts.empty() ? VK_GATHER_NONE : (s->comms.empty() ? VK_GATHER_PEER_COPY : VK_GATHER_RCCL);
     out->tree_suspended_frames = 0;

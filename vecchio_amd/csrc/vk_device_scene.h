@@ -165,5 +165,11 @@ struct DScene {
     const uint32_t *unit_item; const DItem *unit_tree;
 };
 
+// A view that walks the grid (grid.nu != 0) instead of the rebuilt tree: the grid form is sound for every ordinary ray wherever it
+// starts, so the tree forms' conditions — the trusted ball, the near form's reach — do not apply (vk_trace.h segment_unsafe keeps the
+// safe-winner test).  A view that walks the TREE of a world that also has a grid must keep them: drop_grid().
+inline void use_grid(DScene &s) { s.trust_r0sq = __builtin_inff(); s.reach = 0.0f; s.primary_ref = 0u; }
+inline void drop_grid(DScene &s) { s.grid.nu = 0u; s.grid.nv = 0u; }
+
 }  // namespace vkd
 #endif

@@ -113,6 +113,15 @@ struct LdsMem {
         return o;
     }
     __device__ __forceinline__ uint32_t smat(uint32_t i) const { return sphere_mat[i]; }
+    // the grid form (DGrid): the staged table [cells | refs] takes the items' place at LDS address 0
+    __device__ __forceinline__ uint32_t grid_cell(const DScene &, uint32_t c) const {
+        typedef const uint32_t __attribute__((address_space(3))) *lds_u;
+        return *(lds_u)(uintptr_t)(c << 2);
+    }
+    __device__ __forceinline__ uint32_t grid_ref(const DScene &S, uint32_t k) const {
+        typedef const uint32_t __attribute__((address_space(3))) *lds_u;
+        return *(lds_u)(uintptr_t)((S.grid.nu * S.grid.nv + 1u + k) << 2);
+    }
 };
 
 extern __shared__ uint4 smem[];
@@ -385,8 +394,9 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool e
             cold[CF_DEPTH * 64 + lane] = __uint_as_float(__float_as_uint(cold[CF_DEPTH * 64 + lane]) | 0x80000000u);
         }
     }
-    if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && LDS_SCENE) {
-        // scene in LDS (the rebuilt tree only): the sample of such a segment is dropped here and rendered by the second launch on the
+    if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) {
+        // scene in LDS (the rebuilt tree only) — and the grid form wherever it is walked from: the sample of such a segment is dropped
+        // here (a queue was handed in: redo_list) and rendered by the second launch on the
         // tree as handed over.  One counter update per wave and phase, prefix sums over the dropping lanes.
         uint2 *rl = KARG(P, redo_list);
         const unsigned long long m_drop = __builtin_amdgcn_ballot_w64(is_shade && early && rl != nullptr);
@@ -482,7 +492,7 @@ __device__ __forceinline__ void shade_refill_body(Lane &L, bool is_shade, bool e
         uint32_t txy = __builtin_amdgcn_readfirstlane(ws.x), s0 = __builtin_amdgcn_readfirstlane(ws.y);
         uint32_t total = __builtin_amdgcn_readfirstlane(ws.z), next = __builtin_amdgcn_readfirstlane(ws.w);
         // the second launch of exact re-treeing (sphere-only variants): units are slices of the redo queues
-        const bool list_mode = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) && LDS_SCENE && KARG(P, list_mode) == 1u;
+        const bool list_mode = ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) && KARG(P, list_mode) == 1u;
         if (next >= total) {
             uint32_t unit = 0;
             if (lane == 0) {
@@ -607,7 +617,11 @@ __device__ __attribute__((noinline)) ShadeIo shade_refill_call(ShadeIo io, uint3
 // prefix popcount (active-ray compaction), and the wave pulls the NEXT unit the moment the current one is handed out:
 // nobody waits for the slowest path of a unit (the "drain" cost 5 % on C2 and most of the lanes on C5). That is possible because pixel sums
 // are order independent (to_fixed above).
-template <uint32_t F, bool LDS_SCENE, int MINW, bool STATS, bool COST = false>
+// GRID: the sphere-only variants' walk on the grid form of exact re-treeing (DGrid; vk_trace.h grid_step) instead of a tree.  Staged in
+// LDS, the table [cells | refs] takes the items' place (lds_items = its size in 32-byte units).  A failed segment requeues its sample for
+// the second launch — also from global memory (walking the tree as handed over in place was tried: with a lane or two per wave on that
+// tree nearly every step of the wave pays for both walks, the 1 M-sphere scene ran at half the tree forms' rate).
+template <uint32_t F, bool LDS_SCENE, int MINW, bool STATS, bool COST = false, bool GRID = false>
 __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ? 768 : 1024))), MINW) void render_kernel(KArgs A_byval) {
     // (MINW == 7: the sphere-only LDS variants' dual launch, 1024- and 768-thread workgroups of the same build: vk_api.hip launch_dual)
     (void)A_byval;
@@ -621,7 +635,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
         st_t_mat = 0, st_t_refill = 0, st_t_install = 0, st_t1 = 0, st_t_turb = 0, st_t_cold = 0;
     if (STATS) st_t_total = clock64();
 
-    if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u && LDS_SCENE) {      // the fallback launch of exact re-treeing: nothing to do, nearly always
+    if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) {      // the fallback launch of exact re-treeing: nothing to do, nearly always
         KArgsC P = kargs_fresh();
         if (KARG(P, list_mode) == 2u && KARG(P, redo_plan)[2] == 0u) return;
     }
@@ -645,11 +659,16 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             wstate[WS_KARGS] = (uint32_t)a; wstate[WS_KARGS + 1] = (uint32_t)(a >> 32);
         }
         if (LDS_SCENE) {
+            if constexpr (GRID) {
+                const uint4 *gt = reinterpret_cast<const uint4 *>(KARG(P, S.grid_cells));      // [cells | refs], padded to 32 bytes
+                for (uint32_t k = threadIdx.x; k < 2u * lds_items; k += blockDim.x) smem[k] = gt[k];
+            } else {
             const uint4 *gi = reinterpret_cast<const uint4 *>(KARG(P, S.items));
             for (uint32_t k = threadIdx.x; k < 2u * lds_items; k += blockDim.x) {
                 uint4 h = gi[k];
                 if ((k & 1u) && (h.z >> 28) == 0u) h.z <<= LdsMem::ISHIFT;      // an inner item's skip link, in cursor units
                 smem[(k >> 1) + ((k & 1u) ? lds_items : 0u)] = h;
+            }
             }
             const uint4 *gs = reinterpret_cast<const uint4 *>(KARG(P, S.spheres));
             for (uint32_t k = threadIdx.x; k < lds_spheres; k += blockDim.x) smem[2u * lds_items + k] = gs[k];
@@ -697,6 +716,7 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
         const unsigned long long m_pend0 = __builtin_amdgcn_uicmp(L.pend, 0u, 33 /* ne */) & m_act;
         unsigned long long m_trav = __builtin_amdgcn_uicmp(L.i, L.end, 36 /* ult */);
         if (F & VKF_INSTANCE) m_trav |= __builtin_amdgcn_sicmp(L.cur_inst, 0, 39 /* sge */);
+        if (GRID) m_trav |= __builtin_amdgcn_uicmp(L.cell, GRID_LAST, 36 /* ult */);
         const unsigned long long m_heavy = HAS_HEAVY ? (heavy_mask<F>(L.pend) & m_pend0) : 0ull;
         const unsigned long long m_light = m_pend0 & ~m_heavy;
         const unsigned long long m_shade = m_act & ~m_pend0 & ~m_trav;
@@ -737,7 +757,8 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
             unsigned long long m_pend, m_lt, m_inst = 0ull;
             auto masks = [&]() {
                 m_pend = __builtin_amdgcn_uicmp(L.pend, 0u, 33 /* ne */);
-                m_lt = __builtin_amdgcn_uicmp(L.i, range_end<F, Mem>(L, S), 36 /* ult */);
+                if constexpr (GRID) m_lt = __builtin_amdgcn_uicmp(L.i, L.end, 36 /* ult */) | __builtin_amdgcn_uicmp(L.cell, GRID_LAST, 36 /* ult */);
+                else m_lt = __builtin_amdgcn_uicmp(L.i, range_end<F, Mem>(L, S), 36 /* ult */);
                 if (F & VKF_INSTANCE) m_inst = __builtin_amdgcn_sicmp(L.cur_inst, 0, 39 /* sge */);
             };
             masks();
@@ -757,6 +778,9 @@ __global__ __launch_bounds__((MINW <= 4 ? 1024 : (MINW == 5 ? 640 : (MINW == 6 ?
                         box_steps<F, Mem, 1>(L, S, M, go);
                         go = active && L.pend == 0u && L.i < range_end<F, Mem>(L, S);
                     }
+                } else if constexpr (GRID) {
+                    // one grid step per exit test: the next two references of the lane's cell, or the next cell
+                    if (go) (void)grid_step(L, S, M);
                 } else {
                     box_steps<F, Mem, UNROLL>(L, S, M, go);
                 }

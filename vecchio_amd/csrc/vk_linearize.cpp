@@ -42,12 +42,8 @@ DScene LinearScene::host_view() const {
     s.clear_k = clear_k; s.clear_r2 = clear_r2; s.clear_slack = clear_slack;
     // (only where Lemma 1 is PROVEN: in the empirical form the stricter own-box test is part of what keeps it right in practice)
     s.unit_item = (ref_items.empty() || unit_item.empty() || !proven) ? nullptr : unit_item.data(); s.unit_tree = ref_items.data();
-    if (!ref_items.empty() && grid.nu != 0u) {
-        // the grid form: sound for every ordinary ray wherever it starts — no ball, no reach (vk_trace.h segment_unsafe keeps the
-        // safe-winner test)
-        s.grid = grid; s.grid_cells = grid_cells.data(); s.grid_refs = grid_refs.data();
-        s.trust_r0sq = INFINITY; s.reach = 0.0f;
-    }
+    // (the grid form, where the world is eligible: whoever walks it — use_grid() — lifts the tree forms' conditions)
+    if (!ref_items.empty() && grid.nu != 0u) { s.grid = grid; s.grid_cells = grid_cells.data(); s.grid_refs = grid_refs.data(); }
     s.fast_div = 1u;
     for (const DSphere &sp : spheres)
         if (!(fabsf(sp.cx) < 1073741824.0f && fabsf(sp.cy) < 1073741824.0f && fabsf(sp.cz) < 1073741824.0f && fabsf(sp.r) < 1073741824.0f)) s.fast_div = 0u;

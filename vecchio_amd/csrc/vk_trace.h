@@ -83,7 +83,7 @@ struct Lane {
     // traversal cursor
     uint32_t i, end, pend, pend2; int32_t cur_inst;
     // ... of the grid form (DGrid; grid_step below): i, end = the current cell's range in refs[]; cell = major index | minor index << 10
-    // | last minor index of this column << 20, or GRID_START / GRID_DONE; the segment's parameter range inside the layer's dilated box
+    // | last minor index of this column << 20, or GRID_LAST / GRID_DONE; the segment's parameter range inside the layer's dilated box
     // and the dilation itself
     uint32_t cell; float ta, tb, dl;
     // closest hit so far (deferred record)
@@ -391,12 +391,25 @@ VK_HD bool slab_exact(const DItem &n, V3 o, V3 d, float tmin, float tmax) {
     return true;
 }
 // ------------------------------------------------------------------ traversal
-constexpr uint32_t GRID_START = 0xFFFFFFFEu, GRID_DONE = 0xFFFFFFFFu;
+// Lane::cell: GRID_DONE = the lane walks a tree (no grid, or a segment walked again); GRID_LAST = a grid lane with no cell left to
+// visit (what is left of its current list, i .. end, is still to be tested); below that: the packed cell
+constexpr uint32_t GRID_DONE = 0xFFFFFFFFu, GRID_LAST = 0xFFFFFFFEu;
+// (a reciprocal computed where it is needed — v_rcp_f32 on the device, 1 ulp — instead of the lane's L.inv: the grid kernels then do not
+// keep the three reciprocals and three o/d products of the tree walk alive through their loops)
+VK_HD float rcp_here(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(VK_EXACT_INV)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
 // exact re-treeing: outside the ball in which the gate lemma's bounds hold (DScene::trust_c0; never for r0 = +inf)
 VK_HD bool origin_untrusted(const DScene &S, V3 o) {
     const V3 oc = o - v3(S.trust_c0[0], S.trust_c0[1], S.trust_c0[2]);
     return !(length2(oc) <= S.trust_r0sq);
 }
+VK_HD void grid_begin(Lane &L, const DScene &S);
 // redo (exact re-treeing of a scene traversed from global memory, DScene::walk_start != 0): this lane walks the tree as handed over,
 // items[0, walk_start - 1), on unscaled distances
 template <uint32_t ISHIFT = 0, bool FUSED = false, bool TIGHT = FUSED>
@@ -412,7 +425,7 @@ VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time, bool 
     L.cell = GRID_DONE;
     // the grid form: refs[0, n_always) first (a segment walked again — scenes in global memory keep the tree as handed over in items[],
     // walk_start = its length — walks that tree instead)
-    if (TIGHT && S.grid.nu != 0u && !redo) { L.i = 0u; L.end = S.grid.n_always; L.cell = GRID_START; }
+    if (TIGHT && S.grid.nu != 0u && !redo) grid_begin(L, S);
     L.T = INFINITY; L.best_prim = 0; L.best_inst = -1; L.best_aux = 0.0f;
     // A ray with a NaN (or infinite) direction or origin hits EVERY box — f32::min/max drop the NaN quotients, accel.rs:21-31 —
     // and no sphere: Sphere::hit's discriminant is NaN (hittable.rs:66-70).  The reference walks its whole tree for such a ray
@@ -422,7 +435,7 @@ VK_HD void begin_segment(Lane &L, const DScene &S, V3 o, V3 d, float time, bool 
     // EVERY frame, whatever its length.
     if (S.features == 0u) {
         bool dead = !(L.a < INFINITY) || !(fabsf(o.x) + fabsf(o.y) + fabsf(o.z) < INFINITY);
-        if (dead) { L.i = L.end; L.cell = GRID_DONE; }
+        if (dead) { L.i = L.end; if (L.cell != GRID_DONE) L.cell = GRID_LAST; }
     }
 }
 
@@ -576,7 +589,7 @@ VK_HD void process_ref(Lane &L, const DScene &S, const Mem &M, uint32_t ref) {
 //              (accel.rs:64-70)
 // A lane has box work when pend == 0 and prim work when pend != 0; objects are always
 // finished before the next item is fetched, which is the reference's order.
-VK_HD bool traversing(const Lane &L) { return L.i < L.end || L.pend != 0 || L.cur_inst >= 0 || L.cell != GRID_DONE; }
+VK_HD bool traversing(const Lane &L) { return L.i < L.end || L.pend != 0 || L.cur_inst >= 0 || L.cell < GRID_LAST; }
 VK_HD bool has_prim_work(const Lane &L) { return L.pend != 0; }
 // Sphere / MovingSphere / Rect tests are ~50 instructions; Boxy, lists, media and instance entry cost several times that
 // In the everything-variants a Boxy (kind 7: six rect tests, no draw, no change of space) counts as light and is served inside the
@@ -653,7 +666,13 @@ VK_HD bool segment_unsafe(const Lane &L, const DScene &S, const Mem &M) {
         const DSphere sp = M.sphere(VKD_INDEX(L.best_prim));
         const float bx0 = sp.cx - sp.r, bx1 = sp.cx + sp.r, by0 = sp.cy - sp.r, by1 = sp.cy + sp.r, bz0 = sp.cz - sp.r, bz1 = sp.cz + sp.r;
         float x0, x1, y0, y1, z0, z1;
-        if constexpr (fused_box<F, Mem>()) {
+        if (S.grid.nu != 0u) {
+            // (the grid form: reciprocals made here, see rcp_here; the unfused form, whose error the margins below cover a fortiori)
+            const float ix = rcp_here(L.d.x) * S.gate_scale, iy = rcp_here(L.d.y) * S.gate_scale, iz = rcp_here(L.d.z) * S.gate_scale;
+            x0 = (bx0 - L.o.x) * ix; x1 = (bx1 - L.o.x) * ix;
+            y0 = (by0 - L.o.y) * iy; y1 = (by1 - L.o.y) * iy;
+            z0 = (bz0 - L.o.z) * iz; z1 = (bz1 - L.o.z) * iz;
+        } else if constexpr (fused_box<F, Mem>()) {
             x0 = __builtin_fmaf(bx0, L.inv.x, -L.oi.x); x1 = __builtin_fmaf(bx1, L.inv.x, -L.oi.x);
             y0 = __builtin_fmaf(by0, L.inv.y, -L.oi.y); y1 = __builtin_fmaf(by1, L.inv.y, -L.oi.y);
             z0 = __builtin_fmaf(bz0, L.inv.z, -L.oi.z); z1 = __builtin_fmaf(bz1, L.inv.z, -L.oi.z);
@@ -680,6 +699,7 @@ VK_HD bool segment_unsafe(const Lane &L, const DScene &S, const Mem &M) {
             own.mnx = bx0; own.mxx = bx1; own.mny = by0; own.mxy = by1; own.mnz = bz0; own.mxz = bz1; own.w0 = 0u; own.w1 = 0u;
             ok = slab_exact(own, L.o, L.d, T_MIN, L.T);
         }
+#ifndef VK_NO_SECOND_CHANCE
         if (!ok && L.xnan == L.xnan && S.unit_item != nullptr) {
             // Second chance: the box that gates the sphere in the tree as handed over — its leaf's.  The reference reaches the sphere
             // through that leaf and its ancestors, which contain it: if the leaf's box passes AxisBB::hit with tmax = the winner's t,
@@ -690,6 +710,7 @@ VK_HD bool segment_unsafe(const Lane &L, const DScene &S, const Mem &M) {
             const uint32_t ui = S.unit_item[VKD_INDEX(L.best_prim)];
             if (ui != 0xFFFFFFFFu) ok = slab_exact(S.unit_tree[ui], L.o, L.d, T_MIN, L.T);
         }
+#endif
         unsafe = unsafe || !ok || !(sp.r > 0.0f);
     }
     return unsafe;
@@ -835,68 +856,65 @@ VK_HD void prim_step(Lane &L, const DScene &S, const Mem &M) {
 // cells of the column within e of that are visited.  Every cell within e of the ray's path is: a point of the path lies in some
 // column's dilated strip at a parameter inside that column's range.  The reciprocals are the lane's (1 ulp, times gate_scale: undone
 // here), floor() of a quotient may land a cell off: dl carries 2 m_reg for that (vk_linearize.cpp rt_build_grid).
+// the segment's set-up (begin_segment): its parameter range inside the layer's dilated box, the dilation, the first column
+VK_HD void grid_begin(Lane &L, const DScene &S) {
+    const DGrid &G = S.grid;
+    L.i = 0u; L.end = G.n_always;
+    const bool mz = fabsf(L.d.z) > fabsf(L.d.x);
+    const float unscale = 1.0f + S.t_pad;                 // (the reciprocals set_space has just made carry gate_scale)
+    // the dilation this origin can need at most (the far corner of the layer's box), the segment's range inside the box dilated by
+    // that, the dilation its far end needs, the range again across the layer
+    const float fx = fmaxf(fabsf(L.o.x - G.lo[0]), fabsf(L.o.x - G.hi[0])), fy = fmaxf(fabsf(L.o.y - G.lo[1]), fabsf(L.o.y - G.hi[1]));
+    const float fz = fmaxf(fabsf(L.o.z - G.lo[2]), fabsf(L.o.z - G.hi[2]));
+    const float dlc = __builtin_fmaf(G.k, sqrtf(fx * fx + fy * fy + fz * fz) + G.r2, G.slack);
+    const float ix_ = L.inv.x * unscale, iy_ = L.inv.y * unscale, iz_ = L.inv.z * unscale;
+    const float x0 = ((G.lo[0] - dlc) - L.o.x) * ix_, x1 = ((G.hi[0] + dlc) - L.o.x) * ix_;
+    const float y0 = ((G.lo[1] - dlc) - L.o.y) * iy_, y1 = ((G.hi[1] + dlc) - L.o.y) * iy_;
+    const float z0 = ((G.lo[2] - dlc) - L.o.z) * iz_, z1 = ((G.hi[2] + dlc) - L.o.z) * iz_;
+    float ta = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+    float tb = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    float dl = fminf(__builtin_fmaf(G.k, __builtin_fmaf(tb, sqrtf(L.a), G.r2), G.slack), dlc);
+    if (!(dl >= 0.0f)) dl = dlc;
+    const float w0 = ((G.lo[1] - dl) - L.o.y) * iy_, w1 = ((G.hi[1] + dl) - L.o.y) * iy_;
+    ta = fmaxf(ta, fminf(w0, w1)); tb = fminf(tb, fmaxf(w0, w1));
+    L.ta = ta; L.tb = tb; L.dl = dl;
+    if (!(ta <= tb)) { L.cell = GRID_LAST; return; }       // (the path never comes near the layer: only refs[0, n_always))
+    const float ou = mz ? L.o.z : L.o.x, du = mz ? L.d.z : L.d.x, gu = mz ? G.ov : G.ou;
+    const int nmaj = (int)(mz ? G.nv : G.nu);
+    const float ua = __builtin_fmaf(du, ta, ou) - (du > 0.0f ? dl : -dl);
+    const int i0 = (int)fminf(fmaxf(floorf((ua - gu) * G.inv_cell), 0.0f), (float)(nmaj - 1));
+    // "the cell after the last one of column i0 - dir": the first grid_advance enters column i0
+    L.cell = ((uint32_t)(i0 - (du > 0.0f ? 1 : -1)) & 1023u) | (1u << 10);
+}
 template <class Mem>
 VK_HD void grid_advance(Lane &L, const DScene &S, const Mem &M) {
     const DGrid &G = S.grid;
     const bool mz = fabsf(L.d.z) > fabsf(L.d.x);
-    const float unscale = 1.0f + S.t_pad;
     const float ou = mz ? L.o.z : L.o.x, ov = mz ? L.o.x : L.o.z, du = mz ? L.d.z : L.d.x, dv = mz ? L.d.x : L.d.z;
-    const float ru = (mz ? L.inv.z : L.inv.x) * unscale;
     const float gu = mz ? G.ov : G.ou, gv = mz ? G.ou : G.ov;
     const int nmaj = (int)(mz ? G.nv : G.nu), nmin = (int)(mz ? G.nu : G.nv);
     const int dir = du > 0.0f ? 1 : -1;
-    int i, j, jhi;
-    bool enter;                       // a column is to be entered (else: the next cell of the current one)
-    if (L.cell == GRID_START) {
-        // the dilation this origin can need at most (the far corner of the layer's box), the segment's range inside the box dilated by
-        // that, the dilation its far end needs, the range again across the layer
-        const float fx = fmaxf(fabsf(L.o.x - G.lo[0]), fabsf(L.o.x - G.hi[0])), fy = fmaxf(fabsf(L.o.y - G.lo[1]), fabsf(L.o.y - G.hi[1]));
-        const float fz = fmaxf(fabsf(L.o.z - G.lo[2]), fabsf(L.o.z - G.hi[2]));
-        const float dlc = __builtin_fmaf(G.k, sqrtf(fx * fx + fy * fy + fz * fz) + G.r2, G.slack);
-        const float ix_ = L.inv.x * unscale, iy_ = L.inv.y * unscale, iz_ = L.inv.z * unscale;
-        const float x0 = ((G.lo[0] - dlc) - L.o.x) * ix_, x1 = ((G.hi[0] + dlc) - L.o.x) * ix_;
-        const float y0 = ((G.lo[1] - dlc) - L.o.y) * iy_, y1 = ((G.hi[1] + dlc) - L.o.y) * iy_;
-        const float z0 = ((G.lo[2] - dlc) - L.o.z) * iz_, z1 = ((G.hi[2] + dlc) - L.o.z) * iz_;
-        float ta = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-        float tb = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), L.T));
-        if (!(ta <= tb)) { L.cell = GRID_DONE; return; }
-        const float dn = sqrtf(L.a);
-        float dl = fminf(__builtin_fmaf(G.k, __builtin_fmaf(tb, dn, G.r2), G.slack), dlc);
-        if (!(dl >= 0.0f)) dl = dlc;
-        const float w0 = ((G.lo[1] - dl) - L.o.y) * iy_, w1 = ((G.hi[1] + dl) - L.o.y) * iy_;
-        ta = fmaxf(ta, fminf(w0, w1)); tb = fminf(tb, fmaxf(w0, w1));
-        if (!(ta <= tb)) { L.cell = GRID_DONE; return; }
-        L.ta = ta; L.tb = tb; L.dl = dl;
-        const float ua = __builtin_fmaf(du, ta, ou) - (float)dir * dl;
-        i = (int)fminf(fmaxf(floorf((ua - gu) * G.inv_cell), 0.0f), (float)(nmaj - 1));
-        j = 0; jhi = 0;
-        enter = true;
-    } else {
-        i = (int)(L.cell & 1023u); j = (int)((L.cell >> 10) & 1023u) + 1; jhi = (int)((L.cell >> 20) & 1023u);
-        enter = j > jhi;
-        if (enter) i += dir;
-    }
-    const float e = L.dl;
-    for (int guard = 0; guard < 4 && enter; guard++) {
-        if (i < 0 || i >= nmaj) { L.cell = GRID_DONE; return; }
+    // (the major index is kept in 10 bits, two's complement: -1 = 1023 is the column before the first one)
+    int i = (int)(L.cell & 1023u); if (i == 1023) i = -1;
+    int j = (int)((L.cell >> 10) & 1023u) + 1, jhi = (int)((L.cell >> 20) & 1023u);
+    if (j > jhi) {
+        // the next column; ONE per step (a column outside the segment's range leaves the state "after its last cell")
+        i += dir;
+        if (i < 0 || i >= nmaj) { L.cell = GRID_LAST; return; }
+        const float e = L.dl, ru = rcp_here(du);
         const float tend = fminf(L.tb, L.T);
         const float U0 = __builtin_fmaf((float)i, G.cell, gu), U1 = U0 + G.cell;
         const float tA = ((U0 - e) - ou) * ru, tB = ((U1 + e) - ou) * ru;
         const float t_lo = fmaxf(L.ta, fminf(tA, tB)), t_hi = fminf(tend, fmaxf(tA, tB));
         if (!(t_lo <= t_hi)) {
-            if (!(fminf(tA, tB) <= tend)) { L.cell = GRID_DONE; return; }       // the path ends before this column
-            i += dir;                                                           // (the column lies before the range's start)
-            continue;
+            if (!(fminf(tA, tB) <= tend)) { L.cell = GRID_LAST; return; }       // the path ends before this column
+            L.cell = ((uint32_t)i & 1023u) | (1u << 10);                          // (the column lies before the range's start)
+            L.i = 0u; L.end = 0u;
+            return;
         }
         const float v0 = __builtin_fmaf(dv, t_lo, ov), v1 = __builtin_fmaf(dv, t_hi, ov);
         j = (int)fminf(fmaxf(floorf(((fminf(v0, v1) - e) - gv) * G.inv_cell), 0.0f), (float)(nmin - 1));
         jhi = (int)fminf(fmaxf(floorf(((fmaxf(v0, v1) + e) - gv) * G.inv_cell), 0.0f), (float)(nmin - 1));
-        enter = false;
-    }
-    if (enter) {       // (four columns in a row outside the range: go on in the next step)
-        L.cell = (uint32_t)(i - dir) | (1u << 10);          // j = 1 > jhi = 0: the next step enters column i
-        L.i = 0u; L.end = 0u;
-        return;
     }
     const uint32_t c = mz ? (uint32_t)j * G.nv + (uint32_t)i : (uint32_t)i * G.nv + (uint32_t)j;
     L.i = M.grid_cell(S, c); L.end = M.grid_cell(S, c + 1u);
@@ -904,7 +922,7 @@ VK_HD void grid_advance(Lane &L, const DScene &S, const Mem &M) {
 }
 template <class Mem>
 VK_HD bool grid_step(Lane &L, const DScene &S, const Mem &M) {       // returns: references were queued
-    if (!(L.i < L.end)) grid_advance(L, S, M);
+    if (!(L.i < L.end) && L.cell < GRID_LAST) grid_advance(L, S, M);
     if (L.i < L.end) {
         L.pend = M.grid_ref(S, L.i);
         L.pend2 = L.i + 1u < L.end ? M.grid_ref(S, L.i + 1u) : 0u;

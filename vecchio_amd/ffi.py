@@ -140,7 +140,7 @@ class PartInfo(C.Structure):
                 ("can_access_landing_device", C.c_uint32), ("kernel_ms", C.c_double)]
 
 
-VK_TREE_HANDED_OVER, VK_TREE_REBUILT_PROVEN, VK_TREE_REBUILT_EMPIRICAL, VK_TREE_REBUILT_FAST, VK_TREE_REBUILT_NEAR = range(5)
+VK_TREE_HANDED_OVER, VK_TREE_REBUILT_PROVEN, VK_TREE_REBUILT_EMPIRICAL, VK_TREE_REBUILT_FAST, VK_TREE_REBUILT_NEAR, VK_TREE_REBUILT_GRID = range(6)
 VK_GATHER_NONE, VK_GATHER_PEER_COPY, VK_GATHER_RCCL = range(3)
 
 
