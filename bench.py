@@ -49,6 +49,14 @@ WORKLOADS = {
 }
 
 
+
+def is_main_kernel(name):
+    """a render_kernel<F, LDS_SCENE, MINW, STATS, COST, GRID> instance that is not the probe launch's (COST = true)"""
+    import re
+    m = re.search(r"render_kernel<\s*\d+u?,\s*(?:true|false),\s*\d+,\s*(?:true|false),\s*(true|false)(?:,\s*(?:true|false))?\s*>", name)
+    return bool(m) and m.group(1) == "false"
+
+
 def WORKLOAD_SAMPLES(name):
     _, w, spp, _, _ = WORKLOADS[name]
     h = {"C2": 1080, "C3": 800, "C4": 1024, "C5": 4096}[name]
@@ -152,7 +160,7 @@ def measure_counters_live(workload, timeout_s=75):
             vals = {c: [] for c in group}
             for f in glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if "render_kernel" in r["Kernel_Name"] and ", true>(" not in r["Kernel_Name"] and r["Counter_Name"] in vals:
+                    if is_main_kernel(r["Kernel_Name"]) and r["Counter_Name"] in vals:
                         vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
             for c in group:
                 if not vals[c]:

@@ -47,6 +47,8 @@ static DScene scene_view(const LinearScene &LS, std::vector<DItem> &both) {
     if (const char *e = getenv("EMU_GRID")) { if (e[0] == '0') drop_grid(S); }
     if (S.grid.nu != 0u && !LS.ref_items.empty()) {
         use_grid(S);
+        // (test switch: no dilation — the walk then visits the cells on the ray's exact path only, and part F's control shows what is lost)
+        if (const char *e = getenv("EMU_GRID_NO_DILATION")) { if (e[0] == '1') { S.grid.k = 0.0f; S.grid.slack = 0.0f; } }
         // the grid form: a failed segment requeues its sample (trace_one: the whole sample again on reference_view), whether the device
         // walks the grid from LDS or from global memory
         return S;
@@ -792,6 +794,78 @@ int emu_hit(const vk_scene_desc *desc, const float o[3], const float d[3], float
     };
     if (glob) run(GlobalMem{}); else run(FusedMem{});
     return VK_OK;
+}
+
+// Part F of the gate lemma's tests (round 5): the GRID form finds every candidate.  n rays against the world of `desc` (spheres only,
+// eligible for the grid form): the closest hit of the grid walk — begin_segment, grid_step, prim_step, exactly as the device runs them
+// — against the closest hit over ALL spheres, tested one by one with the same Sphere::hit arithmetic.  Rays where they hurt: origins on
+// spheres, in them, far away (out to 1e4), directions along the layer, and lines that pass a random sphere at (1 + delta) radii, delta
+// where the f32 discriminant reports hits that are not there.  counts = {rays, rays with a hit, rays whose two answers differ};
+// viol = the first such ray (o, d, T grid, T brute force).
+int emu_grid_claims(const vk_scene_desc *desc, uint64_t n, uint64_t seed, uint64_t counts[3], float viol[8]) {
+    LinearScene LS;
+    int st = linearize_env(desc, LS, g_err);
+    if (st != VK_OK) return st;
+    if (LS.features != 0u || LS.grid.nu == 0u) { g_err = "emu_grid_claims: a world the grid form applies to"; return VK_ERR_UNSUPPORTED; }
+    std::vector<DItem> both;
+    DScene S = scene_view(LS, both);
+    if (S.grid.nu == 0u) { g_err = "emu_grid_claims: the grid is switched off"; return VK_ERR_UNSUPPORTED; }
+    FusedMem M; static_cast<GlobalMem &>(M) = GlobalMem{S.items, S.spheres, S.sphere_mat, S.boxes};
+    Lcg g(seed);
+    counts[0] = counts[1] = counts[2] = 0;
+    const double U24 = 1.0 / 16777216.0;
+    const uint32_t ns = S.n_spheres;
+    for (uint64_t it = 0; it < n; it++) {
+        const DSphere sp = S.spheres[(uint32_t)(g.uni() * ns) % ns];
+        const double R = sp.r, c[3] = {sp.cx, sp.cy, sp.cz};
+        // the origin: on a sphere, inside one, near, far
+        const double pick = g.uni();
+        const double rho = pick < 0.3 ? R * (1.0 + 1e-4) : pick < 0.4 ? R * g.uni() : pick < 0.7 ? g.log_uni(1.5 * R, 50.0) : g.log_uni(50.0, 1e4);
+        double od[3] = {g.uni() - .5, g.uni() - .5, g.uni() - .5};
+        if (g.uni() < 0.5) od[1] = std::fabs(od[1]) * (g.uni() < 0.5 ? 1.0 : 0.05);        // above the layer, often low above it
+        const double on = std::sqrt(od[0] * od[0] + od[1] * od[1] + od[2] * od[2]) + 1e-30;
+        const V3 o = v3((float)(c[0] + od[0] / on * rho), (float)(c[1] + od[1] / on * rho), (float)(c[2] + od[2] / on * rho));
+        // the direction: anywhere, along the layer, or past ANOTHER sphere at (1 + delta) of its radius
+        double dd[3];
+        const double kind = g.uni();
+        if (kind < 0.25) { dd[0] = g.uni() - .5; dd[1] = g.uni() - .5; dd[2] = g.uni() - .5; }
+        else if (kind < 0.45) { dd[0] = g.uni() - .5; dd[1] = (g.uni() - .5) * 0.02; dd[2] = g.uni() - .5; }
+        else {
+            const DSphere tq = S.spheres[(uint32_t)(g.uni() * ns) % ns];
+            const double tr = tq.r, tc[3] = {tq.cx, tq.cy, tq.cz};
+            double oc[3] = {tc[0] - o.x, tc[1] - o.y, tc[2] - o.z};
+            const double dist = std::sqrt(oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2]) + 1e-30;
+            double e1[3] = {g.uni() - .5, g.uni() - .5, g.uni() - .5};
+            const double dp = (e1[0] * oc[0] + e1[1] * oc[1] + e1[2] * oc[2]) / (dist * dist);
+            for (int a = 0; a < 3; a++) e1[a] -= dp * oc[a];
+            const double en = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) + 1e-30;
+            const double wob = 64.0 * U24 * (dist / tr) * (dist / tr) + 1e-6;
+            const double delta = (g.uni() < 0.5 ? 1.0 : -1.0) * g.log_uni(1e-9, 1.0) * wob;
+            for (int a = 0; a < 3; a++) dd[a] = tc[a] + e1[a] / en * tr * (1.0 + delta) - (a == 0 ? o.x : a == 1 ? o.y : o.z);
+        }
+        const double dn = std::sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2]) + 1e-30, dl = g.log_uni(1e-2, 1e2);
+        const V3 d = v3((float)(dd[0] / dn * dl), (float)(dd[1] / dn * dl), (float)(dd[2] / dn * dl));
+        Lane L; memset(&L, 0, sizeof(L));
+        begin_segment<FusedMem::ISHIFT, true, true>(L, S, o, d, 0.0f);
+        if (!(L.xnan == L.xnan)) continue;                  // (not an ordinary ray: never trusted, segment_unsafe)
+        while (traversing(L)) traverse_step<0u, FusedMem>(L, S, M);
+        const float Tg = L.T;
+        // every sphere, one by one
+        float Tb = INFINITY;
+        const float ya = refined_rcp(L.a);
+        for (uint32_t k = 0; k < ns; k++) {
+            const DSphere q = S.spheres[k];
+            float t; bool tie;
+            if (sphere_t_tie_y(q.cx, q.cy, q.cz, q.r, L.o, L.d, L.a, ya, S.fast_div != 0u, T_MIN, Tb, t, tie)) Tb = t;
+        }
+        counts[0]++;
+        if (Tb < INFINITY) counts[1]++;
+        if (vk::f32_bits(Tg) != vk::f32_bits(Tb)) {
+            if (counts[2] == 0 && viol) { const float v[8] = {o.x, o.y, o.z, d.x, d.y, d.z, Tg, Tb}; memcpy(viol, v, sizeof(v)); }
+            counts[2]++;
+        }
+    }
+    return 0;
 }
 
 }  // extern "C"

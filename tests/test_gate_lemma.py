@@ -237,3 +237,35 @@ def test_the_clearance_margin_is_not_idle(lem):
     lem.emu_near_form_claims(4, 500_000, 1, cnt, v)
     print(f"no margin at all: {cnt[1]} candidates in {cnt[0]} pairs")
     assert cnt[1] > 100
+
+
+# ---- part F: the GRID form (late round 5; vk_linearize.cpp rt_build_grid, vk_trace.h grid_step, docs/gate_lemma.md section 8) finds
+# every candidate: its closest hit is the closest hit over ALL spheres, for rays from on, in, near and far from the spheres, along the
+# layer, and past spheres where the f32 discriminant reports hits that are not there.
+@pytest.mark.parametrize("scene,n", [("random_spheres_iow", 1_500_000), ("stress_spheres:60", 150_000), ("stress_spheres:150", 20_000)])
+def test_grid_form_finds_every_candidate(scene, n, lem, monkeypatch):
+    from vecchio_amd import HostScene
+    lem.emu_grid_claims.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    monkeypatch.delenv("EMU_GRID_NO_DILATION", raising=False)
+    hs = HostScene(scene, 1)
+    total = 0
+    for seed in (1, 2):
+        cnt = (C.c_uint64 * 3)(); v = (C.c_float * 8)()
+        assert lem.emu_grid_claims(hs.desc, n, seed, cnt, v) == 0
+        assert cnt[2] == 0, f"{scene}: {cnt[2]} of {cnt[0]} rays, e.g. o {list(v[0:3])} d {list(v[3:6])} grid {v[6]} all spheres {v[7]}"
+        assert cnt[1] > 0.5 * cnt[0]
+        total += cnt[0]
+    print(f"{scene}: 0 of {total} rays")
+
+
+def test_the_grids_dilation_is_not_idle(lem, monkeypatch):
+    """control of part F: with the dilation switched off (the cells on the ray's exact path only) candidates ARE missed — hits an f32
+    Sphere::hit reports for rays that pass a far sphere at more than its radius"""
+    from vecchio_amd import HostScene
+    lem.emu_grid_claims.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    monkeypatch.setenv("EMU_GRID_NO_DILATION", "1")
+    hs = HostScene("stress_spheres:60", 1)
+    cnt = (C.c_uint64 * 3)(); v = (C.c_float * 8)()
+    assert lem.emu_grid_claims(hs.desc, 150_000, 1, cnt, v) == 0
+    print(f"no dilation: {cnt[2]} of {cnt[0]} rays differ")
+    assert cnt[2] > 20

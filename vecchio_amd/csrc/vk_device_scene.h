@@ -102,6 +102,9 @@ struct DGrid {
     float lo[3], hi[3];           // the box around the registered spheres' surfaces
     float k, r2, slack;           // the dilation: dl = k (s + r2) + slack
     uint32_t n_always;            // refs[0, n_always): the spheres tested for every segment; cells' lists follow
+    // ... of which the LAST n_gated (large spheres, but not the ground's size) only when the ray passes the box [alo, ahi] around them,
+    // dilated like the layer's
+    uint32_t n_gated; float alo[3], ahi[3];
 };
 
 // What the kernel sees.  All pointers are device (or, in the CPU emulator, host) addresses.

@@ -956,6 +956,17 @@ struct Builder {
             r_max = std::max(r_max, (double)sp.r);
         }
         if (always.size() > 8u || field.size() < 64u) return false;
+        // the largest first; those within 64 median radii (not a ground sphere, whose box every ray is in) share one gate box
+        std::sort(always.begin(), always.end(), [&](uint32_t a, uint32_t b) { return L.spheres[VKD_INDEX(a)].r > L.spheres[VKD_INDEX(b)].r; });
+        uint32_t n_gated = 0;
+        float alo[3] = {INFINITY, INFINITY, INFINITY}, ahi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t r : always) {
+            const DSphere &sp = L.spheres[VKD_INDEX(r)];
+            if (!((double)sp.r <= 64.0 * r_med)) continue;
+            n_gated++;
+            const float c[3] = {sp.cx, sp.cy, sp.cz};
+            for (int a = 0; a < 3; a++) { alo[a] = fminf(alo[a], std::nextafter(c[a] - sp.r, -INFINITY)); ahi[a] = fmaxf(ahi[a], std::nextafter(c[a] + sp.r, INFINITY)); }
+        }
         const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
         if (!(ex >= 4.0 * ey && ez >= 4.0 * ey && ex > 0.0 && ez > 0.0)) return false;
         double h = std::sqrt(ex * ez / (double)field.size());
@@ -1005,6 +1016,8 @@ struct Builder {
         G.r2 = (float)(2.0 * r_max * (1.0 + 1e-6));
         G.slack = (float)(2.0 * m_reg);
         G.n_always = (uint32_t)always.size();
+        G.n_gated = n_gated;
+        for (int a = 0; a < 3; a++) { G.alo[a] = n_gated ? alo[a] : 0.0f; G.ahi[a] = n_gated ? ahi[a] : 0.0f; }
         if (getenv("VK_RETREE_DEBUG"))
             fprintf(stderr, "vecchio_amd: exact re-treeing, grid form: %zu spheres in %u x %u cells of %g (%zu references), %zu tested always\n",
                 field.size(), nu, nv, h, L.grid_refs.size() - 1u - always.size(), always.size());

@@ -878,6 +878,15 @@ VK_HD void grid_begin(Lane &L, const DScene &S) {
     const float w0 = ((G.lo[1] - dl) - L.o.y) * iy_, w1 = ((G.hi[1] + dl) - L.o.y) * iy_;
     ta = fmaxf(ta, fminf(w0, w1)); tb = fminf(tb, fmaxf(w0, w1));
     L.ta = ta; L.tb = tb; L.dl = dl;
+    if (G.n_gated != 0u) {
+        // the large spheres' common gate: a candidate of one of them lies within dlc of it, hence of their box
+        const float p0 = ((G.alo[0] - dlc) - L.o.x) * ix_, p1 = ((G.ahi[0] + dlc) - L.o.x) * ix_;
+        const float q0 = ((G.alo[1] - dlc) - L.o.y) * iy_, q1 = ((G.ahi[1] + dlc) - L.o.y) * iy_;
+        const float r0 = ((G.alo[2] - dlc) - L.o.z) * iz_, r1 = ((G.ahi[2] + dlc) - L.o.z) * iz_;
+        const float gin = fmaxf(fmaxf(fminf(p0, p1), fminf(q0, q1)), fmaxf(fminf(r0, r1), 0.0f));
+        const float gout = fminf(fminf(fmaxf(p0, p1), fmaxf(q0, q1)), fmaxf(r0, r1));
+        if (gin > gout * 1.000001f + 1e-30f) L.end = G.n_always - G.n_gated;      // (a NaN anywhere: tested)
+    }
     if (!(ta <= tb)) { L.cell = GRID_LAST; return; }       // (the path never comes near the layer: only refs[0, n_always))
     const float ou = mz ? L.o.z : L.o.x, du = mz ? L.d.z : L.d.x, gu = mz ? G.ov : G.ou;
     const int nmaj = (int)(mz ? G.nv : G.nu);
