@@ -89,6 +89,27 @@ def test_unit_form_forced_on_the_gpu(device):
     assert r.returncode == 0 and "UNIT FORM OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_near_form_in_lds_where_the_grid_form_would_do(device):
+    """the NEAR form staged in LDS (the InOneWeekend worlds' default before the grid form, still the default of a spanned world that is
+    no layer, or has lights): VK_NO_GRID=1 (read at scene creation: a child process).  Every pixel the handed-over tree's, a few samples
+    through the second launch."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from vecchio_amd import DeviceScene, HostScene, ffi\n"
+            "out = []\n"
+            "for flags in (0, ffi.VK_SCENE_REFERENCE_TREE):\n"
+            "    hs = HostScene('random_spheres_iow', 3); hs.desc.contents.flags = flags; cam = hs.next_camera()\n"
+            "    ds = DeviceScene(hs.desc)\n"
+            "    img, st = ds.render(cam, hs.params(640, 96, 50, seed=3))\n"
+            "    out.append((img, ds.info().tree, ds.last_requeued_samples(), st.scene_in_lds, st.samples)); ds.close()\n"
+            "assert out[0][1] == ffi.VK_TREE_REBUILT_NEAR and out[1][1] == ffi.VK_TREE_HANDED_OVER, (out[0][1], out[1][1])\n"
+            "assert out[0][3] and out[0][2] < 0.01 * out[0][4], out[0][2:]\n"
+            "assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))\n"
+            "print('NEAR FORM OK', out[0][2])\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VK_NO_GRID="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "NEAR FORM OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_the_headline_frame_at_full_size_is_the_handed_over_trees(device):
     """BASELINE C2 exactly as bench.py renders it — 1920 x 1080 x 1024 spp, depth 50, scene seed 1, render seed 2: the default (exact
     re-treeing, near form staged in LDS) against VK_SCENE_REFERENCE_TREE, all 2.1 G samples, bit for bit (main.rs:181-198; 0.6 s of GPU)."""

@@ -371,8 +371,8 @@ int launch_variant(vk_scene *s, const KArgs &A, bool lds, dim3 grid, size_t shme
         return VK_OK;
     };
     int rc;
-    if constexpr ((F & ~(uint32_t)VKF_INTEG_PDF) == 0u) {
-        if (A.S.grid.nu != 0u) {      // the grid form of exact re-treeing (DGrid)
+    if constexpr (F == 0u) {
+        if (A.S.grid.nu != 0u) {      // the grid form of exact re-treeing (DGrid): worlds without lights, i.e. the scatter integrator's
             if (cost) rc = lds ? go(&render_kernel<F, true, MINW, false, true, true>) : go(&render_kernel<F, false, MINW_G, false, true, true>);
             else rc = lds ? go(&render_kernel<F, true, MINW, false, false, true>) : go(&render_kernel<F, false, MINW_G, false, false, true>);
             if (rc != VK_OK) return rc;
@@ -760,8 +760,7 @@ int enqueue_render_f32(vk_scene *s, const vk_camera *cam, const vk_render_params
         }
         const bool gridw = A.S.grid.nu != 0u;
         if (dual && F == 0u) rc = gridw ? launch_dual<0u, true>(s, A, per_wave_lds_bytes(0u), st) : launch_dual<0u>(s, A, per_wave_lds_bytes(0u), st);
-        else if (dual && F == (uint32_t)VKF_INTEG_PDF) rc = gridw ? launch_dual<VKF_INTEG_PDF, true>(s, A, per_wave_lds_bytes(0u), st)
-                                                                   : launch_dual<VKF_INTEG_PDF>(s, A, per_wave_lds_bytes(0u), st);
+        else if (dual && F == (uint32_t)VKF_INTEG_PDF) rc = launch_dual<VKF_INTEG_PDF>(s, A, per_wave_lds_bytes(0u), st);
         else rc = launch_by_features(s, F, A, lds, dim3(grid), shmem, st, false);
     }
     if (rc != VK_OK) return rc;

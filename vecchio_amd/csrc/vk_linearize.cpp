@@ -1120,7 +1120,8 @@ struct Builder {
                 if (first || VKD_KIND(dr) == DK_RECT) L.tie_rank[id] = (n_blocks << 20) | (k ? ranked[i].rank2 : ranked[i].rank);
             }
         }
-        if (retree_units && proven && allow_grid && inst < 0 && items0 == 0) (void)rt_build_grid(ranked);
+        // (a world without lights: it can only be rendered with the scatter integrator, whose sphere-only kernel has the grid walk)
+        if (retree_units && proven && allow_grid && inst < 0 && items0 == 0 && d->n_lights == 0u) (void)rt_build_grid(ranked);
         rt_emit(objs, 0, objs.size(), 0);
         done = true;
         if (inst < 0 && VK_REF_KIND(d->world) == VK_KIND_BVH && root == VK_REF_INDEX(d->world)) world_rebuilt = true;
