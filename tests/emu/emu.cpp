@@ -796,6 +796,26 @@ int emu_hit(const vk_scene_desc *desc, const float o[3], const float d[3], float
     return VK_OK;
 }
 
+// debug: the ancestors of sphere `sidx`'s leaf in the tree as handed over, and whether each box passes AxisBB::hit(T_MIN, tmax) for the ray
+int emu_unit_chain(const vk_scene_desc *desc, uint32_t sidx, const float o[3], const float d[3], float tmax) {
+    LinearScene LS;
+    int st = linearize_env(desc, LS, g_err);
+    if (st != VK_OK) return st;
+    const uint32_t ui = LS.unit_item.empty() ? 0xFFFFFFFFu : LS.unit_item[sidx];
+    fprintf(stderr, "sphere %u unit item %u of %zu\n", sidx, ui, LS.ref_items.size());
+    if (ui == 0xFFFFFFFFu) return 0;
+    const V3 O = v3(o[0], o[1], o[2]), D = v3(d[0], d[1], d[2]);
+    for (uint32_t i = 0; i <= ui; i++) {
+        const DItem &it = LS.ref_items[i];
+        const bool inner = (it.w0 >> 28) == 0u;
+        const bool anc = i == ui || (inner && it.w0 > ui);
+        if (!anc) continue;
+        fprintf(stderr, "  item %u %s box (%.9g %.9g %.9g)-(%.9g %.9g %.9g) w %08x %08x passes %d\n", i, inner ? "inner" : "leaf", it.mnx, it.mny, it.mnz,
+            it.mxx, it.mxy, it.mxz, it.w0, it.w1, (int)slab_exact(it, O, D, T_MIN, tmax));
+    }
+    return 0;
+}
+
 // Part F of the gate lemma's tests (round 5): the GRID form finds every candidate.  n rays against the world of `desc` (spheres only,
 // eligible for the grid form): the closest hit of the grid walk — begin_segment, grid_step, prim_step, exactly as the device runs them
 // — against the closest hit over ALL spheres, tested one by one with the same Sphere::hit arithmetic.  Rays where they hurt: origins on

@@ -229,6 +229,87 @@ class SphereCrowd(Gen):
         return desc, cam, params(32, 24, 3, max_depth=int(r.choice([3, 12, 50])), seed=int(r.integers(1, 1000)), **kw)
 
 
+class LayerWorld(SphereCrowd):
+    """Worlds the GRID form applies to (vk_linearize.cpp rt_build_grid): hundreds of small spheres in a layer across y — on a jittered
+    grid, in rows, in a ring, or scattered; layers far from the coordinate origin (rounding of the cell arithmetic), very thin and four
+    times thicker ones, radii mixed within the 2.5-median-radii class — plus a ground sphere and a few large ones, random tree shapes as
+    in SphereCrowd; cameras inside the layer, above it, far from it, grazing it."""
+    def build(self, far=None):
+        r = self.r
+        n_side = int(r.choice([9, 14, 24, 40]))
+        pitch = float(r.choice([0.5, 1.0, 2.5]))
+        rad = float(r.choice([0.05, 0.2, 0.45])) * pitch
+        centre = np.array([0.0, 0.0, 0.0]) if r.uniform() < 0.5 else r.uniform(-1.0, 1.0, 3) * np.array([3000.0, 40.0, 3000.0])
+        thick = float(r.choice([0.0, 0.0, 1.5])) * rad
+        shape = int(r.integers(0, 4))
+        objs = []
+        for i in range(n_side):
+            for j in range(n_side):
+                if shape == 1 and j % 3:                      # rows
+                    continue
+                if shape == 2 and not (0.25 * n_side ** 2 <= (i - n_side / 2) ** 2 + (j - n_side / 2) ** 2 <= 0.3 * n_side ** 2 + n_side):      # a ring
+                    continue
+                x, z = (i - n_side / 2 + r.uniform(0, 0.8)) * pitch, (j - n_side / 2 + r.uniform(0, 0.8)) * pitch
+                if shape == 3:
+                    x, z = r.uniform(-n_side / 2, n_side / 2, 2) * pitch
+                rr = rad * float(r.choice([1.0, 1.0, 0.6, 1.8]))
+                objs.append(self.one(centre + np.array([x, rr + r.uniform(0, 1) * thick, z]), rr))
+        if len(objs) < 90:
+            for _ in range(90 - len(objs)):
+                x, z = r.uniform(-n_side / 2, n_side / 2, 2) * pitch
+                objs.append(self.one(centre + np.array([x, rad, z]), rad))
+        R = float(r.choice([1.0e3, 1.0e4]))
+        objs.append(self.one(centre + np.array([0.0, -R, 0.0]), R))                 # the ground
+        for _ in range(int(r.integers(0, 4))):                                       # large spheres standing in the layer
+            big = rad * float(r.uniform(4.0, 9.0))
+            objs.append(self.one(centre + np.array([r.uniform(-3, 3) * pitch, big, r.uniform(-3, 3) * pitch]), big, m=self.surface[int(r.integers(0, 4))]))
+        order = r.permutation(len(objs))
+        world, _ = self.tree([objs[i] for i in order])
+        desc = self.d.finish(world, [])
+        ext = n_side * pitch
+        view = int(r.integers(0, 4))
+        ang = r.uniform(0, 6.28)
+        if view == 0:      # inside the layer, a sphere's height above the ground
+            lf = centre + np.array([0.3 * ext * np.cos(ang), 2.5 * rad, 0.3 * ext * np.sin(ang)]); la = centre + np.array([0.0, rad, 0.0])
+        elif view == 1:    # above it
+            lf = centre + np.array([0.2 * ext, 0.8 * ext, 0.1 * ext]); la = centre
+        elif view == 2:    # far away
+            lf = centre + np.array([40.0 * ext * np.cos(ang), 9.0 * ext, 40.0 * ext * np.sin(ang)]); la = centre
+        else:              # grazing
+            lf = centre + np.array([2.0 * ext * np.cos(ang), 3.0 * rad, 2.0 * ext * np.sin(ang)]); la = centre + np.array([0.0, rad, 0.0])
+        cam = camera(tuple(float(x) for x in lf), tuple(float(x) for x in la), vfov=float(r.choice([3.0, 25.0, 60.0])) if view != 2 else 2.0)
+        return desc, cam, params(32, 24, 3, max_depth=int(r.choice([3, 12, 50])), seed=int(r.integers(1, 1000)),
+                                 integrator=ffi.VK_INTEGRATOR_SCATTER, background=ffi.VK_BACKGROUND_SKY)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_grid_form_on_layer_worlds_is_the_handed_over_tree_per_sample(seed, oracle, emu, built, monkeypatch):
+    """the GRID form on forty random layer worlds: every sample the oracle's (equal draw counts, |dRGB|) and the handed-over tree's bit
+    for bit; the grid walk's closest hit the closest hit over ALL spheres for 20 000 adversarial rays (tests/emu emu_grid_claims); and
+    the same world on the near / unit form's TREE (EMU_GRID=0), which a scene too large for LDS is walked on"""
+    import ctypes as C
+    import emu_ffi
+    desc, cam, p = LayerWorld(9000 + seed).build()
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    desc.contents.flags = ffi.VK_SCENE_REFERENCE_TREE
+    img_r, ps_r, steps_r, info_r = emu.render_samples(desc, cam, p)
+    compare(ps_o, ps_r, img_o, img_r)
+    desc.contents.flags = 0
+    lib = emu_ffi.load()
+    lib.emu_grid_claims.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]
+    cnt = (C.c_uint64 * 3)(); v = (C.c_float * 8)()
+    monkeypatch.delenv("EMU_GRID", raising=False)
+    assert lib.emu_grid_claims(desc, 20000, seed + 1, cnt, v) == 0, "not a world the grid form applies to"
+    assert cnt[2] == 0, f"{cnt[2]} of {cnt[0]} rays, e.g. o {list(v[0:3])} d {list(v[3:6])} grid {v[6]} all spheres {v[7]}"
+    for env in ({}, {"EMU_GRID": "0"}, {"EMU_GRID": "0", "EMU_GLOBAL_VARIANT": "1"}):
+        for k in ("EMU_GRID", "EMU_GLOBAL_VARIANT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        img_x, ps_x, steps_x, info_x = emu.render_samples(desc, cam, p)
+        assert np.array_equal(ps_x.view(np.uint32), ps_r.view(np.uint32)), (env, int((ps_x.view(np.uint32) != ps_r.view(np.uint32)).any(axis=1).sum()))
+
+
 @pytest.mark.parametrize("seed", range(60))
 def test_exact_retree_on_sphere_crowds_is_the_handed_over_tree_per_sample(seed, oracle, emu, built, monkeypatch):
     import emu_ffi
@@ -275,6 +356,29 @@ def test_a_tree_whose_boxes_do_not_hold_their_spheres_is_walked_as_handed_over(o
         desc.contents.flags = flags
         img_x, ps_x, steps_x, info_x = emu.render_samples(desc, cam, p)
         assert steps_x == steps_r and np.array_equal(ps_x.view(np.uint32), ps_r.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(24))
+def test_grid_form_on_layer_worlds_on_the_gpu(seed, device, oracle):
+    """the GRID form through the C ABI on random layer worlds (LayerWorld above): every sample the oracle's, and the handed-over tree's
+    bit for bit"""
+    from test_gpu_parity import compare_samples, device_samples
+    from vecchio_amd import DeviceScene
+    desc, cam, p = LayerWorld(9100 + seed).build()
+    img_o, ps_o = oracle.render_samples(desc, cam, p)
+    out = []
+    for flags in (0, ffi.VK_SCENE_REFERENCE_TREE):
+        desc.contents.flags = flags
+        ds = DeviceScene(desc)
+        if flags == 0:      # (the grid form where the scene fits LDS — most of these — else the near form's tree, exact too)
+            assert ds.info().tree in (ffi.VK_TREE_REBUILT_GRID, ffi.VK_TREE_REBUILT_NEAR, ffi.VK_TREE_REBUILT_PROVEN), ds.info().tree
+            assert ds.info().tree == ffi.VK_TREE_REBUILT_GRID or not ds.info().lds_bytes
+        img_d, ps_d = device_samples(ds, cam, p)
+        compare_samples(ps_o, ps_d, img_o, img_d)
+        out.append(ps_d)
+        ds.close()
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
 
 
 @pytest.mark.gpu

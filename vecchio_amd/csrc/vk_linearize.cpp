@@ -1386,11 +1386,19 @@ int linearize(const vk_scene_desc *desc, LinearScene &out, std::string &err, con
         // every sphere's leaf in the tree as handed over (the node whose box gates it there): the safe-winner test's second chance
         // (vk_trace.h segment_unsafe).  A shared sphere: the first leaf that holds it.
         out.unit_item.assign(out.spheres.size(), 0xFFFFFFFFu);
-        for (size_t i = 0; i < out.ref_items.size(); i++) {
-            const DItem &it = out.ref_items[i];
-            if ((it.w0 >> 28) == 0u) continue;
-            for (uint32_t w : {it.w0, it.w1})
-                if (w && VKD_KIND(w) == DK_SPHERE && out.unit_item[VKD_INDEX(w)] == 0xFFFFFFFFu) out.unit_item[VKD_INDEX(w)] = (uint32_t)i;
+        {
+            // (an object that is a bare child of a node — which BVHNode::new never builds, descriptions may — sits in a leaf item whose
+            // box lets everything through: what gates it in the reference is its PARENT node's box, the innermost open inner item)
+            std::vector<uint32_t> open;
+            for (size_t i = 0; i < out.ref_items.size(); i++) {
+                const DItem &it = out.ref_items[i];
+                while (!open.empty() && out.ref_items[open.back()].w0 <= (uint32_t)i) open.pop_back();
+                if ((it.w0 >> 28) == 0u) { open.push_back((uint32_t)i); continue; }
+                const bool bare = !(it.mnx > -1.0e38f);
+                const uint32_t gate = bare ? (open.empty() ? 0xFFFFFFFFu : open.back()) : (uint32_t)i;
+                for (uint32_t w : {it.w0, it.w1})
+                    if (w && VKD_KIND(w) == DK_SPHERE && out.unit_item[VKD_INDEX(w)] == 0xFFFFFFFFu) out.unit_item[VKD_INDEX(w)] = gate;
+            }
         }
         // The gate's relative padding.  Proven form (rt_grow_units succeeded): RT_PAD, which covers the hit points of FAR origins — they
         // may precede the ray's entry into the unit's grown box by up to the box's size; near origins are covered by the growth.

@@ -699,10 +699,9 @@ VK_HD bool segment_unsafe(const Lane &L, const DScene &S, const Mem &M) {
             own.mnx = bx0; own.mxx = bx1; own.mny = by0; own.mxy = by1; own.mnz = bz0; own.mxz = bz1; own.w0 = 0u; own.w1 = 0u;
             ok = slab_exact(own, L.o, L.d, T_MIN, L.T);
         }
-#ifndef VK_NO_SECOND_CHANCE
         if (!ok && L.xnan == L.xnan && S.unit_item != nullptr) {
-            // Second chance: the box that gates the sphere in the tree as handed over — its leaf's.  The reference reaches the sphere
-            // through that leaf and its ancestors, which contain it: if the leaf's box passes AxisBB::hit with tmax = the winner's t,
+            // Second chance: the box that gates the sphere in the tree as handed over — its leaf's (of a bare child of a node: that
+            // node's; DScene::unit_item).  The reference reaches the sphere through that node and its ancestors, which contain it: if the leaf's box passes AxisBB::hit with tmax = the winner's t,
             // they all do (same monotonicity), whatever the sphere's own box says.  (The hit point of a FAR origin lies up to
             // eta(rho) off its sphere, sometimes outside the sphere's own box and still inside the leaf's: of the 1 M-sphere scene's
             // segments 0.66 % fail the first test, 0.47 % both — hits reported BEFORE the ray enters the leaf's box, which the reference
@@ -710,7 +709,6 @@ VK_HD bool segment_unsafe(const Lane &L, const DScene &S, const Mem &M) {
             const uint32_t ui = S.unit_item[VKD_INDEX(L.best_prim)];
             if (ui != 0xFFFFFFFFu) ok = slab_exact(S.unit_tree[ui], L.o, L.d, T_MIN, L.T);
         }
-#endif
         unsafe = unsafe || !ok || !(sp.r > 0.0f);
     }
     return unsafe;
