@@ -13,13 +13,17 @@ F_CORNELL = 0x2 | 0x4 | 0x10 | 0x100          # RECT | LIST | INSTANCE | BOX  (v
 F_PDF = 0x80
 
 
-def variants():
+def variants(grid=False):
+    """render_kernel<F, LDS_SCENE, MINW, STATS, COST, GRID>: the instances with the given GRID (the grid form of exact re-treeing walks
+    a table of cells instead of a tree: its own budget, test_grid_kernels_budget)"""
     txt = open(build.kernel_resources_path()).read()
     out = {}
     for blk in txt.split("Name: ")[1:]:
         name = blk.split("\n")[0].strip()
-        m = re.search(r"render_kernelILj(\d+)ELb([01])ELi(\d+)ELb([01])ELb([01])E", name)
-        if not m or m.group(5) == "1":      # ...ELb1E = the probe (COST) build: runs a few samples per pixel, not pinned
+        m = re.search(r"render_kernelILj(\d+)ELb([01])ELi(\d+)ELb([01])ELb([01])ELb([01])E", name)
+        if not m or m.group(5) == "1":      # COST = the probe build: runs a few samples per pixel, not pinned
+            continue
+        if (m.group(6) == "1") != grid:
             continue
         get = lambda k: int(re.search(re.escape(k) + r": (\d+)", blk).group(1))
         out[(int(m.group(1)), m.group(2) == "1", int(m.group(3)), m.group(4) == "1")] = dict(
@@ -96,3 +100,18 @@ def test_no_static_lds(built):
     """LdsMem::item reads the staged items at ABSOLUTE LDS addresses (cursor = address): the dynamic LDS array must start at 0"""
     for key, r in variants().items():
         assert r["static_lds"] == 0, (key, r)
+
+
+def test_grid_kernels_budget(built):
+    """the GRID instances (sphere-only scatter variant; staged in LDS in production: the dual launch's seven waves per SIMD and the
+    single-launch shape's six; the global-memory instance exists for comparisons, VK_GRID_GLOBAL=1).  They spill more than the tree walk's
+    (36 registers at seven waves when written: hoisted invariants reloaded once per code section, none in the cell loop) and are faster
+    all the same (C2 +10 %); the pin is against getting worse unnoticed."""
+    v = variants(grid=True)
+    assert (0, True, 7, False) in v and (0, True, 6, False) in v and (0, False, 7, False) in v, sorted(v)
+    assert all(k[0] == 0 for k in v), sorted(v)           # (worlds without lights only: no PDF twin)
+    r = v[(0, True, 7, False)]
+    assert r["occupancy"] >= 7 and r["vgprs"] <= 72 and r["agprs"] == 0 and not r["dynamic_stack"] and r["static_lds"] == 0, r
+    assert r["scratch"] <= 88 and r["scratch_ops"] <= 110, r
+    r = v[(0, True, 6, False)]
+    assert r["occupancy"] >= 6 and r["vgprs"] <= 80 and r["scratch"] <= 48 and not r["dynamic_stack"] and r["static_lds"] == 0, r
