@@ -979,9 +979,11 @@ int create_on_device(const std::shared_ptr<const LinearScene> &host, int device,
     s->hot_bytes = hot;
     plan_residency(s.get(), hot);
     if (grid && s->lds_bytes == 0 && !s->env.grid_global) {
-        // The grid form is for scenes staged in LDS.  A large layer seen from far away — the 1 M-sphere scene — needs wide bands of cells
-        // around its primary rays (the dilation grows with the distance from the origin: 1.4 per 1 000), and a wave waits for its
-        // longest walk: measured 500 against the near form's 1 290 Msamples/s there, 1 880 against 3 270 on 3 600 spheres.
+        // The grid form is for scenes staged in LDS.  From global memory every visited cell is three dependent cache misses (cell ->
+        // references -> sphere) once the tables outgrow an XCD's L2, where a tree's top levels stay hot; and a large layer seen from far
+        // away needs wide bands of cells around its primary rays (the dilation grows with the distance from the origin: 1.4 per 1 000).
+        // Measured: 1 M spheres 500 against the near form's 1 280 Msamples/s, 160 000 spheres 850 against 1 290 (40 000: 1 930 against
+        // 1 400, a win while everything fits L2: profiles/r05/experiments/README.md).
         grid = false;
         hot = std::max(H.items.size(), H.ref_items.size()) * sizeof(DItem) + H.spheres.size() * sizeof(DSphere) + H.boxes.size() * sizeof(DBox);
         s->grid_on = false; s->hot_bytes = hot;
