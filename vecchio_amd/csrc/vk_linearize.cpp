@@ -970,6 +970,7 @@ struct Builder {
         const double ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
         if (!(ex >= 4.0 * ey && ez >= 4.0 * ey && ex > 0.0 && ez > 0.0)) return false;
         double h = std::sqrt(ex * ez / (double)field.size());
+        if (const char *e = getenv("VK_GRID_CELL_SCALE")) { const double f = atof(e); if (f >= 0.25 && f <= 4.0) h *= f; }      // (diagnostics)
         h = std::max(h, 2.5 * r_med);
         h = std::max(h, std::max(ex, ez) / 990.0);
         double maxabs = 0.0;
