@@ -189,10 +189,13 @@ typedef struct vk_scene_desc {
  * NEAR form (ABI 6, VK_TREE_REBUILT_NEAR): every sphere behind its OWN box, which is sound for ray origins within a trusted radius of
  * the sphere (~144 radii); a segment's result is taken only if its hit lies within that reach of its origin or the ray provably runs
  * clear of every small sphere beyond it, and every other segment is decided by the tree as handed over (both trees stay in device
- * memory; docs/gate_lemma.md section 7).  It is the default where its reach spans the world's small spheres (the InOneWeekend scene:
- * +20 % throughput over the tree handed over) and where the other form is too dear (BVHNode::new's long leaf boxes on the 1 M-sphere
+ * memory; docs/gate_lemma.md section 7).  It is the default where its reach spans the world's small spheres
+ * and where the other form is too dear (BVHNode::new's long leaf boxes on the 1 M-sphere
  * stress scene: +85 %).  The UNIT form (VK_TREE_REBUILT_PROVEN): the reference's leaf units as gates, grown by the bound — where that is
- * cheap and the near form's reach does not span the world.  A world for which neither form applies is walked as handed over.
+ * cheap and the near form's reach does not span the world.  And, where the world's small spheres lie in a layer across y and the scene
+ * is staged in LDS (the InOneWeekend scene), no tree at all — the GRID form (VK_TREE_REBUILT_GRID): every sphere that can hold a
+ * candidate for the ray is found through a grid over the layer and tested, the winner checked like the other forms' (docs/gate_lemma.md
+ * section 8; +33 % throughput over the tree handed over).  A world for which no form applies is walked as handed over.
  * VK_SCENE_REFERENCE_TREE: walk the tree handed over and nothing else.
  * VK_SCENE_EMPIRICAL_TREES: allow the rebuilt tree also where NEITHER proven form applies (since ABI 6: worlds with a sphere far
  * smaller than the rest; the environment's VK_GATE_PROOF=0 prefers it to the proven forms, for comparisons) — with the units' boxes as
