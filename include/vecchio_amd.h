@@ -185,7 +185,7 @@ typedef struct vk_scene_desc {
  * and whenever its winner is not certain to be the reference's too — a hit not safely behind its own box's entry, a ray from outside
  * the region the bound was derived for — the tree as handed over decides (the segment is walked again, or its sample is rendered by
  * a second launch).  That this reproduces BVHNode::hit is a THEOREM given the bound (the "gate lemma"; forward error analysis, K < 30
- * against the 32 used; tests/test_gate_lemma.py attacks it with 10^7 adversarial rays).  Two proven forms (vk_scene_info.tree).  The
+ * against the 32 used; tests/test_gate_lemma.py attacks it with 10^7 adversarial rays).  Three proven forms (vk_scene_info.tree).  The
  * NEAR form (ABI 6, VK_TREE_REBUILT_NEAR): every sphere behind its OWN box, which is sound for ray origins within a trusted radius of
  * the sphere (~144 radii); a segment's result is taken only if its hit lies within that reach of its origin or the ray provably runs
  * clear of every small sphere beyond it, and every other segment is decided by the tree as handed over (both trees stay in device
