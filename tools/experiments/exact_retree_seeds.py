@@ -13,7 +13,7 @@ from vecchio_amd import DeviceScene, HostScene, ffi  # noqa: E402
 
 total = 0
 bad = 0
-for name, w, spp, seeds in (("random_spheres_iow", 1920, 128, range(2, 42)), ("stress_spheres:500", 4096, 4, range(2, 6)),
+for name, w, spp, seeds in (("random_spheres_iow", 1920, 128, range(2, 82)), ("stress_spheres:500", 4096, 4, range(2, 6)),
                             ("stress_spheres:200", 2048, 8, range(2, 14)), ("stress_spheres:100", 2048, 8, range(2, 10)),
                             ("stress_spheres:60", 1024, 32, range(2, 8))):
     for seed in seeds:
